@@ -1,0 +1,11 @@
+"""dorado_amd — MI355X-native simplex basecalling hot path (conv -> LSTM stack -> CRF head ->
+CRF beam-search decode) behind the reference's ModelRunnerBase boundary.
+
+Layout:
+  csrc/      hand-written gfx950 HIP kernels + the C-ABI shared library (include/mibc.h)
+  config.py  host mirror of dorado/config (BasecallModelConfig, BatchParams)
+  capi.py    ctypes binding of the C-ABI (the only way Python reaches the kernels)
+  runner.py  host mirror of basecall::ModelRunnerBase / BasecallerNode chunk->batch->stitch
+  synth.py   seeded synthetic weights and 5 kHz signal chunks (no network, no real models)
+"""
+__version__ = "0.1.0"

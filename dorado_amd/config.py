@@ -1,0 +1,267 @@
+"""Host-side mirror of the reference's model configuration for the hot path.
+
+Follows dorado/config/BasecallModelConfig.cpp:214-323 (load_lstm_model_config),
+dorado/config/common.cpp:53-87 (conv parsing, swish->swish_clamp when followed by a clamp),
+dorado/config/BatchParams.cpp:89-105 (normalise) and
+dorado/utils/include/utils/parameters.h:7-15 (defaults: chunk 10000, overlap 500).
+"""
+from __future__ import annotations
+
+import ctypes
+import dataclasses
+import os
+from typing import List, Optional
+
+ACT_SWISH, ACT_SWISH_CLAMP, ACT_TANH = 0, 1, 2  # config/common.h Activation order
+
+DEFAULT_CHUNK_SIZE = 10000
+DEFAULT_OVERLAP = 500
+
+
+class ModelDescC(ctypes.Structure):
+    """C layout of `mibc_model_desc` (include/mibc.h). oracle/ restates the same layout."""
+
+    _fields_ = [
+        ("n_convs", ctypes.c_int),
+        ("conv_insize", ctypes.c_int * 8),
+        ("conv_size", ctypes.c_int * 8),
+        ("conv_winlen", ctypes.c_int * 8),
+        ("conv_stride", ctypes.c_int * 8),
+        ("conv_act", ctypes.c_int * 8),
+        ("lstm_size", ctypes.c_int),
+        ("lstm_layers", ctypes.c_int),
+        ("state_len", ctypes.c_int),
+        ("outsize", ctypes.c_int),
+        ("bias", ctypes.c_int),
+        ("clamp", ctypes.c_int),
+        ("scale", ctypes.c_float),
+        ("out_features", ctypes.c_int),
+        ("num_features", ctypes.c_int),
+        ("tx_d_model", ctypes.c_int),
+        ("tx_nhead", ctypes.c_int),
+        ("tx_depth", ctypes.c_int),
+        ("tx_dim_ff", ctypes.c_int),
+        ("tx_win_upper", ctypes.c_int),
+        ("tx_win_lower", ctypes.c_int),
+        ("tx_max_seq_len", ctypes.c_int),
+        ("tx_deepnorm_alpha", ctypes.c_float),
+        ("tx_theta", ctypes.c_float),
+        ("up_size", ctypes.c_int),
+        ("up_scale_factor", ctypes.c_int),
+        ("crf_scale", ctypes.c_float),
+        ("crf_blank_score", ctypes.c_float),
+        ("crf_expand_blanks", ctypes.c_int),
+    ]
+
+
+@dataclasses.dataclass
+class ConvParams:
+    insize: int
+    size: int
+    winlen: int
+    stride: int = 1
+    activation: int = ACT_SWISH
+
+
+@dataclasses.dataclass
+class ModelConfig:
+    """The subset of BasecallModelConfig (config/include/config/BasecallModelConfig.h:99-160)
+    the hot path reads."""
+
+    convs: List[ConvParams]
+    lstm_size: int
+    lstm_layers: int = 5
+    state_len: int = 4
+    bias: bool = False
+    clamp: bool = True
+    scale: float = 1.0
+    blank_score: float = 2.0
+    out_features: Optional[int] = None
+    num_features: int = 1
+    qscale: float = 1.0
+    qbias: float = 0.0
+    sample_rate: int = 5000
+    chunk_size: int = DEFAULT_CHUNK_SIZE
+    overlap: int = DEFAULT_OVERLAP
+    name: str = "synthetic"
+
+    @property
+    def stride(self) -> int:
+        s = 1
+        for c in self.convs:
+            s *= c.stride
+        return s
+
+    @property
+    def outsize(self) -> int:
+        return 4 ** (self.state_len + 1)
+
+    @property
+    def num_states(self) -> int:
+        return 4 ** self.state_len
+
+    def normalise_basecaller_params(self) -> None:
+        """BatchParams::normalise (BatchParams.cpp:89-105): overlap -> multiple of stride,
+        chunk -> multiple of the granularity (= stride for LSTM models)."""
+        stride = self.stride
+        self.overlap = (self.overlap // stride) * stride
+        self.chunk_size = (self.chunk_size // stride) * stride
+        if self.chunk_size <= self.overlap:
+            raise ValueError("chunk_size must be greater than overlap")
+
+    def n_weights(self) -> int:
+        n = 2 * len(self.convs) + 4 * self.lstm_layers + 1
+        if self.out_features is not None:
+            n += 1 + (1 if self.bias else 0)
+        elif not (self.convs[0].size > 4 and self.num_features == 1):
+            n += 1  # pre-v4: linear bias
+        return n
+
+    def to_desc(self) -> ModelDescC:
+        d = ModelDescC()
+        d.n_convs = len(self.convs)
+        for i, c in enumerate(self.convs):
+            d.conv_insize[i] = c.insize
+            d.conv_size[i] = c.size
+            d.conv_winlen[i] = c.winlen
+            d.conv_stride[i] = c.stride
+            d.conv_act[i] = c.activation
+        d.lstm_size = self.lstm_size
+        d.lstm_layers = self.lstm_layers
+        d.state_len = self.state_len
+        d.outsize = self.outsize
+        d.bias = int(self.bias)
+        d.clamp = int(self.clamp)
+        d.scale = self.scale
+        d.out_features = self.out_features if self.out_features is not None else -1
+        d.num_features = self.num_features
+        d.tx_d_model = 0
+        return d
+
+
+def hac_v43() -> ModelConfig:
+    """dna_r10.4.1_e8.2_400bps_hac@v4.3.0 (tests/data/model_configs/.../config.toml)."""
+    cfg = ModelConfig(
+        convs=[
+            ConvParams(1, 16, 5, 1, ACT_SWISH),
+            ConvParams(16, 16, 5, 1, ACT_SWISH),
+            ConvParams(16, 384, 19, 6, ACT_TANH),
+        ],
+        lstm_size=384,
+        lstm_layers=5,
+        state_len=4,
+        clamp=True,
+        qscale=1.1,
+        qbias=-1.1,
+        name="dna_r10.4.1_e8.2_400bps_hac@v4.3.0",
+    )
+    cfg.normalise_basecaller_params()
+    return cfg
+
+
+def sup_v43() -> ModelConfig:
+    """dna_r10.4.1_e8.2_400bps_sup@v4.3.0 — config NOT in the reference tree; topology
+    inferred in SURVEY.md §8 (C=1024, state_len 5)."""
+    cfg = ModelConfig(
+        convs=[
+            ConvParams(1, 16, 5, 1, ACT_SWISH),
+            ConvParams(16, 16, 5, 1, ACT_SWISH),
+            ConvParams(16, 1024, 19, 6, ACT_TANH),
+        ],
+        lstm_size=1024,
+        lstm_layers=5,
+        state_len=5,
+        clamp=True,
+        name="dna_r10.4.1_e8.2_400bps_sup@v4.3.0(inferred)",
+    )
+    cfg.normalise_basecaller_params()
+    return cfg
+
+
+def tiny(C: int = 64, state_len: int = 3, stride: int = 6) -> ModelConfig:
+    """Small same-topology model for fast parity tests."""
+    cfg = ModelConfig(
+        convs=[
+            ConvParams(1, 16, 5, 1, ACT_SWISH),
+            ConvParams(16, 16, 5, 1, ACT_SWISH),
+            ConvParams(16, C, 19, stride, ACT_TANH),
+        ],
+        lstm_size=C,
+        lstm_layers=5,
+        state_len=state_len,
+        clamp=True,
+        name=f"tiny-{C}-{state_len}",
+    )
+    cfg.normalise_basecaller_params()
+    return cfg
+
+
+def load_model_config(path: str) -> ModelConfig:
+    """Parse `<path>/config.toml` (v4-type LSTM models) the way
+    BasecallModelConfig.cpp:214-323 does."""
+    import tomli
+
+    with open(os.path.join(path, "config.toml"), "rb") as f:
+        t = tomli.load(f)
+    enc = t["encoder"]
+    if "type" not in enc:
+        raise NotImplementedError("pre-v4 model configs are not supported yet")
+    if any(s.get("type") in ("upsample",) for s in enc["sublayers"]) or "transformer_encoder" in enc:
+        raise NotImplementedError("transformer configs are handled in a later round")
+    subs = enc["sublayers"]
+    convs: List[ConvParams] = []
+    lstm_layers = 0
+    out_features = None
+    bias = False
+    scale = 1.0
+    blank_score = 2.0
+    clamp = any(s["type"] == "clamp" for s in subs)
+    for i, s in enumerate(subs):
+        ty = s["type"]
+        if ty == "convolution":
+            nxt_clamp = i + 1 < len(subs) and subs[i + 1]["type"] == "clamp"
+            act = s["activation"]
+            if act == "swish":
+                a = ACT_SWISH_CLAMP if nxt_clamp else ACT_SWISH
+            elif act == "tanh":
+                a = ACT_TANH
+            else:
+                raise ValueError(f"Unknown activation: `{act}`")
+            convs.append(ConvParams(s["insize"], s["size"], s["winlen"], s["stride"], a))
+        elif ty == "lstm":
+            lstm_layers += 1
+        elif ty == "linear":
+            out_features = int(s["out_features"])
+        elif ty == "linearcrfencoder":
+            blank_score = float(s["blank_score"])
+            scale = float(s.get("scale", 1.0))
+    lstm_size = convs[-1].size
+    for s in subs:
+        if s["type"] == "linear":
+            bias = bool(s.get("bias", lstm_size > 128))
+    if len(convs) != 3:
+        raise ValueError(f"Expected 3 convolution layers but found: {len(convs)}")
+    q = t.get("qscore", {})
+    cfg = ModelConfig(
+        convs=convs,
+        lstm_size=lstm_size,
+        lstm_layers=lstm_layers,
+        state_len=int(t["global_norm"]["state_len"]),
+        bias=bias,
+        clamp=clamp,
+        scale=scale,
+        blank_score=blank_score,
+        out_features=out_features,
+        num_features=int(t["input"]["features"]),
+        qscale=float(q.get("scale", 1.0)),
+        qbias=float(q.get("bias", 0.0)),
+        sample_rate=int(t.get("run_info", {}).get("sample_rate", -1)),
+        name=os.path.basename(os.path.normpath(path)),
+    )
+    bc = t.get("basecaller", {})
+    if "chunksize" in bc:
+        cfg.chunk_size = int(bc["chunksize"])
+    if "overlap" in bc:
+        cfg.overlap = int(bc["overlap"])
+    cfg.normalise_basecaller_params()
+    return cfg

@@ -1,0 +1,868 @@
+/* oracle/oracle.c — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C (f32) restatement of the reference's simplex-basecalling hot path, function by
+ * function, each citing the reference file:line it follows (paths relative to
+ * /root/reference/dorado).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library; the product (dorado_amd/) never does.
+ *
+ * Pinning: every function here is checked (tests/test_oracle_*.py, `-m "not gpu"`) against
+ *   (1) the golden vectors the reference's own tests hold (tests/ChunkTest.cpp:28-39,
+ *       tests/StitchTest.cpp:10-99) and
+ *   (2) outputs of the reference itself compiled in place (oracle/_ref/libdorado_ref.so),
+ *       committed as fixtures under tests/golden/ by tests/golden/make_golden.py.
+ * The reference holds NO golden vectors for the network/decoder, so for those
+ * rows the pin is (2) only.
+ *
+ * Two transcendental modes (last argument `det` of the decode functions):
+ *   det = 0: glibc expf/logf/log1pf — the natural restatement.
+ *   det = 1: a fixed fmaf-only polynomial exp/log (det_expf/det_logf below) that the HIP
+ *            decoder evaluates with the identical operation sequence, so that the integer
+ *            outputs (moves, bases) can be compared BIT-EXACTLY between CPU and GPU.
+ * Build with -ffp-contract=off (see oracle/Makefile) so no a*b+c is fused behind our back.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * Deterministic transcendental kernel (shared definition with dorado_amd/csrc/detmath.h —
+ * restated there, not included from here).
+ * ---------------------------------------------------------------------------------------- */
+static inline float bits_to_f(uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline uint32_t f_to_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
+/* exp(x) for x <= 0 (and small positive); returns 0 below -103. */
+static float det_expf(float x) {
+    if (x < -103.0f) {
+        return 0.0f;
+    }
+    if (x > 88.0f) {
+        x = 88.0f;
+    }
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, x);       /* ln2 hi */
+    r = fmaf(n, -1.42860682030941723212e-6f, r);     /* ln2 lo */
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    p = fmaf(p, r2, r);
+    p = p + 1.0f;
+    /* scale by 2^n in two steps so that n down to -149 stays exact until the final rounding */
+    const int ni = (int)n;
+    const int n1 = ni / 2, n2 = ni - n1;
+    p = p * bits_to_f((uint32_t)(n1 + 127) << 23);
+    p = p * bits_to_f((uint32_t)(n2 + 127) << 23);
+    return p;
+}
+
+/* log(x) for finite x > 0 (normal). */
+static float det_logf(float x) {
+    uint32_t ix = f_to_bits(x);
+    int e = (int)(ix >> 23) - 127;
+    ix = (ix & 0x007fffffu) | 0x3f800000u; /* m in [1,2) */
+    float m = bits_to_f(ix);
+    if (m > 1.41421356237f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    const float f = m - 1.0f;
+    const float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, f, -1.1514610310e-1f);
+    p = fmaf(p, f, 1.1676998740e-1f);
+    p = fmaf(p, f, -1.2420140846e-1f);
+    p = fmaf(p, f, 1.4249322787e-1f);
+    p = fmaf(p, f, -1.6668057665e-1f);
+    p = fmaf(p, f, 2.0000714765e-1f);
+    p = fmaf(p, f, -2.4999993993e-1f);
+    p = fmaf(p, f, 3.3333331174e-1f);
+    float y = (f * z) * p;
+    const float fe = (float)e;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(-0.5f, z, y);
+    float r = f + y;
+    r = fmaf(fe, 0.693359375f, r);
+    return r;
+}
+
+static inline float m_exp(float x, int det) { return det ? det_expf(x) : expf(x); }
+static inline float m_log(float x, int det) { return det ? det_logf(x) : logf(x); }
+
+ORC_API float orc_det_expf(float x) { return det_expf(x); }
+ORC_API float orc_det_logf(float x) { return det_logf(x); }
+
+/* ------------------------------------------------------------------------------------------
+ * a12: chunking and stitching (integer, bit-exact contract)
+ * ---------------------------------------------------------------------------------------- */
+
+/* read_pipeline/base/chunk.cpp:11-47.  Returns the number of offsets (written to out, at most
+ * max_out of them), or -1 for the argument combinations on which the reference throws. */
+ORC_API long orc_generate_chunks(uint64_t num_samples, uint64_t chunk_size, uint64_t stride,
+                                 uint64_t overlap, uint64_t *out, long max_out) {
+    if (num_samples == 0 || stride == 0) {
+        return -1;
+    }
+    if (chunk_size == 0 || (chunk_size % stride) != 0 || chunk_size <= overlap) {
+        return -1;
+    }
+    if ((overlap % stride) != 0) {
+        return -1;
+    }
+    long n = 0;
+    if (n < max_out) {
+        out[n] = 0;
+    }
+    ++n;
+    uint64_t last = (num_samples > chunk_size) ? (num_samples - chunk_size) : 0;
+    const uint64_t mis = last % stride;
+    if (mis != 0) {
+        last += stride - mis;
+    }
+    const uint64_t step = chunk_size - overlap;
+    uint64_t off = 0;
+    while (off + chunk_size < num_samples) {
+        off = (off + step < last) ? (off + step) : last;
+        if (n < max_out) {
+            out[n] = off;
+        }
+        ++n;
+    }
+    return n;
+}
+
+/* read_pipeline/base/stitch.cpp:12-96.  Chunks i = 0..n-1 with input_offset[i],
+ * raw_chunk_size[i], per-chunk moves (T_i each, concatenated; moves_off[i] = start), seq/qstr
+ * (concatenated; seq_off[i], seq_len[i]).  Outputs the stitched read; returns the stitched
+ * sequence length, *n_moves_out the number of moves. */
+ORC_API long orc_stitch_chunks(int n_chunks, const int64_t *input_offset,
+                               const int64_t *raw_chunk_size, const uint8_t *moves,
+                               const int64_t *moves_off, const int64_t *moves_len, const char *seq,
+                               const char *qstr, const int64_t *seq_off, const int64_t *seq_len,
+                               int64_t raw_samples, int model_stride, char *seq_out,
+                               char *qstr_out, uint8_t *moves_out, int64_t *n_moves_out) {
+    int64_t so = 0, mo = 0;
+    int start_pos = 0, mid_front = 0;
+    for (int i = 0; i < n_chunks - 1; ++i) {
+        const int overlap_size =
+                (int)((raw_chunk_size[i] + input_offset[i]) - input_offset[i + 1]);
+        const int overlap_ds = overlap_size / model_stride;
+        const int mid_rear = overlap_ds / 2;
+        const uint8_t *mv = moves + moves_off[i];
+        const int64_t ml = moves_len[i];
+        int trim = 0;
+        for (int64_t j = ml - mid_rear; j < ml; ++j) {
+            trim += mv[j];
+        }
+        const int end_pos = (int)seq_len[i] - trim;
+        const int trimmed = end_pos - start_pos;
+        memcpy(seq_out + so, seq + seq_off[i] + start_pos, (size_t)trimmed);
+        memcpy(qstr_out + so, qstr + seq_off[i] + start_pos, (size_t)trimmed);
+        so += trimmed;
+        for (int64_t j = mid_front; j < ml - mid_rear; ++j) {
+            moves_out[mo++] = mv[j];
+        }
+        mid_front = overlap_ds - mid_rear;
+        start_pos = 0;
+        const uint8_t *nmv = moves + moves_off[i + 1];
+        for (int j = 0; j < mid_front; ++j) {
+            start_pos += nmv[j];
+        }
+    }
+    const int L = n_chunks - 1;
+    const uint8_t *lmv = moves + moves_off[L];
+    for (int64_t j = mid_front; j < moves_len[L]; ++j) {
+        moves_out[mo++] = lmv[j];
+    }
+    if (n_chunks == 1) {
+        const int64_t keep = raw_samples / model_stride;
+        if (mo > keep) {
+            mo = keep;
+        }
+        int end = 0;
+        for (int64_t j = 0; j < mo; ++j) {
+            end += moves_out[j];
+        }
+        /* substr(start_pos, end) clamps to the string length */
+        int64_t avail = seq_len[L] - start_pos;
+        int64_t take = end < avail ? end : avail;
+        if (take < 0) take = 0;
+        memcpy(seq_out + so, seq + seq_off[L] + start_pos, (size_t)take);
+        memcpy(qstr_out + so, qstr + seq_off[L] + start_pos, (size_t)take);
+        so += take;
+    } else {
+        const int64_t take = seq_len[L] - start_pos;
+        memcpy(seq_out + so, seq + seq_off[L] + start_pos, (size_t)take);
+        memcpy(qstr_out + so, qstr + seq_off[L] + start_pos, (size_t)take);
+        so += take;
+    }
+    /* remove partial stride overhang (stitch.cpp:85-95) */
+    if (mo > raw_samples / model_stride) {
+        if (moves_out[mo - 1] == 1) {
+            --so;
+        }
+        --mo;
+    }
+    *n_moves_out = mo;
+    return so;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a2-a4: network layers (f32, activations NTC)
+ * ---------------------------------------------------------------------------------------- */
+static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+/* nn/ConvStack.cpp:103-113 (Conv1d, padding = winlen/2) and :146-163 (activation).
+ * in [N,T_in,Cin], W [Cout,Cin,win] (torch layout), out [N,T_out,Cout].
+ * act: 0 swish, 1 swish clamp(<=3.5), 2 tanh.  Returns T_out. */
+ORC_API int orc_conv1d(const float *in, int N, int T_in, int Cin, const float *W, const float *b,
+                       int Cout, int win, int stride, int act, float *out) {
+    const int pad = win / 2;
+    const int T_out = (T_in + 2 * pad - win) / stride + 1;
+    if (!out) {
+        return T_out;
+    }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n) {
+        for (int t = 0; t < T_out; ++t) {
+            const float *xin = in + (size_t)n * T_in * Cin;
+            float *y = out + ((size_t)n * T_out + t) * Cout;
+            for (int co = 0; co < Cout; ++co) {
+                float acc = b ? b[co] : 0.0f;
+                const float *w = W + (size_t)co * Cin * win;
+                for (int k = 0; k < win; ++k) {
+                    const int ti = t * stride + k - pad;
+                    if (ti < 0 || ti >= T_in) {
+                        continue;
+                    }
+                    const float *xv = xin + (size_t)ti * Cin;
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        acc += w[ci * win + k] * xv[ci];
+                    }
+                }
+                float v;
+                if (act == 2) {
+                    v = tanhf(acc);
+                } else {
+                    v = acc * sigmoidf_(acc);
+                    if (act == 1 && v > 3.5f) {
+                        v = 3.5f;
+                    }
+                }
+                y[co] = v;
+            }
+        }
+    }
+    return T_out;
+}
+
+/* One uni-directional LSTM layer; nn/LSTMStack.cpp:19-27 (torch::nn::LSTM(size,size),
+ * batch_first) with torch's gate order i,f,g,o, zero initial state, bias_ih + bias_hh.
+ * `reverse` = process t from T-1 down to 0 (the flip()s of LSTMStack.cpp:29-41 expressed in
+ * original time).  in/out [N,T,C]. */
+ORC_API void orc_lstm_layer(const float *in, int N, int T, int C, const float *Wih,
+                            const float *Whh, const float *bih, const float *bhh, int reverse,
+                            float *out) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int n = 0; n < N; ++n) {
+        float *h = (float *)calloc((size_t)C, sizeof(float));
+        float *c = (float *)calloc((size_t)C, sizeof(float));
+        float *g = (float *)malloc((size_t)4 * C * sizeof(float));
+        for (int step = 0; step < T; ++step) {
+            const int t = reverse ? (T - 1 - step) : step;
+            const float *x = in + ((size_t)n * T + t) * C;
+            for (int j = 0; j < 4 * C; ++j) {
+                const float *wi = Wih + (size_t)j * C;
+                const float *wh = Whh + (size_t)j * C;
+                float a0 = 0.f, a1 = 0.f;
+                for (int k = 0; k < C; ++k) {
+                    a0 += wi[k] * x[k];
+                }
+                for (int k = 0; k < C; ++k) {
+                    a1 += wh[k] * h[k];
+                }
+                g[j] = (a0 + bih[j]) + (a1 + bhh[j]);
+            }
+            float *y = out + ((size_t)n * T + t) * C;
+            for (int j = 0; j < C; ++j) {
+                const float ig = sigmoidf_(g[j]);
+                const float fg = sigmoidf_(g[C + j]);
+                const float gg = tanhf(g[2 * C + j]);
+                const float og = sigmoidf_(g[3 * C + j]);
+                c[j] = fg * c[j] + ig * gg;
+                h[j] = og * tanhf(c[j]);
+                y[j] = h[j];
+            }
+        }
+        free(h);
+        free(c);
+        free(g);
+    }
+}
+
+/* nn/CRFModules.cpp:24-34: y = x W^T (+ b); optional tanh * scale.  W [Cout,Cin]. */
+ORC_API void orc_linear(const float *in, long rows, int Cin, const float *W, const float *b,
+                        int Cout, int use_tanh, float scale, float *out) {
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < rows; ++r) {
+        const float *x = in + (size_t)r * Cin;
+        float *y = out + (size_t)r * Cout;
+        for (int j = 0; j < Cout; ++j) {
+            const float *w = W + (size_t)j * Cin;
+            float a = 0.f;
+            for (int k = 0; k < Cin; ++k) {
+                a += w[k] * x[k];
+            }
+            if (b) {
+                a += b[j];
+            }
+            if (use_tanh) {
+                a = tanhf(a) * scale;
+            }
+            y[j] = a;
+        }
+    }
+}
+
+/* nn/CRFModules.cpp:128-134 */
+ORC_API void orc_clamp(float *x, long n, float lo, float hi) {
+    for (long i = 0; i < n; ++i) {
+        x[i] = x[i] < lo ? lo : (x[i] > hi ? hi : x[i]);
+    }
+}
+
+/* Same field layout as RefModelDesc in oracle/ref_driver.cpp. */
+typedef struct {
+    int n_convs;
+    int conv_insize[8], conv_size[8], conv_winlen[8], conv_stride[8];
+    int conv_act[8];
+    int lstm_size, lstm_layers;
+    int state_len, outsize;
+    int bias;
+    int clamp;
+    float scale;
+    int out_features;
+    int num_features;
+    int tx_d_model, tx_nhead, tx_depth, tx_dim_ff, tx_win_upper, tx_win_lower, tx_max_seq_len;
+    float tx_deepnorm_alpha, tx_theta;
+    int up_size, up_scale_factor;
+    float crf_scale, crf_blank_score;
+    int crf_expand_blanks;
+} orc_model_desc;
+
+/* basecall/model/CRFModel.cpp:29-62 (assembly; three head variants) + :127 (Sequential
+ * forward).  weights in module.parameters() order = crf_utils.cpp:34-88:
+ *   conv{i}.weight, conv{i}.bias ...; rnn{l}.{weight_ih,weight_hh,bias_ih,bias_hh} ...;
+ *   linear1.weight [, linear1.bias] [, linear2.weight]
+ * in [N, num_features, T_in] f32 (NCT, as the runner hands it over); scores_out [N,T,K].
+ * If layer_out != NULL it receives the activations entering the linear head [N,T,C].
+ * Returns T. */
+ORC_API int orc_lstm_crf_forward(const orc_model_desc *d, const float *const *weights,
+                                 const float *in_NCT, int N, int T_in, float *scores_out,
+                                 float *layer_out) {
+    int wi = 0;
+    const int F = d->num_features;
+    float *cur = (float *)malloc((size_t)N * T_in * F * sizeof(float));
+    for (int n = 0; n < N; ++n)
+        for (int f = 0; f < F; ++f)
+            for (int t = 0; t < T_in; ++t)
+                cur[((size_t)n * T_in + t) * F + f] = in_NCT[((size_t)n * F + f) * T_in + t];
+    int T = T_in, C = F;
+    for (int i = 0; i < d->n_convs; ++i) {
+        const int To = orc_conv1d(cur, N, T, C, NULL, NULL, d->conv_size[i], d->conv_winlen[i],
+                                  d->conv_stride[i], d->conv_act[i], NULL);
+        float *nxt = (float *)malloc((size_t)N * To * d->conv_size[i] * sizeof(float));
+        orc_conv1d(cur, N, T, C, weights[wi], weights[wi + 1], d->conv_size[i], d->conv_winlen[i],
+                   d->conv_stride[i], d->conv_act[i], nxt);
+        wi += 2;
+        free(cur);
+        cur = nxt;
+        T = To;
+        C = d->conv_size[i];
+    }
+    /* LSTMStack(layers, size, reverse_first = true): layer 0 reversed, then alternating. */
+    float *buf = (float *)malloc((size_t)N * T * C * sizeof(float));
+    for (int l = 0; l < d->lstm_layers; ++l) {
+        const int reverse = (l % 2 == 0);
+        orc_lstm_layer(cur, N, T, C, weights[wi], weights[wi + 1], weights[wi + 2],
+                       weights[wi + 3], reverse, buf);
+        wi += 4;
+        float *tmp = cur;
+        cur = buf;
+        buf = tmp;
+    }
+    free(buf);
+    if (layer_out) {
+        memcpy(layer_out, cur, (size_t)N * T * C * sizeof(float));
+    }
+    const long rows = (long)N * T;
+    const int tanh_x5 = (d->scale == 5.0f);
+    if (d->out_features > 0) {
+        const int D = d->out_features;
+        float *mid = (float *)malloc((size_t)rows * D * sizeof(float));
+        const float *w1 = weights[wi++];
+        const float *b1 = d->bias ? weights[wi++] : NULL;
+        orc_linear(cur, rows, C, w1, b1, D, 0, 1.0f, mid);
+        orc_linear(mid, rows, D, weights[wi++], NULL, d->outsize, tanh_x5, 5.0f, scores_out);
+        free(mid);
+        if (d->clamp) {
+            orc_clamp(scores_out, rows * d->outsize, -5.0f, 5.0f);
+        }
+    } else if (d->conv_size[0] > 4 && d->num_features == 1) {
+        orc_linear(cur, rows, C, weights[wi++], NULL, d->outsize, tanh_x5, 5.0f, scores_out);
+        if (d->clamp) {
+            orc_clamp(scores_out, rows * d->outsize, -5.0f, 5.0f);
+        }
+    } else {
+        const float *w1 = weights[wi++];
+        const float *b1 = weights[wi++];
+        orc_linear(cur, rows, C, w1, b1, d->outsize, 1, 5.0f, scores_out);
+    }
+    free(cur);
+    return T;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a7-a8: CRF scans and posteriors (one chunk; scores [T,K] with K = 4S, index s*4 + b)
+ * ---------------------------------------------------------------------------------------- */
+static inline float lse5(float v0, float v1, float v2, float v3, float v4, int det) {
+    /* at::logsumexp over {stay, step0..3} (CPUDecoder.cpp:28-34): max, sum of exp, log */
+    float m = v0;
+    m = v1 > m ? v1 : m;
+    m = v2 > m ? v2 : m;
+    m = v3 > m ? v3 : m;
+    m = v4 > m ? v4 : m;
+    float s = m_exp(v0 - m, det);
+    s += m_exp(v1 - m, det);
+    s += m_exp(v2 - m, det);
+    s += m_exp(v3 - m, det);
+    s += m_exp(v4 - m, det);
+    return m + m_log(s, det);
+}
+
+/* decode/CPUDecoder.cpp:43-64 + scan :17-38.  alpha[0] = 0;
+ * alpha[t+1][s] = LSE(alpha[t][s] + stay, alpha[t][pred_b(s)] + M[t][s*4+b]),
+ * pred_b(s) = (s >> 2) + b*(S/4)  (idx = arange(S).repeat_interleave(4).reshape(4,-1).t()). */
+ORC_API void orc_forward_scores(const float *scores, int T, int S, float stay, float *fwd,
+                                int det) {
+    for (int s = 0; s < S; ++s) {
+        fwd[s] = 0.0f;
+    }
+    const int Q = S / 4;
+    for (int t = 0; t < T; ++t) {
+        const float *M = scores + (size_t)t * S * 4;
+        const float *a = fwd + (size_t)t * S;
+        float *o = fwd + (size_t)(t + 1) * S;
+        for (int s = 0; s < S; ++s) {
+            const int p = s >> 2;
+            o[s] = lse5(a[s] + stay, a[p] + M[s * 4 + 0], a[p + Q] + M[s * 4 + 1],
+                        a[p + 2 * Q] + M[s * 4 + 2], a[p + 3 * Q] + M[s * 4 + 3], det);
+        }
+    }
+}
+
+/* decode/CPUDecoder.cpp:66-92.  beta[T] = 0;
+ * beta[t][s] = LSE(beta[t+1][s] + stay, beta[t+1][succ_b(s)] + M[t][succ_b(s)*4 + (s >> 2(L-1))]),
+ * succ_b(s) = ((s << 2) & (S-1)) | b   (idx_T = idx.flatten().argsort(); states idx_T >> 2). */
+ORC_API void orc_backward_scores(const float *scores, int T, int S, float stay, float *bwd,
+                                 int det) {
+    float *last = bwd + (size_t)T * S;
+    for (int s = 0; s < S; ++s) {
+        last[s] = 0.0f;
+    }
+    const int Q = S / 4;
+    for (int t = T - 1; t >= 0; --t) {
+        const float *M = scores + (size_t)t * S * 4;
+        const float *a = bwd + (size_t)(t + 1) * S;
+        float *o = bwd + (size_t)t * S;
+        for (int s = 0; s < S; ++s) {
+            const int hi = s / Q;            /* base that falls off the front */
+            const int n0 = (s << 2) & (S - 1);
+            o[s] = lse5(a[s] + stay, a[n0] + M[(n0 + 0) * 4 + hi], a[n0 + 1] + M[(n0 + 1) * 4 + hi],
+                        a[n0 + 2] + M[(n0 + 2) * 4 + hi], a[n0 + 3] + M[(n0 + 3) * 4 + hi], det);
+        }
+    }
+}
+
+/* decode/CPUDecoder.cpp:130: posts = softmax(fwd + bwd, -1) per timestep. */
+ORC_API void orc_posts(const float *fwd, const float *bwd, int T, int S, float *posts, int det) {
+    for (int t = 0; t <= T; ++t) {
+        const float *f = fwd + (size_t)t * S, *b = bwd + (size_t)t * S;
+        float *p = posts + (size_t)t * S;
+        float m = f[0] + b[0];
+        for (int s = 1; s < S; ++s) {
+            const float v = f[s] + b[s];
+            m = v > m ? v : m;
+        }
+        float sum = 0.f;
+        for (int s = 0; s < S; ++s) {
+            p[s] = m_exp((f[s] + b[s]) - m, det);
+            sum += p[s];
+        }
+        for (int s = 0; s < S; ++s) {
+            p[s] = p[s] / sum;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a9: beam search (decode/beam_search.cpp:125-520), float scores / float posts instantiation
+ * ---------------------------------------------------------------------------------------- */
+#define ORC_MAX_BEAM 256
+#define ORC_FLT_LOWEST (-3.402823466e+38f)
+
+/* beam_search.cpp:104-121, reversed CRC32C polynomial, LSB first */
+static uint32_t crc32c_bits(uint32_t crc, uint32_t bits, int nbits) {
+    for (int i = 0; i < nbits; ++i) {
+        const uint32_t b = (bits ^ crc) & 1u;
+        crc >>= 1;
+        if (b) {
+            crc ^= 0x82f63b78u;
+        }
+        bits >>= 1;
+    }
+    return crc;
+}
+
+/* beam_search.cpp:42-45 */
+static float log_sum_exp2(float x, float y, int det) {
+    const float d = fabsf(x - y);
+    const float m = x > y ? x : y;
+    if (!(d < 17.0f)) {
+        return m + 0.0f;
+    }
+    if (det) {
+        return m + det_logf(1.0f + det_expf(-d));
+    }
+    return m + log1pf(expf(-d));
+}
+
+static int cmp_desc(const void *a, const void *b) {
+    const float x = *(const float *)a, y = *(const float *)b;
+    return (x < y) - (x > y);
+}
+
+ORC_API float orc_beam_search(const float *scores, long block_stride, const float *back_guide,
+                              const float *posts, int num_state_bits, int num_blocks,
+                              int max_beam_width, float beam_cut, float fixed_stay_score,
+                              int32_t *states, uint8_t *moves, float *qual_data, int det) {
+    const int S = 1 << num_state_bits;
+    const uint32_t mask = (uint32_t)(S - 1);
+    const int W = max_beam_width;
+    if (W > ORC_MAX_BEAM) {
+        return NAN;
+    }
+    const float log_cut = (beam_cut > 0.0f) ? logf(beam_cut) : 3.402823466e+38f;
+    const int CAND = 5 * W;
+
+    /* persistent beam: (T+1) x W of {state, prev, stay} (beam_search.cpp:153) */
+    uint16_t *bv_state = (uint16_t *)calloc((size_t)W * (num_blocks + 1), sizeof(uint16_t));
+    uint8_t *bv_prev = (uint8_t *)calloc((size_t)W * (num_blocks + 1), 1);
+    uint8_t *bv_stay = (uint8_t *)calloc((size_t)W * (num_blocks + 1), 1);
+
+    uint32_t *c_hash = (uint32_t *)calloc((size_t)CAND, 4), *p_hash = (uint32_t *)calloc((size_t)CAND, 4);
+    uint16_t *c_state = (uint16_t *)calloc((size_t)CAND, 2), *p_state = (uint16_t *)calloc((size_t)CAND, 2);
+    uint8_t *c_prev = (uint8_t *)calloc((size_t)CAND, 1), *p_prev = (uint8_t *)calloc((size_t)CAND, 1);
+    uint8_t *c_stay = (uint8_t *)calloc((size_t)CAND, 1), *p_stay = (uint8_t *)calloc((size_t)CAND, 1);
+    float *c_score = (float *)calloc((size_t)CAND, 4), *p_score = (float *)calloc((size_t)CAND, 4);
+
+    /* seed (beam_search.cpp:165-198) */
+    float thr = ORC_FLT_LOWEST;
+    if (W < S) {
+        float *tmp = (float *)malloc((size_t)S * 4);
+        memcpy(tmp, back_guide, (size_t)S * 4);
+        qsort(tmp, (size_t)S, 4, cmp_desc);
+        thr = tmp[W - 1];
+        free(tmp);
+    }
+    int ne = 0;
+    for (int s = 0; s < S && ne < W; ++s) {
+        if (back_guide[s] >= thr) {
+            p_hash[ne] = crc32c_bits(0x12345678u, (uint32_t)s, 32);
+            p_state[ne] = (uint16_t)s;
+            p_prev[ne] = 0;
+            p_stay[ne] = 0;
+            p_score[ne] = 0.0f;
+            ++ne;
+        }
+    }
+    int width = W < S ? W : S;
+    for (int i = 0; i < width; ++i) {
+        bv_state[i] = p_state[i];
+        bv_prev[i] = p_prev[i];
+        bv_stay[i] = p_stay[i];
+    }
+
+    uint8_t present[4096 / 8];
+    for (int blk = 0; blk < num_blocks; ++blk) {
+        const float *bs = scores + (size_t)blk * block_stride;
+        const float *bg = back_guide + ((size_t)(blk + 1) << num_state_bits);
+        float max_score = ORC_FLT_LOWEST;
+        memset(present, 0, sizeof(present));
+
+        /* steps (beam_search.cpp:236-260): slot 4e+b */
+        int cnt = 0;
+        for (int e = 0; e < width; ++e) {
+            const uint32_t ps = p_state[e];
+            for (int b = 0; b < 4; ++b) {
+                const uint16_t ns = (uint16_t)(((ps << 2) & mask) | (uint32_t)b);
+                const uint16_t mi = (uint16_t)(((uint32_t)ns << 2) + ((ps << 2) >> num_state_bits));
+                const float sc = p_score[e] + bs[mi] + bg[ns];
+                const uint32_t h = crc32c_bits(p_hash[e], (uint32_t)b, 2);
+                present[(h & 4095u) >> 3] |= (uint8_t)(1u << (h & 7u));
+                c_hash[cnt] = h;
+                c_state[cnt] = ns;
+                c_prev[cnt] = (uint8_t)e;
+                c_stay[cnt] = 0;
+                c_score[cnt] = sc;
+                max_score = sc > max_score ? sc : max_score;
+                ++cnt;
+            }
+        }
+        /* stays + merge (beam_search.cpp:262-308): slot 4*width + e */
+        for (int e = 0; e < width; ++e) {
+            const float sc = p_score[e] + fixed_stay_score + bg[p_state[e]];
+            c_hash[cnt] = p_hash[e];
+            c_state[cnt] = p_state[e];
+            c_prev[cnt] = (uint8_t)e;
+            c_stay[cnt] = 1;
+            c_score[cnt] = sc;
+            max_score = sc > max_score ? sc : max_score;
+            const uint32_t hb = p_hash[e] & 4095u;
+            if (present[hb >> 3] & (1u << (hb & 7u))) {
+                const int si = (width << 2) + e;
+                const int lb = p_state[e] & 3;
+                for (int e2 = 0; e2 < width; ++e2) {
+                    const int ti = (e2 << 2) | lb;
+                    if (c_hash[si] == c_hash[ti]) {
+                        const float folded = log_sum_exp2(c_score[si], c_score[ti], det);
+                        if (c_score[si] > c_score[ti]) {
+                            c_score[si] = folded;
+                            c_score[ti] = ORC_FLT_LOWEST;
+                        } else {
+                            c_score[ti] = folded;
+                            c_score[si] = ORC_FLT_LOWEST;
+                        }
+                        max_score = folded > max_score ? folded : max_score;
+                    }
+                }
+            }
+            ++cnt;
+        }
+
+        /* cut-off (beam_search.cpp:310-396) */
+        float cutoff = max_score - log_cut;
+        int ec = 0;
+        for (int i = 0; i < cnt; ++i) ec += (c_score[i] >= cutoff);
+        if (ec > W) {
+            const int minw = (W * 8) / 10;
+            float lo = cutoff, hi = max_score;
+            int guesses = 1;
+            while ((ec > W || ec < minw) && guesses < 10) {
+                if (ec > W) {
+                    lo = cutoff;
+                    cutoff = (cutoff + hi) / 2.0f;
+                } else {
+                    hi = cutoff;
+                    cutoff = (cutoff + lo) / 2.0f;
+                }
+                ec = 0;
+                for (int i = 0; i < cnt; ++i) ec += (c_score[i] >= cutoff);
+                ++guesses;
+            }
+            if (guesses == 10) {
+                cutoff = hi;
+                ec = 0;
+                for (int i = 0; i < cnt; ++i) ec += (c_score[i] >= cutoff);
+            }
+            if (ec > W) ec = W;
+        }
+
+        /* compaction in slot order (beam_search.cpp:398-409) */
+        int wr = 0;
+        for (int i = 0; i < cnt; ++i) {
+            if (c_score[i] >= cutoff) {
+                if (wr < W) {
+                    p_hash[wr] = c_hash[i];
+                    p_state[wr] = c_state[i];
+                    p_prev[wr] = c_prev[i];
+                    p_stay[wr] = c_stay[i];
+                    p_score[wr] = c_score[i];
+                    ++wr;
+                } else {
+                    break;
+                }
+            }
+        }
+
+        /* last block: best into slot 0 (beam_search.cpp:413-424) */
+        if (blk == num_blocks - 1) {
+            float best = ORC_FLT_LOWEST;
+            int bi = 0;
+            for (int i = 0; i < ec; ++i) {
+                if (p_score[i] > best) {
+                    best = p_score[i];
+                    bi = i;
+                }
+            }
+#define SWP(T_, a_, b_) do { T_ t_ = (a_); (a_) = (b_); (b_) = t_; } while (0)
+            SWP(uint32_t, p_hash[0], p_hash[bi]);
+            SWP(uint16_t, p_state[0], p_state[bi]);
+            SWP(uint8_t, p_prev[0], p_prev[bi]);
+            SWP(uint8_t, p_stay[0], p_stay[bi]);
+            SWP(float, p_score[0], p_score[bi]);
+        }
+
+        /* store (beam_search.cpp:426-437) */
+        const size_t off = (size_t)(blk + 1) * W;
+        for (int i = 0; i < ec; ++i) {
+            p_score[i] -= bg[p_state[i]];
+            bv_state[off + i] = p_state[i];
+            bv_prev[off + i] = p_prev[i];
+            bv_stay[off + i] = p_stay[i];
+        }
+        width = ec;
+    }
+    const float final_score = p_score[0];
+
+    /* trace back (beam_search.cpp:448-455) */
+    uint8_t ei = 0;
+    for (int bi = num_blocks; bi != 0; --bi) {
+        const size_t a = (size_t)bi * W + ei;
+        states[bi - 1] = (int32_t)bv_state[a];
+        moves[bi - 1] = bv_stay[a] ? 0 : 1;
+        ei = bv_prev[a];
+    }
+    moves[0] = 1;
+
+    /* per-block quality (beam_search.cpp:459-517) */
+    for (int blk = 0; blk < num_blocks; ++blk) {
+        const int state = states[blk];
+        states[blk] = state % 4;
+        const int base = states[blk];
+        const float *tp = posts + ((size_t)(blk + 1) << num_state_bits);
+        float prob = tp[state];
+        const int l_idx = state >> 2;
+        const int r_idx = (state << 2) % S;
+        const int msb = S >> 2;
+        int sh[8];
+        for (int b = 0; b < 4; ++b) {
+            sh[2 * b] = l_idx + msb * b;
+            sh[2 * b + 1] = r_idx + b;
+        }
+        for (int i = 0; i < 8; ++i) {
+            const int cs = sh[i];
+            int count = (cs != state);
+            if (count) {
+                for (int j = 0; j < i; ++j) {
+                    if (sh[j] == cs) {
+                        count = 0;
+                        break;
+                    }
+                }
+            }
+            if (count) {
+                prob += tp[cs];
+            }
+        }
+        prob = prob < 0.0f ? 0.0f : (prob > 1.0f ? 1.0f : prob);
+        prob = powf(prob, 0.4f);
+        const float wrong = (1.0f - prob) / 3.0f;
+        for (int b = 0; b < 4; ++b) {
+            qual_data[blk * 4 + b] = (b == base) ? prob : wrong;
+        }
+    }
+
+    free(bv_state); free(bv_prev); free(bv_stay);
+    free(c_hash); free(p_hash); free(c_state); free(p_state);
+    free(c_prev); free(p_prev); free(c_stay); free(p_stay);
+    free(c_score); free(p_score);
+    return final_score;
+}
+
+/* a10: decode/beam_search.cpp:54-102.  Returns the sequence length; seq/qstr get that many
+ * bytes (no terminator). */
+ORC_API int orc_generate_sequence(const uint8_t *moves, const int32_t *states, const float *qual,
+                                  int num_blocks, float shift, float scale, char *seq,
+                                  char *qstr) {
+    int len = 0;
+    for (int i = 0; i < num_blocks; ++i) len += moves[i];
+    float *bp = (float *)calloc((size_t)len + 1, 4), *tp = (float *)calloc((size_t)len + 1, 4);
+    static const char alphabet[4] = {'A', 'C', 'G', 'T'};
+    int pos = 0;
+    for (int blk = 0; blk < num_blocks; ++blk) {
+        const int base = states[blk] & 3;
+        const int mv = moves[blk];
+        const int ppos = pos + (blk == 0 ? 0 : mv - 1);
+        bp[ppos] += qual[blk * 4 + base];
+        for (int k = 0; k < 4; ++k) tp[ppos] += qual[blk * 4 + k];
+        if (blk == 0) {
+            seq[pos++] = alphabet[base];
+        } else {
+            for (int j = 0; j < mv; ++j) seq[pos++] = alphabet[base];
+        }
+    }
+    for (int i = 0; i < len; ++i) {
+        float e = 1.0f - (bp[i] / tp[i]);
+        e = -10.0f * log10f(e);
+        float q = e * scale + shift;
+        q = q < 1.0f ? 1.0f : (q > 50.0f ? 50.0f : q);
+        qstr[i] = (char)(33.5f + q);
+    }
+    free(bp);
+    free(tp);
+    return len;
+}
+
+/* One chunk end to end: CPUDecoder.cpp:127-144 + beam_search.cpp:522-606.
+ * scores [T,K] f32.  moves[T]; seq/qstr capacity T.  Optional fwd/bwd/posts out ([T+1,S]). */
+ORC_API int orc_decode_chunk(const float *scores, int T, int K, int beam_width, float beam_cut,
+                             float blank, float q_shift, float q_scale, uint8_t *moves, char *seq,
+                             char *qstr, float *bwd_out, float *posts_out, int det) {
+    const int S = K / 4;
+    int bits = 0;
+    while ((1 << bits) < S) ++bits;
+    float *fwd = (float *)malloc((size_t)(T + 1) * S * 4);
+    float *bwd = (float *)malloc((size_t)(T + 1) * S * 4);
+    float *posts = (float *)malloc((size_t)(T + 1) * S * 4);
+    orc_forward_scores(scores, T, S, blank, fwd, det);
+    orc_backward_scores(scores, T, S, blank, bwd, det);
+    orc_posts(fwd, bwd, T, S, posts, det);
+    int32_t *states = (int32_t *)malloc((size_t)T * 4);
+    float *qual = (float *)malloc((size_t)T * 16);
+    orc_beam_search(scores, K, bwd, posts, bits, T, beam_width, beam_cut, blank, states, moves,
+                    qual, det);
+    const int len = orc_generate_sequence(moves, states, qual, T, q_shift, q_scale, seq, qstr);
+    if (bwd_out) memcpy(bwd_out, bwd, (size_t)(T + 1) * S * 4);
+    if (posts_out) memcpy(posts_out, posts, (size_t)(T + 1) * S * 4);
+    free(fwd); free(bwd); free(posts); free(states); free(qual);
+    return len;
+}
+
+/* Batch: scores [N,T,K]; outputs [N,T] planes (NUL padded) + seqlen[N]. */
+ORC_API void orc_decode_batch(const float *scores, int N, int T, int K, int beam_width,
+                              float beam_cut, float blank, float q_shift, float q_scale,
+                              uint8_t *moves, char *seq, char *qstr, int *seqlen, int det) {
+    memset(seq, 0, (size_t)N * T);
+    memset(qstr, 0, (size_t)N * T);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int n = 0; n < N; ++n) {
+        seqlen[n] = orc_decode_chunk(scores + (size_t)n * T * K, T, K, beam_width, beam_cut,
+                                     blank, q_shift, q_scale, moves + (size_t)n * T,
+                                     seq + (size_t)n * T, qstr + (size_t)n * T, NULL, NULL, det);
+    }
+}

@@ -1,0 +1,187 @@
+"""ctypes bindings for the CPU oracle (oracle/liboracle.so, the C restatement) and, when
+built, the compiled reference (oracle/_ref/libdorado_ref.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by
+dorado_amd/."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liboracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libdorado_ref.so")
+
+_f32p = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def build(with_ref: bool = True) -> None:
+    subprocess.check_call(["make", "-s", "-C", HERE])
+    if with_ref and os.path.isdir("/root/reference/dorado"):
+        subprocess.check_call(["make", "-s", "-C", HERE, "-f", "Makefile.ref", "-j8"])
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f32p)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            build(with_ref=False)
+        _lib = C.CDLL(ORACLE_SO)
+        _lib.orc_beam_search.restype = C.c_float
+        _lib.orc_generate_chunks.restype = C.c_long
+        _lib.orc_stitch_chunks.restype = C.c_long
+        _lib.orc_det_expf.restype = C.c_float
+        _lib.orc_det_expf.argtypes = [C.c_float]
+        _lib.orc_det_logf.restype = C.c_float
+        _lib.orc_det_logf.argtypes = [C.c_float]
+    return _lib
+
+
+_ref = None
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        import torch  # noqa: F401  (libtorch must be loaded first)
+
+        _ref = C.CDLL(REF_SO)
+        _ref.ref_last_error.restype = C.c_char_p
+    return _ref
+
+
+# ---------------------------------------------------------------- chunk / stitch
+def generate_chunks(num_samples, chunk_size, stride, overlap, use_ref=False):
+    cap = 1 << 16
+    out = (C.c_uint64 * cap)()
+    if use_ref:
+        n = ref().ref_generate_chunks(C.c_uint64(num_samples), C.c_uint64(chunk_size),
+                                      C.c_uint64(stride), C.c_uint64(overlap), out, cap)
+    else:
+        n = lib().orc_generate_chunks(C.c_uint64(num_samples), C.c_uint64(chunk_size),
+                                      C.c_uint64(stride), C.c_uint64(overlap), out, C.c_long(cap))
+    if n < 0:
+        raise ValueError("generate_chunks: invalid arguments")
+    return [int(out[i]) for i in range(n)]
+
+
+def stitch_chunks(offsets, raw_chunk_sizes, moves_list, seqs, qstrs, raw_samples, stride):
+    n = len(offsets)
+    moves = np.concatenate([np.asarray(m, np.uint8) for m in moves_list])
+    mlen = np.array([len(m) for m in moves_list], np.int64)
+    moff = np.concatenate([[0], np.cumsum(mlen)[:-1]]).astype(np.int64)
+    slen = np.array([len(s) for s in seqs], np.int64)
+    soff = np.concatenate([[0], np.cumsum(slen)[:-1]]).astype(np.int64)
+    seq = "".join(seqs).encode()
+    qs = "".join(qstrs).encode()
+    cap = int(slen.sum()) + 8
+    so = C.create_string_buffer(cap)
+    qo = C.create_string_buffer(cap)
+    mo = np.zeros(int(mlen.sum()) + 8, np.uint8)
+    nm = C.c_int64(0)
+    io = np.asarray(offsets, np.int64)
+    rc = np.asarray(raw_chunk_sizes, np.int64)
+    i64p = C.POINTER(C.c_int64)
+    L = lib().orc_stitch_chunks(C.c_int(n), io.ctypes.data_as(i64p), rc.ctypes.data_as(i64p),
+                                moves.ctypes.data_as(_u8p), moff.ctypes.data_as(i64p),
+                                mlen.ctypes.data_as(i64p), seq, qs, soff.ctypes.data_as(i64p),
+                                slen.ctypes.data_as(i64p), C.c_int64(raw_samples), C.c_int(stride),
+                                so, qo, mo.ctypes.data_as(_u8p), C.byref(nm))
+    return so.raw[:L].decode(), qo.raw[:L].decode(), mo[: nm.value].copy()
+
+
+# ---------------------------------------------------------------- network
+def _wptrs(weights):
+    ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+    arr = (_f32p * len(ws))(*[_fp(w) for w in ws])
+    return ws, arr
+
+
+def lstm_crf_forward(cfg, weights, x_f32_NCT, use_ref=False, want_layer=False):
+    """x [N, F, T_in] f32 -> scores [N, T, K] f32."""
+    x = np.ascontiguousarray(x_f32_NCT, np.float32)
+    N, F, T_in = x.shape
+    T = T_in // cfg.stride + 2
+    K = cfg.outsize
+    d = cfg.to_desc()
+    ws, arr = _wptrs(weights)
+    scores = np.zeros((N, T, K), np.float32)
+    if use_ref:
+        r = ref()
+        T_out = r.ref_forward(C.byref(d), arr, len(ws), _fp(x), N, T_in, _fp(scores),
+                              C.c_int64(scores.size))
+        if T_out < 0:
+            raise RuntimeError(r.ref_last_error().decode())
+        return scores.reshape(-1)[: N * T_out * K].reshape(N, T_out, K).copy()
+    layer = np.zeros((N, T, cfg.lstm_size), np.float32) if want_layer else None
+    T_out = lib().orc_lstm_crf_forward(C.byref(d), arr, _fp(x), N, T_in, _fp(scores),
+                                       _fp(layer) if want_layer else None)
+    s = scores.reshape(-1)[: N * T_out * K].reshape(N, T_out, K).copy()
+    if want_layer:
+        return s, layer.reshape(-1)[: N * T_out * cfg.lstm_size].reshape(N, T_out, -1).copy()
+    return s
+
+
+# ---------------------------------------------------------------- decoder
+def scans(scores_NTK, blank=2.0, use_ref=False, det=0):
+    s = np.ascontiguousarray(scores_NTK, np.float32)
+    N, T, K = s.shape
+    S = K // 4
+    fwd = np.zeros((N, T + 1, S), np.float32)
+    bwd = np.zeros_like(fwd)
+    posts = np.zeros_like(fwd)
+    if use_ref:
+        r = ref()
+        if r.ref_scans(_fp(s), N, T, K, C.c_float(blank), _fp(fwd), _fp(bwd), _fp(posts)) != 0:
+            raise RuntimeError(r.ref_last_error().decode())
+        return fwd, bwd, posts
+    L = lib()
+    for n in range(N):
+        L.orc_forward_scores(_fp(s[n]), T, S, C.c_float(blank), _fp(fwd[n]), det)
+        L.orc_backward_scores(_fp(s[n]), T, S, C.c_float(blank), _fp(bwd[n]), det)
+        L.orc_posts(_fp(fwd[n]), _fp(bwd[n]), T, S, _fp(posts[n]), det)
+    return fwd, bwd, posts
+
+
+def decode(scores_NTK, beam_width=32, beam_cut=100.0, blank=2.0, q_shift=0.0, q_scale=1.0,
+           use_ref=False, det=0):
+    """-> list of (sequence, qstring, moves[T] u8)."""
+    s = np.ascontiguousarray(scores_NTK, np.float32)
+    N, T, K = s.shape
+    moves = np.zeros((N, T), np.uint8)
+    seq = np.zeros((N, T), np.uint8)
+    qs = np.zeros((N, T), np.uint8)
+    lens = np.zeros((N,), np.int32)
+    i32p = C.POINTER(C.c_int)
+    cp = C.POINTER(C.c_char)
+    if use_ref:
+        r = ref()
+        rc = r.ref_decode(_fp(s), N, T, K, beam_width, C.c_float(beam_cut), C.c_float(blank),
+                          C.c_float(q_shift), C.c_float(q_scale), moves.ctypes.data_as(_u8p),
+                          seq.ctypes.data_as(cp), qs.ctypes.data_as(cp), lens.ctypes.data_as(i32p))
+        if rc != 0:
+            raise RuntimeError(r.ref_last_error().decode())
+    else:
+        lib().orc_decode_batch(_fp(s), N, T, K, beam_width, C.c_float(beam_cut), C.c_float(blank),
+                               C.c_float(q_shift), C.c_float(q_scale), moves.ctypes.data_as(_u8p),
+                               seq.ctypes.data_as(cp), qs.ctypes.data_as(cp),
+                               lens.ctypes.data_as(i32p), det)
+    out = []
+    for n in range(N):
+        L = int(lens[n])
+        out.append((seq[n, :L].tobytes().decode(), qs[n, :L].tobytes().decode(), moves[n].copy()))
+    return out

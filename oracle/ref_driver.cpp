@@ -1,0 +1,278 @@
+// oracle/ref_driver.cpp — TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Thin extern "C" driver around the *reference's own* CPU hot path, compiled in place from
+// /root/reference/dorado (see oracle/Makefile.ref): CRFModel / TxModel (libtorch CPU, f32),
+// CPUDecoder (scans + posts + beam_search) and utils::generate_chunks.  This file is our code;
+// it contains no reference source, it only *calls* the reference classes:
+//   dorado/basecall/model/CRFModel.cpp:29-62,117-128     (model assembly + forward)
+//   dorado/basecall/model/TxModel.cpp:10-41
+//   dorado/basecall/decode/CPUDecoder.cpp:43-92,100-157  (scans, posts, beam search)
+//   dorado/basecall/ModelRunner.cpp:32-45               (NTC -> TNC, decode options)
+//   dorado/read_pipeline/base/chunk.cpp:11-47
+// Used to (a) pin oracle/oracle.c (the C restatement) and (b) generate tests/golden/*.
+#include "basecall/decode/CPUDecoder.h"
+#include "basecall/model/CRFModel.h"
+#include "basecall/model/TxModel.h"
+#include "config/BasecallModelConfig.h"
+#include "read_pipeline/base/chunk.h"
+
+#include <torch/torch.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace dorado;
+
+extern "C" {
+
+struct RefModelDesc {
+    // convolutions
+    int n_convs;
+    int conv_insize[8], conv_size[8], conv_winlen[8], conv_stride[8];
+    int conv_act[8];  // 0 swish, 1 swish_clamp, 2 tanh  (config/common.h Activation)
+    // LSTM-CRF
+    int lstm_size, lstm_layers;
+    int state_len, outsize;
+    int bias;          // linear bias (pre-v4)
+    int clamp;         // clamp +-5
+    float scale;       // 5.0 => tanh*5 head
+    int out_features;  // -1 = no decomposition
+    int num_features;
+    // Tx (d_model <= 0 => LSTM model)
+    int tx_d_model, tx_nhead, tx_depth, tx_dim_ff, tx_win_upper, tx_win_lower, tx_max_seq_len;
+    float tx_deepnorm_alpha, tx_theta;
+    int up_size, up_scale_factor;
+    float crf_scale, crf_blank_score;
+    int crf_expand_blanks;
+};
+
+static thread_local std::string g_err;
+const char *ref_last_error() { return g_err.c_str(); }
+
+}  // extern "C" (helpers below have C++ linkage)
+
+static config::BasecallModelConfig make_config(const RefModelDesc &d) {
+    config::BasecallModelConfig c;
+    for (int i = 0; i < d.n_convs; ++i) {
+        config::ConvParams p;
+        p.insize = d.conv_insize[i];
+        p.size = d.conv_size[i];
+        p.winlen = d.conv_winlen[i];
+        p.stride = d.conv_stride[i];
+        p.activation = static_cast<config::Activation>(d.conv_act[i]);
+        c.convs.push_back(p);
+    }
+    c.lstm_size = d.lstm_size;
+    c.lstm_layers = d.lstm_layers;
+    c.state_len = d.state_len;
+    c.outsize = d.outsize;
+    c.bias = d.bias != 0;
+    c.clamp = d.clamp != 0;
+    c.scale = d.scale;
+    c.blank_score = 2.0f;
+    c.num_features = d.num_features;
+    if (d.out_features > 0) {
+        c.out_features = d.out_features;
+    }
+    c.stride = 1;
+    for (int i = 0; i < d.n_convs; ++i) {
+        c.stride *= d.conv_stride[i];
+    }
+    if (d.tx_d_model > 0) {
+        config::TxStack tx;
+        tx.tx.d_model = d.tx_d_model;
+        tx.tx.nhead = d.tx_nhead;
+        tx.tx.depth = d.tx_depth;
+        tx.tx.dim_feedforward = d.tx_dim_ff;
+        tx.tx.attn_window = {d.tx_win_upper, d.tx_win_lower};
+        tx.tx.deepnorm_alpha = d.tx_deepnorm_alpha;
+        tx.tx.theta = d.tx_theta;
+        tx.tx.max_seq_len = d.tx_max_seq_len;
+        tx.upsample.size = d.up_size;
+        tx.upsample.scale_factor = d.up_scale_factor;
+        tx.crf.insize = d.up_size;
+        tx.crf.n_base = 4;
+        tx.crf.state_len = d.state_len;
+        tx.crf.scale = d.crf_scale;
+        tx.crf.blank_score = d.crf_blank_score;
+        tx.crf.expand_blanks = d.crf_expand_blanks != 0;
+        tx.crf.permute = {};
+        c.tx = tx;
+    }
+    return c;
+}
+
+template <typename M>
+static int load_flat(M &module, const float *const *weights, int n_weights) {
+    auto params = module->parameters();
+    if (int(params.size()) != n_weights) {
+        g_err = "weight count mismatch: module has " + std::to_string(params.size()) + ", got " +
+                std::to_string(n_weights);
+        return -1;
+    }
+    std::vector<at::Tensor> ws;
+    for (size_t i = 0; i < params.size(); ++i) {
+        at::Tensor t = torch::empty_like(params[i], torch::kFloat32);
+        std::memcpy(t.data_ptr(), weights[i], sizeof(float) * t.numel());
+        ws.push_back(t);
+    }
+    module->load_state_dict(ws);
+    return 0;
+}
+
+extern "C" {
+
+// Number of parameters and their element counts, in module.parameters() order (the order
+// basecall/crf_utils.cpp:34-88 / :100-147 loads them in).
+int ref_param_numels(const RefModelDesc *d, int64_t *numels, int max_n) {
+    try {
+        torch::InferenceMode guard;
+        auto cfg = make_config(*d);
+        std::vector<at::Tensor> params;
+        if (cfg.is_tx_model()) {
+            basecall::model::TxModel m(cfg, at::TensorOptions().dtype(torch::kFloat32));
+            params = m->parameters();
+        } else {
+            basecall::model::CRFModel m(cfg);
+            params = m->parameters();
+        }
+        int n = int(params.size());
+        for (int i = 0; i < n && i < max_n; ++i) {
+            numels[i] = params[i].numel();
+        }
+        return n;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// Forward pass exactly as basecall/ModelRunner.cpp:32-36 drives it (f32, CPU).  in: [N, C, T_in]
+// f32. out: scores [N, T, K] f32 (NTC); returns T (or <0 on error).
+int ref_forward(const RefModelDesc *d,
+                const float *const *weights,
+                int n_weights,
+                const float *in_NCT,
+                int N,
+                int T_in,
+                float *scores_NTK,
+                int64_t scores_capacity) {
+    try {
+        torch::InferenceMode guard;
+        torch::set_num_threads(1);  // torch_utils/torch_utils.cpp:20
+        auto cfg = make_config(*d);
+        auto x = torch::from_blob(const_cast<float *>(in_NCT), {N, d->num_features, T_in},
+                                  torch::kFloat32)
+                         .clone();
+        at::Tensor y;
+        if (cfg.is_tx_model()) {
+            basecall::model::TxModel m(cfg, at::TensorOptions().dtype(torch::kFloat32));
+            if (load_flat(m, weights, n_weights) != 0) {
+                return -1;
+            }
+            m->eval();
+            y = m->forward(x, nullptr);
+        } else {
+            basecall::model::CRFModel m(cfg);
+            if (load_flat(m, weights, n_weights) != 0) {
+                return -1;
+            }
+            m->eval();
+            y = m->forward(x, nullptr);
+        }
+        y = y.contiguous();
+        if (y.numel() > scores_capacity) {
+            g_err = "scores buffer too small";
+            return -2;
+        }
+        std::memcpy(scores_NTK, y.data_ptr<float>(), sizeof(float) * y.numel());
+        return int(y.size(1));
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// CRF scans + posteriors (decode/CPUDecoder.cpp:43-92,130). scores [N,T,K] f32 ->
+// fwd/bwd/posts [N,T+1,S] f32 (any may be null).
+int ref_scans(const float *scores_NTK, int N, int T, int K, float blank, float *fwd, float *bwd,
+              float *posts) {
+    try {
+        torch::InferenceMode guard;
+        torch::set_num_threads(1);
+        auto s_TNC = torch::from_blob(const_cast<float *>(scores_NTK), {N, T, K}, torch::kFloat32)
+                             .transpose(0, 1)
+                             .contiguous();
+        auto f = basecall::decode::inner::forward_scores(s_TNC, blank);
+        auto b = basecall::decode::inner::backward_scores(s_TNC, blank);
+        auto p = at::softmax(f + b, -1);
+        auto put = [&](const at::Tensor &t, float *dst) {
+            if (dst) {
+                auto c = t.transpose(0, 1).contiguous();
+                std::memcpy(dst, c.data_ptr<float>(), sizeof(float) * c.numel());
+            }
+        };
+        put(f, fwd);
+        put(b, bwd);
+        put(p, posts);
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// Full CPU decode of a batch (decode/CPUDecoder.cpp:100-157 -> beam_search.cpp:522-606).
+// scores [N,T,K] f32. Outputs are [N,T] byte planes: moves (0/1), seq (ASCII, NUL padded),
+// qstr (ASCII, NUL padded); seqlen[N].
+int ref_decode(const float *scores_NTK, int N, int T, int K, int beam_width, float beam_cut,
+               float blank, float q_shift, float q_scale, uint8_t *moves, char *seq, char *qstr,
+               int *seqlen) {
+    try {
+        torch::InferenceMode guard;
+        torch::set_num_threads(1);
+        auto s_TNC = torch::from_blob(const_cast<float *>(scores_NTK), {N, T, K}, torch::kFloat32)
+                             .transpose(0, 1)
+                             .contiguous();
+        basecall::decode::DecoderOptions o;
+        o.beam_width = size_t(beam_width);
+        o.beam_cut = beam_cut;
+        o.blank_score = blank;
+        o.q_shift = q_shift;
+        o.q_scale = q_scale;
+        basecall::decode::CPUDecoder dec;
+        auto chunks = dec.beam_search_part_2(dec.beam_search_part_1({s_TNC, N, o}));
+        std::memset(seq, 0, size_t(N) * T);
+        std::memset(qstr, 0, size_t(N) * T);
+        for (int i = 0; i < N; ++i) {
+            const auto &c = chunks[i];
+            std::memcpy(moves + size_t(i) * T, c.moves.data(), T);
+            std::memcpy(seq + size_t(i) * T, c.sequence.data(), c.sequence.size());
+            std::memcpy(qstr + size_t(i) * T, c.qstring.data(), c.qstring.size());
+            seqlen[i] = int(c.sequence.size());
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// read_pipeline/base/chunk.cpp:11-47. Returns count, or -1 if the reference throws.
+int ref_generate_chunks(uint64_t num_samples, uint64_t chunk_size, uint64_t stride,
+                        uint64_t overlap, uint64_t *out, int max_out) {
+    try {
+        auto v = utils::generate_chunks(num_samples, chunk_size, stride, overlap);
+        for (size_t i = 0; i < v.size() && int(i) < max_out; ++i) {
+            out[i] = v[i];
+        }
+        return int(v.size());
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,165 @@
+"""Pins the CPU oracle (oracle/oracle.c) against
+ (1) the golden vectors the reference's own tests hold for this path
+     (/root/reference/tests/ChunkTest.cpp:28-39, tests/StitchTest.cpp:10-99), and
+ (2) outputs of the reference itself (oracle/_ref, compiled from the reference's sources)
+     committed under tests/golden/ by tests/golden/make_golden.py.
+CPU only."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from dorado_amd import config, synth
+from oracle import oracle_py as O
+
+
+# ---------------------------------------------------------------- a12: chunking
+def test_generate_chunks_reference_known_answers():
+    # tests/ChunkTest.cpp:28-39
+    assert O.generate_chunks(9996 // 2, 9996, 6, 498) == [0]
+    assert O.generate_chunks(9996, 9996, 6, 498) == [0]
+    assert O.generate_chunks(9996 + 1, 9996, 6, 498) == [0, 6]
+    assert O.generate_chunks(9996 + 9996 // 2, 9996, 6, 498) == [0, 4998]
+    assert O.generate_chunks(2 * 9996 + 9996 // 2, 9996, 1, 0) == [0, 9996, 14994]
+    assert O.generate_chunks(3 * 9996, 9996, 6, 498) == [0, 9498, 18996, 19992]
+
+
+@pytest.mark.parametrize("args", [(0, 9996, 6, 498), (12345, 0, 6, 498), (12345, 9996, 0, 498),
+                                  (12345, 9996, 10, 498), (12345, 9996, 7, 498),
+                                  (12345, 9996, 6, 9996), (12345, 9996, 6, 9997)])
+def test_generate_chunks_invalid_input_throws(args):
+    # tests/ChunkTest.cpp:11-25
+    with pytest.raises(ValueError):
+        O.generate_chunks(*args)
+
+
+@pytest.mark.parametrize("cs,st,ov", [(9996, 6, 498), (9996, 7, 497), (9996, 12, 492),
+                                      (9996, 17, 510), (555, 5, 25), (83, 1, 13), (123, 1, 0)])
+def test_generate_chunks_properties(cs, st, ov):
+    # tests/ChunkTest.cpp:44-79 (same property checks, numpy RNG instead of mt19937)
+    rng = np.random.default_rng(42)
+    for n in rng.integers(1024, 2097152, size=16):
+        offs = O.generate_chunks(int(n), cs, st, ov)
+        assert offs and offs[0] == 0
+        for i in range(1, len(offs) - 1):
+            assert offs[i] % st == 0 and offs[i] == i * (cs - ov)
+        assert offs[-1] % st == 0 and offs[-1] < n
+        if len(offs) > 1:
+            assert cs - st <= n - offs[-1] <= cs
+
+
+def test_generate_chunks_vs_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "chunks.npz"))
+    pos = 0
+    for (n, cs, st, ov), cnt in zip(g["args"], g["counts"]):
+        want = g["offsets"][pos:pos + cnt].tolist()
+        pos += cnt
+        assert O.generate_chunks(int(n), int(cs), int(st), int(ov)) == want
+
+
+# ---------------------------------------------------------------- a12: stitching
+def test_stitch_chunks_reference_known_answer():
+    # tests/StitchTest.cpp:10-99
+    RAW, CHUNK, OVERLAP = 50, 10, 3
+    moves = [[1, 0, 0, 1, 0, 0, 1, 0, 1, 0], [1, 0, 0, 1, 0, 0, 0, 1, 0, 1],
+             [1, 0, 0, 1, 0, 1, 1, 0, 0, 0], [1, 0, 0, 1, 0, 0, 1, 0, 1, 0],
+             [0, 1, 0, 1, 0, 0, 1, 0, 1, 0], [1, 0, 0, 0, 0, 0, 1, 0, 1, 1],
+             [1, 0, 0, 1, 0, 0, 1, 0, 1, 0]]
+    offsets = [0]
+    off = 0
+    while off + CHUNK < RAW:
+        off = min(off + CHUNK - OVERLAP, RAW - CHUNK)
+        offsets.append(off)
+    assert len(offsets) == 7
+    # The reference test never sets read_common.raw_data, so get_raw_data_samples() is 0 there and
+    # the "partial stride overhang" branch (stitch.cpp:85-95) drops the final move: 49 moves.
+    seq, qs, mv = O.stitch_chunks(offsets, [CHUNK] * 7, moves, ["ACGT"] * 7, ["!&.-"] * 7, 0, 1)
+    assert seq == "ACGTCGCGTCGTCGTCCGT"
+    assert qs == "!&.-&.&.-&.-&.-&&.-"
+    assert mv.tolist() == [1, 0, 0, 1, 0, 0, 1, 0, 1, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 1, 1, 0, 0, 0,
+                           1, 0, 0, 1, 0, 1, 0, 1, 0, 0, 1, 0, 1, 0, 0, 0, 0, 1, 0, 1, 0, 0, 1, 0, 1]
+
+
+# ---------------------------------------------------------------- a2-a4: network
+def _wcrc(ws):
+    c = 0
+    for w in ws:
+        c = zlib.crc32(np.ascontiguousarray(w).tobytes(), c)
+    return c
+
+
+@pytest.mark.parametrize("name,cfg", [("net_tiny64_s3", config.tiny(64, 3)),
+                                      ("net_tiny128_s4", config.tiny(128, 4))])
+def test_network_matches_reference_fixture(golden_dir, name, cfg):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    ws = synth.make_weights(cfg, seed=int(g["seed"]))
+    assert _wcrc(ws) == int(g["weights_crc"]), "synthetic weight generator drifted; regenerate goldens"
+    x = g["signal_f16"].astype(np.float32)[:, None, :]
+    s = O.lstm_crf_forward(cfg, ws, x)
+    assert s.shape == g["scores"].shape
+    # f32 restatement vs f32 libtorch: only summation order differs
+    assert np.abs(s - g["scores"]).max() < 2e-4
+
+
+# ---------------------------------------------------------------- a7-a10: decoder
+@pytest.mark.parametrize("det", [0, 1])
+@pytest.mark.parametrize("name", ["net_tiny64_s3", "net_tiny128_s4"])
+def test_decode_of_reference_scores_matches_fixture(golden_dir, name, det):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    s = g["scores"]
+    fwd, bwd, posts = O.scans(s, det=det)
+    assert np.abs(bwd - g["bwd"]).max() < 5e-4  # values ~1e3; f32 LSE round-off
+    assert np.abs(posts[:, ::16] - g["posts_sample"]).max() < 1e-4
+    dec = O.decode(s, det=det, q_shift=0.0, q_scale=1.0)  # config.tiny(): qbias 0, qscale 1
+    for i, (seq, qs, mv) in enumerate(dec):
+        L = int(g["seqlen"][i])
+        assert seq == g["seq"][i, :L].tobytes().decode()
+        assert (mv == g["moves"][i]).all()
+        want_q = g["qstr"][i, :L].astype(np.int32)
+        got_q = np.frombuffer(qs.encode(), np.uint8).astype(np.int32)
+        assert np.abs(want_q - got_q).max() <= 1
+
+
+@pytest.mark.parametrize("det", [0, 1])
+@pytest.mark.parametrize("name", ["dec_s3", "dec_s4", "dec_s5"])
+def test_decoder_alone_matches_fixture(golden_dir, name, det):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    s = g["scores_f16"].astype(np.float32)
+    dec = O.decode(s, q_shift=-1.1, q_scale=1.1, det=det)
+    _, bwd, _ = O.scans(s[:1], det=det)
+    assert np.abs(bwd[0, 0] - g["bwd_t0"][0]).max() < 2e-3
+    for i, (seq, qs, mv) in enumerate(dec):
+        L = int(g["seqlen"][i])
+        assert seq == g["seq"][i, :L].tobytes().decode()
+        assert (mv == g["moves"][i]).all()
+        want_q = g["qstr"][i, :L].astype(np.int32)
+        got_q = np.frombuffer(qs.encode(), np.uint8).astype(np.int32)
+        assert np.abs(want_q - got_q).max() <= 1
+
+
+def test_det_math_accuracy():
+    L = O.lib()
+    xs = np.concatenate([-np.logspace(-6, 2, 400), [0.0]]).astype(np.float32)
+    for x in xs:
+        want = np.exp(np.float64(x))
+        got = L.orc_det_expf(float(x))
+        assert abs(got - want) <= 4e-7 * max(want, 1e-30) + 1e-44
+    for x in np.logspace(-3, 3, 400).astype(np.float32):
+        assert abs(L.orc_det_logf(float(x)) - np.log(np.float64(x))) <= 3e-7 * max(1.0, abs(np.log(np.float64(x))))
+
+
+# ---------------------------------------------------------------- live vs compiled reference
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_live_against_compiled_reference():
+    cfg = config.tiny(64, 3)
+    ws = synth.make_weights(cfg, seed=77)
+    x = synth.make_signal(2, 720, seed=78).astype(np.float32)[:, None, :]
+    s_o = O.lstm_crf_forward(cfg, ws, x)
+    s_r = O.lstm_crf_forward(cfg, ws, x, use_ref=True)
+    assert np.abs(s_o - s_r).max() < 2e-4
+    for det in (0, 1):
+        d_o = O.decode(s_r, det=det)
+        d_r = O.decode(s_r, use_ref=True)
+        for a, b in zip(d_o, d_r):
+            assert a[0] == b[0] and (a[2] == b[2]).all()
