@@ -1,0 +1,273 @@
+"""ctypes binding of the C-ABI in include/mibc.h (dorado_amd/libmibc.so).
+
+This is the ONLY way Python reaches the kernels; there is no CPU fallback — if the HIP library
+is missing or no GPU is visible, every entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .config import ModelConfig, ModelDescC
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmibc.so")
+
+MIBC_OK = 0
+MIBC_NOT_SUPPORTED = 1
+
+
+class MibcError(RuntimeError):
+    pass
+
+
+class MibcNotSupported(MibcError):
+    pass
+
+
+class DecodeOptsC(C.Structure):
+    _fields_ = [("beam_width", C.c_int), ("beam_cut", C.c_float), ("blank_score", C.c_float),
+                ("q_shift", C.c_float), ("q_scale", C.c_float)]
+
+
+class StageMsC(C.Structure):
+    _fields_ = [("conv", C.c_float), ("lstm", C.c_float), ("head", C.c_float),
+                ("decode", C.c_float), ("total", C.c_float), ("lstm_layer", C.c_float * 8),
+                ("h2d", C.c_float), ("d2h", C.c_float)]
+
+
+EXPORTS = [
+    "mibc_device_count", "mibc_last_error", "mibc_create", "mibc_destroy", "mibc_query_memory",
+    "mibc_reserve", "mibc_output_steps", "mibc_batch_granularity", "mibc_host_alloc",
+    "mibc_host_free", "mibc_device_alloc", "mibc_device_free", "mibc_memcpy_h2d",
+    "mibc_memcpy_d2h", "mibc_forward", "mibc_decode", "mibc_call_device", "mibc_call",
+    "mibc_sync", "mibc_time_forward", "mibc_get_stage_ms", "mibc_set_profile", "mibc_debug_tap",
+]
+
+
+def build() -> None:
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(HERE, "csrc")])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MibcError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
+                            "g.build()'` (there is no CPU fallback)")
+        try:
+            import torch  # noqa: F401  share torch's libamdhip64 (same SONAME) when it is around
+        except Exception:  # pragma: no cover
+            pass
+        L = C.CDLL(LIB_PATH)
+        L.mibc_last_error.restype = C.c_char_p
+        L.mibc_last_error.argtypes = [C.c_void_p]
+        L.mibc_create.argtypes = [C.c_int, C.POINTER(ModelDescC), C.POINTER(C.POINTER(C.c_float)),
+                                  C.c_int, C.POINTER(C.c_void_p)]
+        L.mibc_destroy.argtypes = [C.c_void_p]
+        L.mibc_destroy.restype = None
+        L.mibc_query_memory.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t),
+                                        C.POINTER(C.c_size_t)]
+        L.mibc_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.mibc_output_steps.argtypes = [C.c_void_p, C.c_int]
+        L.mibc_batch_granularity.argtypes = [C.c_void_p]
+        L.mibc_host_alloc.restype = C.c_void_p
+        L.mibc_host_alloc.argtypes = [C.c_size_t]
+        L.mibc_host_free.argtypes = [C.c_void_p]
+        L.mibc_host_free.restype = None
+        L.mibc_device_alloc.restype = C.c_void_p
+        L.mibc_device_alloc.argtypes = [C.c_void_p, C.c_size_t]
+        L.mibc_device_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.mibc_device_free.restype = None
+        L.mibc_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.mibc_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.mibc_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.mibc_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(DecodeOptsC),
+                                  C.c_void_p]
+        L.mibc_call_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                       C.POINTER(DecodeOptsC), C.c_void_p]
+        L.mibc_call.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(DecodeOptsC),
+                                C.c_void_p]
+        L.mibc_sync.argtypes = [C.c_void_p]
+        L.mibc_time_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.mibc_get_stage_ms.argtypes = [C.c_void_p, C.POINTER(StageMsC)]
+        L.mibc_set_profile.argtypes = [C.c_void_p, C.c_int]
+        L.mibc_debug_tap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def device_count() -> int:
+    return int(lib().mibc_device_count())
+
+
+class Engine:
+    """One engine == one device == one HIP stream (the reference's CudaCaller device half)."""
+
+    def __init__(self, cfg: ModelConfig, weights, device: int = 0, taps: bool = False):
+        L = lib()
+        if device_count() <= device:
+            raise MibcError(f"no HIP device {device} visible (device_count={device_count()}); "
+                            "the HIP path has no CPU fallback")
+        if taps:
+            os.environ["MIBC_TAPS"] = "1"
+        self.cfg = cfg
+        self._desc = cfg.to_desc()
+        ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+        arr = (C.POINTER(C.c_float) * len(ws))(*[w.ctypes.data_as(C.POINTER(C.c_float)) for w in ws])
+        h = C.c_void_p()
+        rc = L.mibc_create(device, C.byref(self._desc), arr, len(ws), C.byref(h))
+        if taps:
+            os.environ.pop("MIBC_TAPS", None)
+        if rc != MIBC_OK:
+            msg = L.mibc_last_error(None).decode()
+            raise (MibcNotSupported if rc > 0 else MibcError)(f"mibc_create: {msg}")
+        self._h = h
+        self.opts = DecodeOptsC(32, 100.0, 2.0, cfg.qbias, cfg.qscale)
+
+    # -- helpers
+    def _check(self, rc, what):
+        if rc != MIBC_OK:
+            msg = lib().mibc_last_error(self._h).decode()
+            raise (MibcNotSupported if rc > 0 else MibcError)(f"{what}: {msg}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mibc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def output_steps(self, t_in: int) -> int:
+        return int(lib().mibc_output_steps(self._h, t_in))
+
+    def reserve(self, n_max: int, t_in: int):
+        self._check(lib().mibc_reserve(self._h, n_max, t_in), "mibc_reserve")
+
+    def query_memory(self, t_in: int):
+        a, b = C.c_size_t(), C.c_size_t()
+        self._check(lib().mibc_query_memory(self._h, t_in, C.byref(a), C.byref(b)), "mibc_query_memory")
+        return int(a.value), int(b.value)
+
+    def device_alloc(self, nbytes: int) -> int:
+        p = lib().mibc_device_alloc(self._h, nbytes)
+        if not p:
+            raise MibcError(f"mibc_device_alloc({nbytes}) failed")
+        return p
+
+    def device_free(self, p: int):
+        lib().mibc_device_free(self._h, p)
+
+    def h2d(self, dst: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self._check(lib().mibc_memcpy_h2d(self._h, dst, arr.ctypes.data, arr.nbytes), "h2d")
+
+    def d2h(self, arr: np.ndarray, src: int):
+        self._check(lib().mibc_memcpy_d2h(self._h, arr.ctypes.data, src, arr.nbytes), "d2h")
+
+    def sync(self):
+        self._check(lib().mibc_sync(self._h), "mibc_sync")
+
+    def set_profile(self, level: int):
+        lib().mibc_set_profile(self._h, level)
+
+    def stage_ms(self) -> dict:
+        s = StageMsC()
+        self._check(lib().mibc_get_stage_ms(self._h, C.byref(s)), "mibc_get_stage_ms")
+        return {"conv": s.conv, "lstm": s.lstm, "head": s.head, "decode": s.decode,
+                "total": s.total, "lstm_layer": [s.lstm_layer[i] for i in range(8)]}
+
+    def time_forward(self, n: int, t_in: int) -> float:
+        ms = C.c_float()
+        self._check(lib().mibc_time_forward(self._h, n, t_in, C.byref(ms)), "mibc_time_forward")
+        return float(ms.value)
+
+    def tap(self, tap: int, shape, dtype) -> np.ndarray:
+        out = np.zeros(shape, dtype)
+        self._check(lib().mibc_debug_tap(self._h, tap, out.ctypes.data, out.nbytes), "mibc_debug_tap")
+        return out
+
+    # -- the hot path (device pointers)
+    def forward_device(self, in_dev: int, n: int, t_in: int, scores_dev: int):
+        self._check(lib().mibc_forward(self._h, in_dev, n, t_in, scores_dev), "mibc_forward")
+
+    def decode_device(self, scores_dev: int, n: int, t: int, out_dev: int):
+        self._check(lib().mibc_decode(self._h, scores_dev, n, t, C.byref(self.opts), out_dev),
+                    "mibc_decode")
+
+    def call_device(self, in_dev: int, n: int, t_in: int, out_dev: int):
+        self._check(lib().mibc_call_device(self._h, in_dev, n, t_in, C.byref(self.opts), out_dev),
+                    "mibc_call_device")
+
+    # -- numpy conveniences (tests / small runs)
+    def forward(self, x_f16: np.ndarray) -> np.ndarray:
+        """x [N, T_in] f16 -> scores [N, T, K] f16."""
+        x = np.ascontiguousarray(x_f16, np.float16)
+        n, t_in = x.shape
+        t = self.output_steps(t_in)
+        k = self.cfg.outsize
+        self.reserve(n, t_in)
+        d_in = self.device_alloc(x.nbytes)
+        d_sc = self.device_alloc(n * t * k * 2)
+        try:
+            self.h2d(d_in, x)
+            self.forward_device(d_in, n, t_in, d_sc)
+            self.sync()
+            out = np.zeros((n, t, k), np.float16)
+            self.d2h(out, d_sc)
+        finally:
+            self.device_free(d_in)
+            self.device_free(d_sc)
+        return out
+
+    def decode(self, scores_f16: np.ndarray, t_in_for_reserve: int | None = None):
+        """scores [N, T, K] f16 -> list of (seq, qstr, moves)."""
+        s = np.ascontiguousarray(scores_f16, np.float16)
+        n, t, k = s.shape
+        t_in = t_in_for_reserve if t_in_for_reserve is not None else t * self.cfg.stride
+        assert self.output_steps(t_in) == t
+        self.reserve(max(64, (n + 63) // 64 * 64), t_in)
+        d_sc = self.device_alloc(s.nbytes)
+        d_out = self.device_alloc(3 * n * t)
+        try:
+            self.h2d(d_sc, s)
+            self.decode_device(d_sc, n, t, d_out)
+            self.sync()
+            out = np.zeros((3, n, t), np.int8)
+            self.d2h(out, d_out)
+        finally:
+            self.device_free(d_sc)
+            self.device_free(d_out)
+        return unpack_planes(out)
+
+    def call(self, x_f16: np.ndarray):
+        """Host batch -> decoded chunks, through mibc_call (H2D + forward + decode + D2H)."""
+        x = np.ascontiguousarray(x_f16, np.float16)
+        n, t_in = x.shape
+        t = self.output_steps(t_in)
+        out = np.zeros((3, n, t), np.int8)
+        self._check(lib().mibc_call(self._h, x.ctypes.data, n, t_in, C.byref(self.opts),
+                                    out.ctypes.data), "mibc_call")
+        return unpack_planes(out)
+
+
+def unpack_planes(out3: np.ndarray):
+    """int8 [3][N][T] (moves | bases | qstring) -> [(seq, qstr, moves[T] u8)], the slicing that
+    CUDADecoder::beam_search_part_2 does (decode/CUDADecoder.cpp:115-173)."""
+    moves, seq, qs = out3[0], out3[1], out3[2]
+    res = []
+    for i in range(moves.shape[0]):
+        nb = int(moves[i].sum())
+        res.append((seq[i, :nb].tobytes().decode("ascii"), qs[i, :nb].tobytes().decode("ascii"),
+                    moves[i].astype(np.uint8)))
+    return res

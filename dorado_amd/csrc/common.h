@@ -1,0 +1,39 @@
+// dorado_amd/csrc/common.h — shared device/host helpers for the mibc HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+#define MIBC_WAVE 64
+
+// D[row][col] layout of v_mfma_f32_32x32x16_f16 (cdna_hip_programming.md §3):
+//   col = lane & 31,  row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5),  reg in [0,16)
+// A operand: lane holds A[i = lane & 31][k = 8 * (lane >> 5) + 0..7]; B likewise with j.
+__device__ __forceinline__ float16_t mfma32x32x16(half8_t a, half8_t b, float16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    // 1 / (1 + e^-x); v_exp_f32 / v_rcp_f32 (~1 ulp), saturates cleanly for large |x|
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    // tanh(x) = 2 sigmoid(2x) - 1
+    return fmaf(2.0f, fast_sigmoid(2.0f * x), -1.0f);
+}
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == 2) {
+        return fast_tanh(v);
+    }
+    float s = v * fast_sigmoid(v);
+    if (act == 1) {
+        s = fminf(s, 3.5f);
+    }
+    return s;
+}

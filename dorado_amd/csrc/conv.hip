@@ -1,0 +1,120 @@
+// dorado_amd/csrc/conv.hip — conv front-end of the LSTM-CRF models.
+//
+// Replaces the reference's torch Conv1d+activation stack (dorado/nn/ConvStack.cpp:146-163) and
+// the Koi call sites host_convolution_f16 (ConvStack.cpp:220) for conv1/conv2.  conv3 runs as an
+// implicit-im2col MFMA GEMM (gemm.hip), the same decomposition as ConvStack.cpp:241-261.
+//
+// conv12_kernel: conv1 (1 -> 16, w5, s1) and conv2 (16 -> 16, w5, s1) fused; conv1's output lives
+// only in LDS (f32).  HBM-bound elementwise-ish work: reads 2 B/sample, writes 32 B/sample.
+// Output layout: a2p [N][Tpitch][16] f16 with `pad` zero rows in front of each chunk (and zero
+// rows behind), so that conv3's im2col row for output step t is the contiguous span
+// a2p[n][stride*t .. stride*t + W)[0..16) — no gather needed.
+#include "common.h"
+
+#define C12_TT 256   // output time steps per workgroup
+#define C12_CH 16
+#define C12_W 5
+#define C12_ROW 20   // padded LDS row (floats): 80 B stride => conflict-free ds_read_b128
+
+template <int ACT1, int ACT2>
+__global__ __launch_bounds__(C12_TT) void conv12_kernel(
+        const half_t *__restrict__ x,    // [N][T_in]
+        const float *__restrict__ w1,    // [5][16]     (k, co)
+        const float *__restrict__ b1,    // [16]
+        const float *__restrict__ w2,    // [5][16][16] (k, ci, co)
+        const float *__restrict__ b2,    // [16]
+        half_t *__restrict__ a2p,        // [N][Tpitch][16]
+        half_t *__restrict__ a1_tap,     // optional [N][T_in][16] (parity tap) or nullptr
+        int T_in, int Tpitch, int pad) {
+    __shared__ float xs[C12_TT + 8];
+    __shared__ __attribute__((aligned(16))) float o1[(C12_TT + 4) * C12_ROW];
+    const int n = blockIdx.y;
+    const int t0 = blockIdx.x * C12_TT;
+    const int tid = threadIdx.x;
+    const half_t *xn = x + (size_t)n * T_in;
+
+    for (int i = tid; i < C12_TT + 8; i += C12_TT) {
+        const int t = t0 - 4 + i;
+        xs[i] = (t >= 0 && t < T_in) ? (float)xn[t] : 0.0f;
+    }
+    __syncthreads();
+    // conv1 at times t0-2 .. t0+TT+1 (row r <-> time t0-2+r); zero outside [0,T_in) = conv2's padding
+    for (int r = tid; r < C12_TT + 4; r += C12_TT) {
+        const int t = t0 - 2 + r;
+        const bool inside = (t >= 0 && t < T_in);
+        float acc[C12_CH];
+#pragma unroll
+        for (int c = 0; c < C12_CH; ++c) acc[c] = b1[c];
+#pragma unroll
+        for (int k = 0; k < C12_W; ++k) {
+            const float xv = xs[r + k];  // time t + k - 2  -> xs index (t-2+k) - (t0-4) = r + k
+#pragma unroll
+            for (int c = 0; c < C12_CH; ++c) acc[c] = fmaf(w1[k * C12_CH + c], xv, acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < C12_CH; ++c) {
+            const float v = inside ? act_apply(acc[c], ACT1) : 0.0f;
+            o1[r * C12_ROW + c] = v;
+        }
+        if (a1_tap != nullptr && inside && r >= 2 && r < C12_TT + 2) {
+#pragma unroll
+            for (int c = 0; c < C12_CH; ++c)
+                a1_tap[((size_t)n * T_in + t) * C12_CH + c] = (half_t)act_apply(acc[c], ACT1);
+        }
+    }
+    __syncthreads();
+    const int t = t0 + tid;
+    if (t >= T_in) {
+        return;
+    }
+    float acc[C12_CH];
+#pragma unroll
+    for (int c = 0; c < C12_CH; ++c) acc[c] = b2[c];
+#pragma unroll
+    for (int k = 0; k < C12_W; ++k) {
+        // input time t + k - 2 -> row (t+k-2) - (t0-2) = tid + k
+        const float4_t *row = (const float4_t *)&o1[(tid + k) * C12_ROW];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4_t v = row[q];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ci = q * 4 + j;
+                const float *w = w2 + (k * C12_CH + ci) * C12_CH;
+#pragma unroll
+                for (int c = 0; c < C12_CH; ++c) acc[c] = fmaf(w[c], v[j], acc[c]);
+            }
+        }
+    }
+    half8_t o0, o1v;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        o0[c] = (half_t)act_apply(acc[c], ACT2);
+        o1v[c] = (half_t)act_apply(acc[8 + c], ACT2);
+    }
+    half8_t *dst = (half8_t *)(a2p + ((size_t)n * Tpitch + pad + t) * C12_CH);
+    dst[0] = o0;
+    dst[1] = o1v;
+}
+
+extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w1, const float *b1,
+                                  const float *w2, const float *b2, half_t *a2p, half_t *a1_tap,
+                                  int N, int T_in, int Tpitch, int pad, int act1, int act2) {
+    dim3 grid((T_in + C12_TT - 1) / C12_TT, N);
+#define LAUNCH(A1, A2)                                                                          \
+    hipLaunchKernelGGL((conv12_kernel<A1, A2>), grid, dim3(C12_TT), 0, s, x, w1, b1, w2, b2, a2p, \
+                       a1_tap, T_in, Tpitch, pad)
+    if (act1 == 0 && act2 == 0) {
+        LAUNCH(0, 0);
+    } else if (act1 == 1 && act2 == 1) {
+        LAUNCH(1, 1);
+    } else if (act1 == 0 && act2 == 1) {
+        LAUNCH(0, 1);
+    } else if (act1 == 1 && act2 == 0) {
+        LAUNCH(1, 0);
+    } else {
+        return 1;
+    }
+#undef LAUNCH
+    return 0;
+}

@@ -1,0 +1,628 @@
+// dorado_amd/csrc/decode.hip — CRF decoder on the GPU.
+//
+// Replaces the reference's CPU decoder (dorado/basecall/decode/CPUDecoder.cpp:17-157 +
+// decode/beam_search.cpp:54-520) and the four closed Koi launches of the CUDA path
+// (decode/CUDADecoder.cpp:76-100: back_guide, beam_search, compute_posts, run_decode) with three
+// kernels.  Compile with -ffp-contract=off: the scan / beam arithmetic is a fixed IEEE operation
+// sequence (detmath.h) so that moves and bases are bit-comparable with the CPU oracle.
+//
+//   k1 bwd_scan_kernel   one workgroup per chunk, one thread per state, T sequential steps:
+//                        beta[t][s] = LSE(beta[t+1][s]+stay, beta[t+1][succ_b(s)]+M[t][succ_b(s),s])
+//                        state vector in LDS (ping-pong), score row prefetched one step ahead and
+//                        staged transposed in LDS ([base][state]) so every read is conflict-free.
+//                        HBM: reads 2K B/step (scores), writes 4S B/step (back-guides).
+//   k2 beam_search_kernel one WAVE per chunk: beam (width <= 32) in registers, 5W candidates in
+//                        LDS, hash-merge / bisection cut-off / in-order compaction with wave
+//                        ballots; trace (4 B x W per step) to HBM, traced back through LDS tiles.
+//   k3 posts_qual_kernel one workgroup per chunk: forward scan fused with the posterior of the
+//                        called k-mer (+ its shifted neighbours) — posts[T+1][S] never touches
+//                        HBM —, then sequence / qstring emission.
+#include "common.h"
+#include "detmath.h"
+
+#define FLT_LOWEST (-3.402823466e+38f)
+
+__device__ __forceinline__ float clampf(float v, float c) {
+    return (c > 0.0f) ? fminf(fmaxf(v, -c), c) : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k1: backward scan (decode/CPUDecoder.cpp:66-92 + scan :17-38)
+// ---------------------------------------------------------------------------------------------
+__global__ void bwd_scan_kernel(const half_t *__restrict__ scores,  // [N][T][4S]
+                                float *__restrict__ bwd,            // [N][T+1][S]
+                                int T, int S, float stay, float clampv) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *beta = (float *)smem;                     // [2][S]
+    half_t *sc = (half_t *)(smem + 2 * S * 4);       // [2][4][S]  ([buf][base that fell off][dest])
+    const int n = blockIdx.x;
+    const int s = threadIdx.x;
+    const int K = 4 * S;
+    const int Q = S >> 2;
+    const half_t *sn = scores + (size_t)n * T * K;
+    float *bn = bwd + (size_t)n * (T + 1) * S;
+
+    beta[s] = 0.0f;
+    bn[(size_t)T * S + s] = 0.0f;
+    float mine = 0.0f;
+    half4_t row = *(const half4_t *)(sn + (size_t)(T - 1) * K + 4 * s);
+    const int hi = s / Q;
+    const int n0 = (s << 2) & (S - 1);
+    int p = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        half_t *scw = sc + p * K;
+        // element (dest = s, hi = b) of row t  ->  scw[b][s]
+        scw[0 * S + s] = row[0];
+        scw[1 * S + s] = row[1];
+        scw[2 * S + s] = row[2];
+        scw[3 * S + s] = row[3];
+        __syncthreads();
+        if (t > 0) {
+            row = *(const half4_t *)(sn + (size_t)(t - 1) * K + 4 * s);
+        }
+        const float4_t b4 = *(const float4_t *)(beta + p * S + n0);
+        const half4_t m4 = *(const half4_t *)(scw + hi * S + n0);
+        const float v = dm_lse5(mine + stay, b4[0] + clampf((float)m4[0], clampv),
+                                b4[1] + clampf((float)m4[1], clampv),
+                                b4[2] + clampf((float)m4[2], clampv),
+                                b4[3] + clampf((float)m4[3], clampv));
+        mine = v;
+        beta[(p ^ 1) * S + s] = v;
+        bn[(size_t)t * S + s] = v;
+        p ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k2: beam search (decode/beam_search.cpp:125-455), one wave per chunk
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t crc32c_bits(uint32_t crc, uint32_t bits, int nbits) {
+    // beam_search.cpp:104-121 (reversed Castagnoli polynomial, LSB first)
+    for (int i = 0; i < nbits; ++i) {
+        const uint32_t b = (bits ^ crc) & 1u;
+        crc >>= 1;
+        if (b) crc ^= 0x82f63b78u;
+        bits >>= 1;
+    }
+    return crc;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t f2key(float f) {  // monotone float -> uint
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ int lanes_below(unsigned long long m, int lane) {
+    return __popcll(m & ((1ull << lane) - 1ull));
+}
+
+#define BS_MAXW 32
+#define BS_CAND (5 * BS_MAXW)
+
+template <int S>
+__global__ __launch_bounds__(64) void beam_search_kernel(
+        const half_t *__restrict__ scores,   // [N][T][4S]
+        const float *__restrict__ bwd,       // [N][T+1][S]
+        uint32_t *__restrict__ trace,        // [N][T+1][W]  state | prev<<16 | stay<<24
+        uint16_t *__restrict__ path_state,   // [N][T]  full k-mer state per block
+        int8_t *__restrict__ moves,          // [N][T]
+        int T, int W, float log_cut, float stay, float clampv) {
+    constexpr int K = 4 * S;
+    constexpr int BITS = (S == 64) ? 6 : (S == 256) ? 8 : (S == 1024) ? 10 : 12;
+    constexpr int RPL = (K / 64 / 8) > 0 ? (K / 64 / 8) : 1;  // half8 loads per lane per score row
+    constexpr int GPL = S / 64;      // floats per lane for one guide row
+    __shared__ __attribute__((aligned(16))) half_t sc_row[K];
+    __shared__ __attribute__((aligned(16))) float bg_row[S];
+    __shared__ float c_score[BS_CAND];
+    __shared__ uint32_t c_hash[BS_CAND];
+    __shared__ uint16_t c_state[BS_CAND];
+    __shared__ int tag[4 * BS_MAXW];
+    __shared__ float n_score[BS_MAXW];
+    __shared__ uint32_t n_hash[BS_MAXW];
+    __shared__ uint32_t n_meta[BS_MAXW];       // state | prev<<16 | stay<<24
+    __shared__ uint32_t tb_tile[64 * BS_MAXW];  // trace-back tile
+    __shared__ uint16_t tb_state[64];
+    __shared__ int8_t tb_move[64];
+
+    const int n = blockIdx.x;
+    const int lane = threadIdx.x;
+    const half_t *sn = scores + (size_t)n * T * K;
+    const float *bn = bwd + (size_t)n * (T + 1) * S;
+    uint32_t *tr = trace + (size_t)n * (T + 1) * W;
+    const uint32_t mask = S - 1;
+
+    // ---- seed (beam_search.cpp:165-198): threshold = W-th largest back-guide at t = 0 ----
+    float g0[GPL];
+#pragma unroll
+    for (int i = 0; i < GPL; ++i) g0[i] = bn[i * 64 + lane];
+    uint32_t thr_key = 0;  // lowest
+    if (W < S) {
+        // radix select: largest key with count(key >= thr) >= W
+        uint32_t k = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = k | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < GPL; ++i) cnt += __popcll(__ballot(f2key(g0[i]) >= cand));
+            if (cnt >= W) k = cand;
+        }
+        thr_key = k;
+    }
+    int width = 0;
+    {
+        int base_cnt = 0;
+#pragma unroll
+        for (int i = 0; i < GPL; ++i) {
+            const bool keep = f2key(g0[i]) >= thr_key;
+            const unsigned long long bal = __ballot(keep);
+            const int idx = base_cnt + lanes_below(bal, lane);
+            if (keep && idx < W) {
+                const uint32_t st = i * 64 + lane;
+                n_hash[idx] = crc32c_bits(0x12345678u, st, 32);
+                n_meta[idx] = st;
+                n_score[idx] = 0.0f;
+            }
+            base_cnt += __popcll(bal);
+        }
+        width = base_cnt < W ? base_cnt : W;
+    }
+    __syncthreads();
+    uint32_t p_hash = 0, p_state = 0;
+    float p_score = 0.0f;
+    if (lane < width) {
+        p_hash = n_hash[lane];
+        p_state = n_meta[lane] & 0xffffu;
+        p_score = n_score[lane];
+    }
+
+    // prefetch row 0 of scores and row 1 of guides
+    half8_t rs[RPL];
+    float rg[GPL];
+#pragma unroll
+    for (int i = 0; i < RPL; ++i)
+        if ((i * 64 + lane) * 8 < K) rs[i] = *(const half8_t *)(sn + (i * 64 + lane) * 8);
+#pragma unroll
+    for (int i = 0; i < GPL; ++i) rg[i] = bn[(size_t)S + i * 64 + lane];
+
+    for (int blk = 0; blk < T; ++blk) {
+        __syncthreads();  // previous block's LDS reads are complete
+#pragma unroll
+        for (int i = 0; i < RPL; ++i)
+            if ((i * 64 + lane) * 8 < K) *(half8_t *)(sc_row + (i * 64 + lane) * 8) = rs[i];
+#pragma unroll
+        for (int i = 0; i < GPL; ++i) bg_row[i * 64 + lane] = rg[i];
+        __syncthreads();
+        if (blk + 1 < T) {
+#pragma unroll
+            for (int i = 0; i < RPL; ++i)
+                if ((i * 64 + lane) * 8 < K)
+                    rs[i] = *(const half8_t *)(sn + (size_t)(blk + 1) * K + (i * 64 + lane) * 8);
+#pragma unroll
+            for (int i = 0; i < GPL; ++i) rg[i] = bn[(size_t)(blk + 2) * S + i * 64 + lane];
+        }
+        const bool active = lane < width;
+        const int w4 = width << 2;
+        const int cnt = 5 * width;
+        float my_max = FLT_LOWEST;
+        float stay_sc = FLT_LOWEST;
+        // ---- expand: steps at slot 4e+b (beam_search.cpp:236-260), stay at 4w+e (:262-271) ----
+        if (active) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t ns = ((p_state << 2) & mask) | (uint32_t)b;
+                const uint32_t mi = (ns << 2) + (p_state >> (BITS - 2));
+                const float sc = (p_score + clampf((float)sc_row[mi], clampv)) + bg_row[ns];
+                c_score[4 * lane + b] = sc;
+                c_hash[4 * lane + b] = crc32c_bits(p_hash, (uint32_t)b, 2);
+                c_state[4 * lane + b] = (uint16_t)ns;
+                my_max = fmaxf(my_max, sc);
+            }
+            stay_sc = (p_score + stay) + bg_row[p_state];
+            c_score[w4 + lane] = stay_sc;
+            c_hash[w4 + lane] = p_hash;
+            c_state[w4 + lane] = (uint16_t)p_state;
+            my_max = fmaxf(my_max, stay_sc);
+            tag[4 * lane + 0] = -1;
+            tag[4 * lane + 1] = -1;
+            tag[4 * lane + 2] = -1;
+            tag[4 * lane + 3] = -1;
+        }
+        __syncthreads();
+        // ---- merge stays with equal-hash steps (beam_search.cpp:273-305).  The reference's
+        //      4096-bit presence filter has no false negatives, so "compare against every step
+        //      with the same newest base" is the same set of matches. ----
+        uint32_t mm = 0;
+        const int lb = p_state & 3;
+        if (active) {
+            for (int e2 = 0; e2 < width; ++e2) {
+                if (c_hash[(e2 << 2) | lb] == p_hash) mm |= (1u << e2);
+            }
+        }
+        if (__ballot(mm != 0) != 0ull) {
+            const int tgt = (mm != 0) ? ((__ffs(mm) - 1) * 4 + lb) : 0;
+            if (mm != 0) tag[tgt] = lane;
+            __syncthreads();
+            const bool clash = (mm != 0) && ((__popc(mm) > 1) || (tag[tgt] != lane));
+            if (__ballot(clash) == 0ull) {
+                // common case: every stay folds with at most one step and no step is shared
+                if (mm != 0) {
+                    const float a = stay_sc, b = c_score[tgt];
+                    const float folded = dm_log_sum_exp2(a, b);
+                    if (a > b) {
+                        c_score[w4 + lane] = folded;
+                        c_score[tgt] = FLT_LOWEST;
+                    } else {
+                        c_score[tgt] = folded;
+                        c_score[w4 + lane] = FLT_LOWEST;
+                    }
+                    my_max = fmaxf(my_max, folded);
+                }
+            } else {
+                // rare (hash collision): replay the reference's sequential order exactly
+                volatile float *vs = c_score;
+                for (int e = 0; e < width; ++e) {
+                    uint32_t m = __shfl(mm, e, 64);
+                    const int elb = __shfl(lb, e, 64);
+                    while (m) {
+                        const int e2 = __ffs(m) - 1;
+                        m &= m - 1;
+                        const int si = w4 + e, ti = (e2 << 2) | elb;
+                        const float a = vs[si], b = vs[ti];
+                        const float folded = dm_log_sum_exp2(a, b);
+                        if (lane == 0) {
+                            if (a > b) {
+                                vs[si] = folded;
+                                vs[ti] = FLT_LOWEST;
+                            } else {
+                                vs[ti] = folded;
+                                vs[si] = FLT_LOWEST;
+                            }
+                        }
+                        my_max = fmaxf(my_max, folded);
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const float max_score = wave_max(my_max);
+
+        // ---- cut-off (beam_search.cpp:310-396) ----
+        float cs[3];
+        bool cv[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int slot = g * 64 + lane;
+            cv[g] = slot < cnt;
+            cs[g] = cv[g] ? c_score[slot] : FLT_LOWEST;
+        }
+        float cutoff = max_score - log_cut;
+        auto count_ge = [&](float c) {
+            int k = 0;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) k += __popcll(__ballot(cv[g] && cs[g] >= c));
+            return k;
+        };
+        int ec = count_ge(cutoff);
+        if (ec > W) {
+            const int minw = (W * 8) / 10;
+            float lo = cutoff, hi = max_score;
+            int guesses = 1;
+            while ((ec > W || ec < minw) && guesses < 10) {
+                if (ec > W) {
+                    lo = cutoff;
+                    cutoff = (cutoff + hi) / 2.0f;
+                } else {
+                    hi = cutoff;
+                    cutoff = (cutoff + lo) / 2.0f;
+                }
+                ec = count_ge(cutoff);
+                ++guesses;
+            }
+            if (guesses == 10) {
+                cutoff = hi;
+                ec = count_ge(cutoff);
+            }
+            if (ec > W) ec = W;
+        }
+        // ---- compaction in slot order, first W (beam_search.cpp:398-409) ----
+        {
+            int base_cnt = 0;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const bool keep = cv[g] && cs[g] >= cutoff;
+                const unsigned long long bal = __ballot(keep);
+                const int idx = base_cnt + lanes_below(bal, lane);
+                if (keep && idx < W) {
+                    const int slot = g * 64 + lane;
+                    const bool is_stay = slot >= w4;
+                    const uint32_t prev = is_stay ? (uint32_t)(slot - w4) : (uint32_t)(slot >> 2);
+                    n_score[idx] = cs[g];
+                    n_hash[idx] = c_hash[slot];
+                    n_meta[idx] = (uint32_t)c_state[slot] | (prev << 16) | ((is_stay ? 1u : 0u) << 24);
+                }
+                base_cnt += __popcll(bal);
+            }
+        }
+        __syncthreads();
+        uint32_t meta = 0;
+        if (lane < ec) {
+            p_score = n_score[lane];
+            p_hash = n_hash[lane];
+            meta = n_meta[lane];
+            p_state = meta & 0xffffu;
+        } else {
+            p_score = FLT_LOWEST;
+        }
+        // ---- last block: best element to slot 0 (beam_search.cpp:413-424; strict >, first) ----
+        if (blk == T - 1) {
+            float best = (lane < ec) ? p_score : FLT_LOWEST;
+            const float bmax = wave_max(best);
+            const unsigned long long who = __ballot((lane < ec) && (p_score == bmax));
+            int bi = (who != 0ull) ? (__ffsll((long long)who) - 1) : 0;
+            if (!(bmax > FLT_LOWEST)) bi = 0;
+            const float s0 = __shfl(p_score, 0, 64), sb = __shfl(p_score, bi, 64);
+            const uint32_t h0 = __shfl(p_hash, 0, 64), hb = __shfl(p_hash, bi, 64);
+            const uint32_t m0 = __shfl(meta, 0, 64), mb = __shfl(meta, bi, 64);
+            if (lane == 0) {
+                p_score = sb; p_hash = hb; meta = mb;
+            } else if (lane == bi) {
+                p_score = s0; p_hash = h0; meta = m0;
+            }
+            p_state = meta & 0xffffu;
+        }
+        // ---- store (beam_search.cpp:426-437) ----
+        if (lane < ec) {
+            p_score -= bg_row[p_state];
+            tr[(size_t)(blk + 1) * W + lane] = meta;
+        }
+        width = ec;
+    }
+    __syncthreads();
+    __threadfence_block();
+
+    // ---- trace back (beam_search.cpp:448-455), 64 blocks at a time through LDS ----
+    uint8_t ei = 0;
+    for (int hi_blk = T; hi_blk >= 1; hi_blk -= 64) {
+        const int lo_blk = (hi_blk - 63 > 1) ? (hi_blk - 63) : 1;  // rows lo..hi inclusive
+        const int rows = hi_blk - lo_blk + 1;
+        // lane r loads row lo_blk + r (W entries)
+        for (int i = lane; i < rows * W; i += 64) {
+            tb_tile[i] = tr[(size_t)lo_blk * W + i];
+        }
+        __syncthreads();
+        if (lane == 0) {
+            for (int r = rows - 1; r >= 0; --r) {
+                const uint32_t m = tb_tile[r * W + ei];
+                tb_state[r] = (uint16_t)(m & 0xffffu);
+                tb_move[r] = ((m >> 24) & 1u) ? 0 : 1;
+                ei = (uint8_t)((m >> 16) & 0xffu);
+            }
+        }
+        __syncthreads();
+        ei = (uint8_t)__shfl((int)ei, 0, 64);
+        if (lane < rows) {
+            const int blk = lo_blk + lane - 1;  // beam row b describes block b-1
+            path_state[(size_t)n * T + blk] = tb_state[lane];
+            moves[(size_t)n * T + blk] = (blk == 0) ? (int8_t)1 : tb_move[lane];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k3: forward scan + posterior of the called path + sequence/qstring
+//     (CPUDecoder.cpp:43-64,130; beam_search.cpp:459-517; beam_search.cpp:54-102)
+// ---------------------------------------------------------------------------------------------
+__global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N][T][4S]
+                                  const float *__restrict__ bwd,          // [N][T+1][S]
+                                  const uint16_t *__restrict__ path_state,  // [N][T]
+                                  const int8_t *__restrict__ moves,       // [N][T]
+                                  int8_t *__restrict__ seq_out,           // [N][T]
+                                  int8_t *__restrict__ qstr_out,          // [N][T]
+                                  float *__restrict__ prob_tap,           // [N][T] or nullptr
+                                  int T, int S, float stay, float clampv, float q_shift,
+                                  float q_scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *alpha = (float *)smem;                 // [2][S]
+    float *red = alpha + 2 * S;                   // [2 * 32] reduction scratch
+    float *prob = red + 64;                       // [T]
+    float *bp = prob + T;                         // [T]
+    float *tp = bp + T;                           // [T]
+    uint16_t *pst = (uint16_t *)(tp + T);         // [T]
+    int8_t *pmv = (int8_t *)(pst + T);            // [T]
+    __shared__ int s_len;
+
+    const int n = blockIdx.x;
+    const int s = threadIdx.x;
+    const int K = 4 * S;
+    const int Q = S >> 2;
+    const int nw = (S + 63) >> 6;
+    const int wave = s >> 6, lane = s & 63;
+    const half_t *sn = scores + (size_t)n * T * K;
+    const float *bn = bwd + (size_t)n * (T + 1) * S;
+
+    for (int i = s; i < T; i += S) {
+        pst[i] = path_state[(size_t)n * T + i];
+        pmv[i] = moves[(size_t)n * T + i];
+        bp[i] = 0.0f;
+        tp[i] = 0.0f;
+    }
+    // log Z = LSE_s(bwd[0][s])  (alpha[0] = 0): shift for the posterior exponent
+    float logZ;
+    {
+        const float v = bn[s];
+        float m = v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        float mm = red[0];
+        for (int i = 1; i < nw; ++i) mm = fmaxf(mm, red[i]);
+        __syncthreads();
+        float e = dm_expf(v - mm);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+        if (lane == 0) red[wave] = e;
+        __syncthreads();
+        float es = red[0];
+        for (int i = 1; i < nw; ++i) es += red[i];
+        logZ = mm + dm_logf(es);
+        __syncthreads();
+    }
+    alpha[s] = 0.0f;
+    float mine = 0.0f;
+    const int pred = s >> 2;
+    half4_t row = *(const half4_t *)(sn + 4 * s);
+    float bnext = bn[(size_t)S + s];
+    int p = 0;
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const half4_t m4 = row;
+        const float bw = bnext;
+        if (t + 1 < T) {
+            row = *(const half4_t *)(sn + (size_t)(t + 1) * K + 4 * s);
+            bnext = bn[(size_t)(t + 2) * S + s];
+        }
+        const float *a = alpha + p * S;
+        const float v = dm_lse5(mine + stay, a[pred] + clampf((float)m4[0], clampv),
+                                a[pred + Q] + clampf((float)m4[1], clampv),
+                                a[pred + 2 * Q] + clampf((float)m4[2], clampv),
+                                a[pred + 3 * Q] + clampf((float)m4[3], clampv));
+        mine = v;
+        alpha[(p ^ 1) * S + s] = v;
+        p ^= 1;
+        // posterior mass of the called k-mer and its distinct shifted neighbours
+        const int st = pst[t];
+        const bool in_set = (s == st) ||
+                            ((s & (Q - 1)) == (st >> 2)) ||  // left-shifted:  (st >> 2) + b * Q
+                            ((s >> 2) == (st & (Q - 1)));    // right-shifted: ((st << 2) % S) + b
+        const float e = dm_expf((v + bw) - logZ);
+        float e_all = e, e_sel = in_set ? e : 0.0f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            e_all += __shfl_xor(e_all, o, 64);
+            e_sel += __shfl_xor(e_sel, o, 64);
+        }
+        if (lane == 0) {
+            red[(t & 1) * 32 + wave] = e_all;
+            red[(t & 1) * 32 + 16 + wave] = e_sel;
+        }
+        __syncthreads();  // alpha[p] and red[] visible
+        if (s == 0) {
+            float ta = 0.0f, ts = 0.0f;
+            for (int i = 0; i < nw; ++i) {
+                ta += red[(t & 1) * 32 + i];
+                ts += red[(t & 1) * 32 + 16 + i];
+            }
+            float pr = ts / ta;
+            pr = fminf(fmaxf(pr, 0.0f), 1.0f);
+            prob[t] = powf(pr, 0.4f);
+        }
+    }
+    __syncthreads();
+    // ---- sequence / per-base error accumulation (beam_search.cpp:54-102), sequential ----
+    if (s == 0) {
+        int pos = 0;
+        for (int blk = 0; blk < T; ++blk) {
+            const int base = pst[blk] & 3;
+            const int mv = pmv[blk];
+            const float pr = prob[blk];
+            const float wrong = (1.0f - pr) / 3.0f;
+            const int ppos = pos + ((blk == 0) ? 0 : mv - 1);
+            bp[ppos] += pr;
+            float tot = tp[ppos];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tot += (k == base) ? pr : wrong;
+            tp[ppos] = tot;
+            pos += (blk == 0) ? 1 : mv;
+        }
+        s_len = pos;
+    }
+    __syncthreads();
+    // bases: position of block blk = (number of moves in [0, blk]) - 1 -> parallel prefix sum
+    {
+        // inclusive prefix sum of moves over T with S threads: chunked scan
+        const int per = (T + S - 1) / S;
+        const int b0 = s * per;
+        int local = 0;
+        for (int i = 0; i < per; ++i) {
+            const int blk = b0 + i;
+            if (blk < T) local += (blk == 0) ? 1 : pmv[blk];
+        }
+        // exclusive scan of `local` across threads (Hillis-Steele in LDS, reuse alpha as int)
+        int *scan = (int *)alpha;
+        scan[s] = local;
+        __syncthreads();
+        for (int o = 1; o < S; o <<= 1) {
+            const int add = (s >= o) ? scan[s - o] : 0;
+            __syncthreads();
+            scan[s] += add;
+            __syncthreads();
+        }
+        int pos = scan[s] - local;  // exclusive
+        const char alphabet[4] = {'A', 'C', 'G', 'T'};
+        for (int i = 0; i < per; ++i) {
+            const int blk = b0 + i;
+            if (blk < T) {
+                const int mv = (blk == 0) ? 1 : pmv[blk];
+                if (mv) {
+                    seq_out[(size_t)n * T + pos] = (int8_t)alphabet[pst[blk] & 3];
+                    pos += 1;
+                }
+            }
+        }
+    }
+    const int len = s_len;
+    for (int i = s; i < T; i += S) {
+        if (i < len) {
+            float e = 1.0f - (bp[i] / tp[i]);
+            e = -10.0f * log10f(e);
+            float q = e * q_scale + q_shift;
+            q = fminf(fmaxf(q, 1.0f), 50.0f);
+            qstr_out[(size_t)n * T + i] = (int8_t)(33.5f + q);
+        } else {
+            seq_out[(size_t)n * T + i] = 0;
+            qstr_out[(size_t)n * T + i] = 0;
+        }
+        if (prob_tap != nullptr) prob_tap[(size_t)n * T + i] = prob[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int mibc_launch_decode(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
+                                  float beam_cut, float stay, float clampv, float q_shift,
+                                  float q_scale, float *bwd, uint32_t *trace,
+                                  uint16_t *path_state, int8_t *out3 /* [3][Nplane][T] */,
+                                  size_t plane_stride, float *prob_tap) {
+    if (W > BS_MAXW || W < 1 || (S != 64 && S != 256 && S != 1024) || T < 1) {
+        return 1;
+    }
+    int8_t *moves = out3;
+    int8_t *seq = out3 + plane_stride;
+    int8_t *qstr = out3 + 2 * plane_stride;
+    const float log_cut = (beam_cut > 0.0f) ? logf(beam_cut) : 3.402823466e+38f;
+    const size_t smem1 = (size_t)2 * S * 4 + (size_t)2 * 4 * S * 2;
+    hipLaunchKernelGGL(bwd_scan_kernel, dim3(N), dim3(S), smem1, st, scores, bwd, T, S, stay, clampv);
+    switch (S) {
+        case 64:
+            hipLaunchKernelGGL((beam_search_kernel<64>), dim3(N), dim3(64), 0, st, scores, bwd, trace,
+                               path_state, moves, T, W, log_cut, stay, clampv);
+            break;
+        case 256:
+            hipLaunchKernelGGL((beam_search_kernel<256>), dim3(N), dim3(64), 0, st, scores, bwd,
+                               trace, path_state, moves, T, W, log_cut, stay, clampv);
+            break;
+        default:
+            hipLaunchKernelGGL((beam_search_kernel<1024>), dim3(N), dim3(64), 0, st, scores, bwd,
+                               trace, path_state, moves, T, W, log_cut, stay, clampv);
+            break;
+    }
+    const size_t smem3 = (size_t)(2 * S + 64) * 4 + (size_t)3 * T * 4 + (size_t)T * 2 + (size_t)T + 16;
+    hipLaunchKernelGGL(posts_qual_kernel, dim3(N), dim3(S), smem3, st, scores, bwd, path_state, moves,
+                       seq, qstr, prob_tap, T, S, stay, clampv, q_shift, q_scale);
+    return 0;
+}

@@ -1,0 +1,688 @@
+// dorado_amd/csrc/engine.hip — the C-ABI (include/mibc.h): engine lifetime, weight layout
+// conversion, device workspace, stage orchestration on one HIP stream, timing and parity taps.
+//
+// This is the device-side half of what basecall::CudaCaller does in the reference
+// (dorado/basecall/CudaCaller.cpp:149-200 ctor, :224-271 call_chunks, :323-369 memory model,
+// :552-569 forward timing) minus its libtorch/Koi dependencies.  The thread/queue half
+// (per-device FIFO, runners, pinned batch buffers) lives in dorado_amd/host/.
+#include "../../include/mibc.h"
+#include "common.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+struct GemmArgs {
+    const half_t *A;
+    const half_t *B;
+    const float *bias;
+    half_t *out;
+    int M, Ncols, K;
+    int a_div;
+    long a_outer, a_inner;
+    int o_div;
+    long o_outer, o_inner;
+    int act;
+};
+extern "C" int mibc_launch_gemm_tn(hipStream_t s, const GemmArgs *a);
+extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w1, const float *b1,
+                                  const float *w2, const float *b2, half_t *a2p, half_t *a1_tap,
+                                  int N, int T_in, int Tpitch, int pad, int act1, int act2);
+extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, half_t *Xout,
+                                      const half_t *Wf, const float *biasf, int T, int N,
+                                      int reverse);
+extern "C" int mibc_launch_decode(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
+                                  float beam_cut, float stay, float clampv, float q_shift,
+                                  float q_scale, float *bwd, uint32_t *trace,
+                                  uint16_t *path_state, int8_t *out3, size_t plane_stride,
+                                  float *prob_tap);
+
+static thread_local std::string g_err;
+
+struct mibc_engine {
+    int device = 0;
+    mibc_model_desc d{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    // weights (device)
+    float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *b3 = nullptr;
+    half_t *w3 = nullptr;  // [C][K3pad]
+    int K3 = 0, K3pad = 0;
+    std::vector<half_t *> lstm_w;
+    std::vector<float *> lstm_b;
+    half_t *head_w1 = nullptr, *head_w2 = nullptr;
+    float *head_b1 = nullptr;
+    int head_act1 = -1, head_act2 = -1;
+    // geometry
+    int C = 0, S = 0, K = 0, stride = 1, pad3 = 0;
+    // workspace
+    int N_res = 0, T_in_res = 0, T_res = 0, Tpitch = 0, Nd = 0;
+    half_t *in_stage = nullptr, *a2p = nullptr, *xa = nullptr, *xb = nullptr, *scores = nullptr,
+           *mid = nullptr, *a1_tap = nullptr;
+    float *bwd = nullptr, *prob_tap = nullptr;
+    uint32_t *trace = nullptr;
+    uint16_t *path_state = nullptr;
+    int8_t *out3 = nullptr;
+    size_t ws_bytes = 0;
+    // last call
+    half_t *lstm_out = nullptr;
+    int last_N = 0, last_T = 0, last_T_in = 0;
+    int profile = 0, taps = 0;
+    enum { EV_START, EV_CONV, EV_LSTM0, EV_HEAD_BASE = EV_LSTM0 + 8, EV_END = EV_HEAD_BASE + 1, EV_N };
+    hipEvent_t ev[16] = {};
+    float head_ms = 0, dec_ms = 0;
+    std::vector<hipEvent_t> sub_ev;  // per decode sub-batch: head start, head end, decode end
+    bool timed = false;
+};
+
+#define HIP_OK(e_, call)                                                                  \
+    do {                                                                                  \
+        hipError_t rc_ = (call);                                                          \
+        if (rc_ != hipSuccess) {                                                          \
+            std::string m_ = std::string(#call) + ": " + hipGetErrorString(rc_);          \
+            if (e_) (e_)->err = m_;                                                       \
+            g_err = m_;                                                                   \
+            return MIBC_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+static int fail(mibc_engine *e, int code, const std::string &m) {
+    if (e) e->err = m;
+    g_err = m;
+    return code;
+}
+
+extern "C" int mibc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        return 0;
+    }
+    return n;
+}
+
+extern "C" const char *mibc_last_error(const mibc_engine *e) {
+    return e ? e->err.c_str() : g_err.c_str();
+}
+
+template <typename T>
+static int upload(mibc_engine *e, T **dst, const std::vector<T> &src) {
+    HIP_OK(e, hipMalloc((void **)dst, src.size() * sizeof(T)));
+    HIP_OK(e, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const float *const *weights,
+                           int n_weights, mibc_engine **out) {
+    if (!desc || !weights || !out) {
+        return fail(nullptr, MIBC_ERR_ARG, "null argument");
+    }
+    const mibc_model_desc &d = *desc;
+    if (d.tx_d_model > 0) {
+        return fail(nullptr, MIBC_NOT_SUPPORTED, "transformer models are not supported yet");
+    }
+    if (d.n_convs != 3 || d.num_features != 1 || d.conv_insize[0] != 1 || d.conv_size[0] != 16 ||
+        d.conv_size[1] != 16 || d.conv_winlen[0] != 5 || d.conv_winlen[1] != 5 ||
+        d.conv_stride[0] != 1 || d.conv_stride[1] != 1 || d.conv_insize[2] != 16) {
+        return fail(nullptr, MIBC_NOT_SUPPORTED,
+                    "conv front-end must be 1->16 (w5,s1) ->16 (w5,s1) ->C (v4 LSTM-CRF models)");
+    }
+    const int C = d.lstm_size;
+    if (d.conv_size[2] != C || (C != 128 && C != 256 && C != 384 && C != 512)) {
+        return fail(nullptr, MIBC_NOT_SUPPORTED, "lstm_size must be one of 128/256/384/512 for now");
+    }
+    const int S = 1 << (2 * d.state_len);
+    if (S != 64 && S != 256 && S != 1024) {
+        return fail(nullptr, MIBC_NOT_SUPPORTED, "state_len must be 3, 4 or 5");
+    }
+    if (d.outsize != 4 * S) {
+        return fail(nullptr, MIBC_ERR_ARG, "outsize must be 4^(state_len+1)");
+    }
+    const bool two_stage = d.out_features > 0;
+    const bool v4_single = !two_stage && (d.conv_size[0] > 4 && d.num_features == 1);
+    int expect = 6 + 4 * d.lstm_layers + 1;
+    if (two_stage) expect += 1 + (d.bias ? 1 : 0);
+    else if (!v4_single) expect += 1;
+    if (n_weights != expect) {
+        return fail(nullptr, MIBC_ERR_ARG, "unexpected number of weight tensors: got " +
+                                                   std::to_string(n_weights) + ", expected " +
+                                                   std::to_string(expect));
+    }
+    if (two_stage && (d.out_features % 128 != 0)) {
+        return fail(nullptr, MIBC_NOT_SUPPORTED, "out_features must be a multiple of 128");
+    }
+    if (hipSetDevice(device_id) != hipSuccess) {
+        return fail(nullptr, MIBC_ERR_HIP, "hipSetDevice failed");
+    }
+    mibc_engine *e = new mibc_engine();
+    e->device = device_id;
+    e->d = d;
+    e->C = C;
+    e->S = S;
+    e->K = 4 * S;
+    e->stride = d.conv_stride[2];
+    e->pad3 = d.conv_winlen[2] / 2;
+    HIP_OK(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (auto &ev : e->ev) HIP_OK(e, hipEventCreate(&ev));
+
+    int wi = 0;
+    // conv1 [16][1][5] -> [k][co]; conv2 [16][16][5] -> [k][ci][co]
+    {
+        const float *W = weights[wi++], *B = weights[wi++];
+        std::vector<float> w(5 * 16), b(B, B + 16);
+        for (int co = 0; co < 16; ++co)
+            for (int k = 0; k < 5; ++k) w[k * 16 + co] = W[co * 5 + k];
+        if (upload(e, &e->w1, w) || upload(e, &e->b1, b)) return MIBC_ERR_HIP;
+    }
+    {
+        const float *W = weights[wi++], *B = weights[wi++];
+        std::vector<float> w(5 * 16 * 16), b(B, B + 16);
+        for (int co = 0; co < 16; ++co)
+            for (int ci = 0; ci < 16; ++ci)
+                for (int k = 0; k < 5; ++k) w[(k * 16 + ci) * 16 + co] = W[(co * 16 + ci) * 5 + k];
+        if (upload(e, &e->w2, w) || upload(e, &e->b2, b)) return MIBC_ERR_HIP;
+    }
+    // conv3 [C][16][W3] -> GEMM B matrix [C][K3pad], k = w*16 + ci (im2col row order)
+    {
+        const int W3 = d.conv_winlen[2];
+        e->K3 = W3 * 16;
+        e->K3pad = (e->K3 + 31) / 32 * 32;
+        const float *W = weights[wi++], *B = weights[wi++];
+        std::vector<half_t> w((size_t)C * e->K3pad, (half_t)0.0f);
+        for (int co = 0; co < C; ++co)
+            for (int ci = 0; ci < 16; ++ci)
+                for (int k = 0; k < W3; ++k)
+                    w[(size_t)co * e->K3pad + k * 16 + ci] = (half_t)W[((size_t)co * 16 + ci) * W3 + k];
+        std::vector<float> b(B, B + C);
+        if (upload(e, &e->w3, w) || upload(e, &e->b3, b)) return MIBC_ERR_HIP;
+    }
+    // LSTM layers: [W_ih | W_hh] in MFMA-fragment order + summed biases in D-register order
+    for (int l = 0; l < d.lstm_layers; ++l) {
+        const float *Wih = weights[wi++], *Whh = weights[wi++], *bih = weights[wi++],
+                    *bhh = weights[wi++];
+        const int KS = 2 * C / 16;
+        std::vector<half_t> wf((size_t)4 * C * 2 * C);
+        for (int j = 0; j < C / 32; ++j)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int g = 0; g < 4; ++g)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int i = 0; i < 8; ++i) {
+                            const int row = g * C + 32 * j + (lane & 31);
+                            const int k = ks * 16 + 8 * (lane >> 5) + i;
+                            const float v = (k < C) ? Wih[(size_t)row * C + k]
+                                                    : Whh[(size_t)row * C + (k - C)];
+                            wf[((((size_t)j * KS + ks) * 4 + g) * 64 + lane) * 8 + i] = (half_t)v;
+                        }
+        std::vector<float> bf((size_t)4 * C * 2);
+        for (int j = 0; j < C / 32; ++j)
+            for (int g = 0; g < 4; ++g)
+                for (int lhi = 0; lhi < 2; ++lhi)
+                    for (int r = 0; r < 16; ++r) {
+                        const int hid = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        bf[(((size_t)j * 4 + g) * 2 + lhi) * 16 + r] = bih[g * C + hid] + bhh[g * C + hid];
+                    }
+        half_t *dw = nullptr;
+        float *db = nullptr;
+        if (upload(e, &dw, wf) || upload(e, &db, bf)) return MIBC_ERR_HIP;
+        e->lstm_w.push_back(dw);
+        e->lstm_b.push_back(db);
+    }
+    // head (basecall/model/CRFModel.cpp:43-61)
+    const int tanh_x5 = (d.scale == 5.0f) ? 3 : -1;
+    auto to_half = [](const float *p, size_t n) {
+        std::vector<half_t> v(n);
+        for (size_t i = 0; i < n; ++i) v[i] = (half_t)p[i];
+        return v;
+    };
+    if (two_stage) {
+        const int D = d.out_features;
+        if (upload(e, &e->head_w1, to_half(weights[wi++], (size_t)D * C))) return MIBC_ERR_HIP;
+        if (d.bias) {
+            const float *B = weights[wi++];
+            if (upload(e, &e->head_b1, std::vector<float>(B, B + D))) return MIBC_ERR_HIP;
+        }
+        if (upload(e, &e->head_w2, to_half(weights[wi++], (size_t)e->K * D))) return MIBC_ERR_HIP;
+        e->head_act1 = -1;
+        e->head_act2 = tanh_x5;
+    } else if (v4_single) {
+        if (upload(e, &e->head_w1, to_half(weights[wi++], (size_t)e->K * C))) return MIBC_ERR_HIP;
+        e->head_act1 = tanh_x5;
+    } else {
+        if (upload(e, &e->head_w1, to_half(weights[wi++], (size_t)e->K * C))) return MIBC_ERR_HIP;
+        const float *B = weights[wi++];
+        if (upload(e, &e->head_b1, std::vector<float>(B, B + e->K))) return MIBC_ERR_HIP;
+        e->head_act1 = 3;
+    }
+    const char *tp = getenv("MIBC_TAPS");
+    e->taps = tp ? atoi(tp) : 0;
+    *out = e;
+    return MIBC_OK;
+}
+
+static void free_ws(mibc_engine *e) {
+    void *ptrs[] = {e->in_stage, e->a2p, e->xa, e->xb, e->scores, e->mid, e->a1_tap, e->bwd,
+                    e->prob_tap, e->trace, e->path_state, e->out3};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    e->in_stage = e->a2p = e->xa = e->xb = e->scores = e->mid = e->a1_tap = nullptr;
+    e->bwd = e->prob_tap = nullptr;
+    e->trace = nullptr;
+    e->path_state = nullptr;
+    e->out3 = nullptr;
+    for (auto ev : e->sub_ev) (void)hipEventDestroy(ev);
+    e->sub_ev.clear();
+    e->N_res = 0;
+    e->ws_bytes = 0;
+}
+
+extern "C" void mibc_destroy(mibc_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    free_ws(e);
+    void *ptrs[] = {e->w1, e->b1, e->w2, e->b2, e->b3, e->w3, e->head_w1, e->head_w2, e->head_b1};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto p : e->lstm_w) (void)hipFree(p);
+    for (auto p : e->lstm_b) (void)hipFree(p);
+    for (auto &ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int mibc_output_steps(const mibc_engine *e, int T_in) {
+    const int W3 = e->d.conv_winlen[2];
+    return (T_in + 2 * e->pad3 - W3) / e->stride + 1;
+}
+
+extern "C" int mibc_batch_granularity(const mibc_engine *) { return 64; }
+
+static int decode_sub(const mibc_engine *e, int N) {
+    const char *s = getenv("MIBC_DECODE_SUB");
+    int nd = s ? atoi(s) : 4096;
+    if (nd < 64) nd = 64;
+    nd = (nd / 64) * 64;
+    return N < nd ? N : nd;
+}
+
+// Bytes per chunk (linear in N) and fixed part — the analogue of CudaCaller.cpp:323-369.
+extern "C" int mibc_query_memory(const mibc_engine *e, int T_in, size_t *bytes_per_chunk,
+                                 size_t *bytes_fixed) {
+    if (!e || T_in <= 0) return MIBC_ERR_ARG;
+    const size_t T = (size_t)mibc_output_steps(e, T_in);
+    const size_t Tpitch = (size_t)T_in + 2 * e->pad3 + 2;
+    size_t per = 0;
+    per += (size_t)T_in * 2;                 // staged input
+    per += Tpitch * 16 * 2;                  // conv2 out (padded)
+    per += 2 * T * e->C * 2;                 // LSTM ping-pong
+    per += 3 * T;                            // out planes
+    const size_t per_dec = T * e->K * 2 + (T + 1) * e->S * 4 + (T + 1) * 32 * 4 + T * 2 + T * 4 +
+                           (e->d.out_features > 0 ? T * e->d.out_features * 2 : 0);
+    if (bytes_per_chunk) *bytes_per_chunk = per;
+    if (bytes_fixed) *bytes_fixed = per_dec * 4096;  // decode scratch is per sub-batch
+    return MIBC_OK;
+}
+
+extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
+    if (!e || N_max <= 0 || T_in <= 0) return MIBC_ERR_ARG;
+    if (N_max % 64 != 0) return fail(e, MIBC_ERR_ARG, "N_max must be a multiple of 64");
+    HIP_OK(e, hipSetDevice(e->device));
+    if (e->N_res >= N_max && e->T_in_res == T_in) return MIBC_OK;
+    HIP_OK(e, hipStreamSynchronize(e->stream));
+    free_ws(e);
+    const size_t T = (size_t)mibc_output_steps(e, T_in);
+    if (T < 1) return fail(e, MIBC_ERR_ARG, "chunk too short");
+    const size_t N = (size_t)N_max;
+    e->Tpitch = T_in + 2 * e->pad3 + 2;
+    e->Nd = decode_sub(e, N_max);
+    const size_t Nd = (size_t)e->Nd;
+    size_t total = 0;
+    auto alloc = [&](void **p, size_t bytes) -> int {
+        HIP_OK(e, hipMalloc(p, bytes));
+        total += bytes;
+        return 0;
+    };
+    if (alloc((void **)&e->in_stage, N * T_in * 2)) return MIBC_ERR_MEM;
+    if (alloc((void **)&e->a2p, (N * e->Tpitch + 64) * 16 * 2)) return MIBC_ERR_MEM;
+    HIP_OK(e, hipMemset(e->a2p, 0, (N * e->Tpitch + 64) * 16 * 2));
+    if (alloc((void **)&e->xa, T * N * e->C * 2)) return MIBC_ERR_MEM;
+    if (alloc((void **)&e->xb, T * N * e->C * 2)) return MIBC_ERR_MEM;
+    if (alloc((void **)&e->scores, Nd * T * e->K * 2)) return MIBC_ERR_MEM;
+    if (e->d.out_features > 0)
+        if (alloc((void **)&e->mid, Nd * T * e->d.out_features * 2)) return MIBC_ERR_MEM;
+    if (alloc((void **)&e->bwd, Nd * (T + 1) * e->S * 4)) return MIBC_ERR_MEM;
+    if (alloc((void **)&e->trace, Nd * (T + 1) * 32 * 4)) return MIBC_ERR_MEM;
+    if (alloc((void **)&e->path_state, Nd * T * 2)) return MIBC_ERR_MEM;
+    if (alloc((void **)&e->out3, 3 * N * T)) return MIBC_ERR_MEM;
+    if (e->taps) {
+        if (alloc((void **)&e->a1_tap, N * T_in * 16 * 2)) return MIBC_ERR_MEM;
+        if (alloc((void **)&e->prob_tap, Nd * T * 4)) return MIBC_ERR_MEM;
+    }
+    const int nsub = (N_max + e->Nd - 1) / e->Nd;
+    e->sub_ev.resize((size_t)nsub * 3);
+    for (auto &ev : e->sub_ev) HIP_OK(e, hipEventCreate(&ev));
+    e->N_res = N_max;
+    e->T_in_res = T_in;
+    e->T_res = (int)T;
+    e->ws_bytes = total;
+    return MIBC_OK;
+}
+
+extern "C" void *mibc_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void mibc_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+extern "C" void *mibc_device_alloc(mibc_engine *e, size_t bytes) {
+    void *p = nullptr;
+    if (e) (void)hipSetDevice(e->device);
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void mibc_device_free(mibc_engine *e, void *p) {
+    if (e) (void)hipSetDevice(e->device);
+    if (p) (void)hipFree(p);
+}
+extern "C" int mibc_memcpy_h2d(mibc_engine *e, void *dst, const void *src, size_t bytes) {
+    HIP_OK(e, hipSetDevice(e->device));
+    HIP_OK(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_OK(e, hipStreamSynchronize(e->stream));
+    return MIBC_OK;
+}
+extern "C" int mibc_memcpy_d2h(mibc_engine *e, void *dst, const void *src, size_t bytes) {
+    HIP_OK(e, hipSetDevice(e->device));
+    HIP_OK(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_OK(e, hipStreamSynchronize(e->stream));
+    return MIBC_OK;
+}
+extern "C" int mibc_sync(mibc_engine *e) {
+    HIP_OK(e, hipSetDevice(e->device));
+    HIP_OK(e, hipStreamSynchronize(e->stream));
+    return MIBC_OK;
+}
+extern "C" int mibc_set_profile(mibc_engine *e, int level) {
+    e->profile = level;
+    return MIBC_OK;
+}
+
+// conv1+conv2 -> conv3 (implicit GEMM) -> LSTM stack.  Leaves e->lstm_out.
+static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
+    const mibc_model_desc &d = e->d;
+    const int T = mibc_output_steps(e, T_in);
+    const bool prof = e->profile > 0;
+    if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_START], e->stream));
+    if (mibc_launch_conv12(e->stream, in_dev, e->w1, e->b1, e->w2, e->b2, e->a2p, e->a1_tap, N, T_in,
+                           e->Tpitch, e->pad3, d.conv_act[0], d.conv_act[1]) != 0)
+        return fail(e, MIBC_NOT_SUPPORTED, "conv activation combination not supported");
+    GemmArgs g{};
+    g.A = e->a2p;
+    g.B = e->w3;
+    g.bias = e->b3;
+    g.out = e->xa;
+    g.M = N * T;
+    g.Ncols = e->C;
+    g.K = e->K3pad;
+    g.a_div = T;
+    g.a_outer = (long)e->Tpitch * 16;
+    g.a_inner = (long)e->stride * 16;
+    g.o_div = T;
+    g.o_outer = e->C;             // n
+    g.o_inner = (long)N * e->C;   // t
+    g.act = d.conv_act[2];
+    if (mibc_launch_gemm_tn(e->stream, &g) != 0) return fail(e, MIBC_NOT_SUPPORTED, "conv3 gemm shape");
+    if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_CONV], e->stream));
+    half_t *cur = e->xa, *nxt = e->xb;
+    for (int l = 0; l < d.lstm_layers; ++l) {
+        // LSTMStack(layers, size, reverse_first = true): nn/LSTMStack.cpp:29-41, CRFModel.cpp:41
+        const int reverse = (l % 2 == 0) ? 1 : 0;
+        if (mibc_launch_lstm_layer(e->stream, e->C, cur, nxt, e->lstm_w[l], e->lstm_b[l], T, N,
+                                   reverse) != 0)
+            return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
+        if (prof && l < 8) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_LSTM0 + l], e->stream));
+        half_t *t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    e->lstm_out = cur;
+    HIP_OK(e, hipGetLastError());
+    return MIBC_OK;
+}
+
+// head for chunk rows [n0, n0+ns) of the LSTM output -> scores_out [ns][T][K]
+static int run_head(mibc_engine *e, int N, int T, int n0, int ns, half_t *scores_out) {
+    const mibc_model_desc &d = e->d;
+    GemmArgs g{};
+    g.A = e->lstm_out + (size_t)n0 * e->C;
+    g.M = ns * T;
+    g.K = e->C;
+    g.a_div = ns;
+    g.a_outer = (long)N * e->C;  // t
+    g.a_inner = e->C;            // n'
+    g.o_div = ns;
+    if (d.out_features > 0) {
+        const int D = d.out_features;
+        g.B = e->head_w1;
+        g.bias = e->head_b1;
+        g.out = e->mid;
+        g.Ncols = D;
+        g.o_outer = (long)ns * D;  // t   (mid laid out [T][ns][D])
+        g.o_inner = D;             // n'
+        g.act = e->head_act1;
+        if (mibc_launch_gemm_tn(e->stream, &g) != 0) return fail(e, MIBC_NOT_SUPPORTED, "head gemm 1");
+        GemmArgs h{};
+        h.A = e->mid;
+        h.B = e->head_w2;
+        h.bias = nullptr;
+        h.out = scores_out;
+        h.M = ns * T;
+        h.Ncols = e->K;
+        h.K = D;
+        h.a_div = ns;
+        h.a_outer = (long)ns * D;
+        h.a_inner = D;
+        h.o_div = ns;
+        h.o_outer = e->K;             // t
+        h.o_inner = (long)T * e->K;   // n'
+        h.act = e->head_act2;
+        if (mibc_launch_gemm_tn(e->stream, &h) != 0) return fail(e, MIBC_NOT_SUPPORTED, "head gemm 2");
+    } else {
+        g.B = e->head_w1;
+        g.bias = e->head_b1;
+        g.out = scores_out;
+        g.Ncols = e->K;
+        g.o_outer = e->K;             // t
+        g.o_inner = (long)T * e->K;   // n'
+        g.act = e->head_act1;
+        if (mibc_launch_gemm_tn(e->stream, &g) != 0) return fail(e, MIBC_NOT_SUPPORTED, "head gemm");
+    }
+    return MIBC_OK;
+}
+
+static int check_call(mibc_engine *e, int N, int T_in) {
+    if (!e) return MIBC_ERR_ARG;
+    if (N <= 0 || N % 64 != 0) return fail(e, MIBC_ERR_ARG, "N must be a positive multiple of 64");
+    if (e->N_res < N || e->T_in_res != T_in) {
+        const int rc = mibc_reserve(e, N, T_in);
+        if (rc != MIBC_OK) return rc;
+    }
+    HIP_OK(e, hipSetDevice(e->device));
+    return MIBC_OK;
+}
+
+extern "C" int mibc_forward(mibc_engine *e, const uint16_t *in_dev, int N, int T_in,
+                            uint16_t *scores_dev) {
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    const int T = mibc_output_steps(e, T_in);
+    rc = run_encoder(e, (const half_t *)in_dev, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    // the two-stage head uses the sub-batch sized `mid` buffer
+    for (int n0 = 0; n0 < N; n0 += e->Nd) {
+        const int ns = (N - n0 < e->Nd) ? (N - n0) : e->Nd;
+        rc = run_head(e, N, T, n0, ns, (half_t *)scores_dev + (size_t)n0 * T * e->K);
+        if (rc != MIBC_OK) return rc;
+    }
+    if (e->profile > 0) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_END], e->stream));
+    e->last_N = N;
+    e->last_T = T;
+    e->last_T_in = T_in;
+    e->timed = false;
+    HIP_OK(e, hipGetLastError());
+    return MIBC_OK;
+}
+
+static float clamp_value(const mibc_engine *e) { return e->d.clamp ? 5.0f : 0.0f; }
+
+extern "C" int mibc_decode(mibc_engine *e, const uint16_t *scores_dev, int N, int T,
+                           const mibc_decode_opts *o, int8_t *out_dev) {
+    if (!e || !o || N <= 0) return MIBC_ERR_ARG;
+    if (e->N_res <= 0 || T != e->T_res) return fail(e, MIBC_ERR_ARG, "mibc_reserve first (T mismatch)");
+    HIP_OK(e, hipSetDevice(e->device));
+    for (int n0 = 0; n0 < N; n0 += e->Nd) {
+        const int ns = (N - n0 < e->Nd) ? (N - n0) : e->Nd;
+        const int rc = mibc_launch_decode(e->stream, (const half_t *)scores_dev + (size_t)n0 * T * e->K,
+                                          ns, T, e->S, o->beam_width, o->beam_cut, o->blank_score,
+                                          clamp_value(e), o->q_shift, o->q_scale, e->bwd, e->trace,
+                                          e->path_state, out_dev + (size_t)n0 * T, (size_t)N * T,
+                                          e->prob_tap);
+        if (rc != 0) return fail(e, MIBC_NOT_SUPPORTED, "decoder: beam_width must be 1..32");
+    }
+    HIP_OK(e, hipGetLastError());
+    return MIBC_OK;
+}
+
+extern "C" int mibc_call_device(mibc_engine *e, const uint16_t *in_dev, int N, int T_in,
+                                const mibc_decode_opts *o, int8_t *out_dev) {
+    if (!o) return MIBC_ERR_ARG;
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    const int T = mibc_output_steps(e, T_in);
+    const bool prof = e->profile > 0;
+    rc = run_encoder(e, (const half_t *)in_dev, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    int si = 0;
+    for (int n0 = 0; n0 < N; n0 += e->Nd, ++si) {
+        const int ns = (N - n0 < e->Nd) ? (N - n0) : e->Nd;
+        if (prof) HIP_OK(e, hipEventRecord(e->sub_ev[si * 3 + 0], e->stream));
+        rc = run_head(e, N, T, n0, ns, e->scores);
+        if (rc != MIBC_OK) return rc;
+        if (prof) HIP_OK(e, hipEventRecord(e->sub_ev[si * 3 + 1], e->stream));
+        if (mibc_launch_decode(e->stream, e->scores, ns, T, e->S, o->beam_width, o->beam_cut,
+                               o->blank_score, clamp_value(e), o->q_shift, o->q_scale, e->bwd, e->trace,
+                               e->path_state, out_dev + (size_t)n0 * T, (size_t)N * T,
+                               e->prob_tap) != 0)
+            return fail(e, MIBC_NOT_SUPPORTED, "decoder: beam_width must be 1..32");
+        if (prof) HIP_OK(e, hipEventRecord(e->sub_ev[si * 3 + 2], e->stream));
+    }
+    if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_END], e->stream));
+    e->last_N = N;
+    e->last_T = T;
+    e->last_T_in = T_in;
+    e->timed = prof;
+    HIP_OK(e, hipGetLastError());
+    return MIBC_OK;
+}
+
+extern "C" int mibc_call(mibc_engine *e, const uint16_t *in_host, int N, int T_in,
+                         const mibc_decode_opts *o, int8_t *out_host) {
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    const int T = mibc_output_steps(e, T_in);
+    HIP_OK(e, hipMemcpyAsync(e->in_stage, in_host, (size_t)N * T_in * 2, hipMemcpyHostToDevice,
+                             e->stream));
+    rc = mibc_call_device(e, (const uint16_t *)e->in_stage, N, T_in, o, e->out3);
+    if (rc != MIBC_OK) return rc;
+    HIP_OK(e, hipMemcpyAsync(out_host, e->out3, (size_t)3 * N * T, hipMemcpyDeviceToHost, e->stream));
+    HIP_OK(e, hipStreamSynchronize(e->stream));
+    return MIBC_OK;
+}
+
+extern "C" int mibc_get_stage_ms(mibc_engine *e, mibc_stage_ms *out) {
+    if (!e || !out) return MIBC_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    if (!e->timed) return fail(e, MIBC_ERR_ARG, "no profiled mibc_call_device yet (mibc_set_profile(1))");
+    HIP_OK(e, hipSetDevice(e->device));
+    HIP_OK(e, hipEventSynchronize(e->ev[mibc_engine::EV_END]));
+    float ms = 0;
+    HIP_OK(e, hipEventElapsedTime(&ms, e->ev[mibc_engine::EV_START], e->ev[mibc_engine::EV_CONV]));
+    out->conv = ms;
+    hipEvent_t prev = e->ev[mibc_engine::EV_CONV];
+    for (int l = 0; l < e->d.lstm_layers && l < 8; ++l) {
+        HIP_OK(e, hipEventElapsedTime(&ms, prev, e->ev[mibc_engine::EV_LSTM0 + l]));
+        out->lstm_layer[l] = ms;
+        out->lstm += ms;
+        prev = e->ev[mibc_engine::EV_LSTM0 + l];
+    }
+    const int nsub = (e->last_N + e->Nd - 1) / e->Nd;
+    for (int si = 0; si < nsub; ++si) {
+        HIP_OK(e, hipEventElapsedTime(&ms, e->sub_ev[si * 3 + 0], e->sub_ev[si * 3 + 1]));
+        out->head += ms;
+        HIP_OK(e, hipEventElapsedTime(&ms, e->sub_ev[si * 3 + 1], e->sub_ev[si * 3 + 2]));
+        out->decode += ms;
+    }
+    HIP_OK(e, hipEventElapsedTime(&ms, e->ev[mibc_engine::EV_START], e->ev[mibc_engine::EV_END]));
+    out->total = ms;
+    return MIBC_OK;
+}
+
+// min of 2 timed forward runs (network only), like CudaCaller.cpp:552-569
+extern "C" int mibc_time_forward(mibc_engine *e, int N, int T_in, float *ms_out) {
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    const int T = mibc_output_steps(e, T_in);
+    HIP_OK(e, hipMemsetAsync(e->in_stage, 0, (size_t)N * T_in * 2, e->stream));
+    float best = 1e30f;
+    hipEvent_t a, b;
+    HIP_OK(e, hipEventCreate(&a));
+    HIP_OK(e, hipEventCreate(&b));
+    const int save = e->profile;
+    e->profile = 0;
+    for (int it = 0; it < 3; ++it) {
+        HIP_OK(e, hipEventRecord(a, e->stream));
+        rc = run_encoder(e, e->in_stage, N, T_in);
+        if (rc == MIBC_OK)
+            for (int n0 = 0; n0 < N && rc == MIBC_OK; n0 += e->Nd)
+                rc = run_head(e, N, T, n0, (N - n0 < e->Nd) ? (N - n0) : e->Nd, e->scores);
+        HIP_OK(e, hipEventRecord(b, e->stream));
+        HIP_OK(e, hipEventSynchronize(b));
+        float ms = 0;
+        HIP_OK(e, hipEventElapsedTime(&ms, a, b));
+        if (it > 0 && ms < best) best = ms;  // first run is warm-up
+    }
+    e->profile = save;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (rc != MIBC_OK) return rc;
+    *ms_out = best;
+    return MIBC_OK;
+}
+
+extern "C" int mibc_debug_tap(mibc_engine *e, int tap, void *host_dst, size_t bytes) {
+    if (!e || !host_dst) return MIBC_ERR_ARG;
+    HIP_OK(e, hipSetDevice(e->device));
+    HIP_OK(e, hipStreamSynchronize(e->stream));
+    const void *src = nullptr;
+    size_t have = 0;
+    const size_t N = (size_t)e->last_N, T = (size_t)e->last_T, Tin = (size_t)e->last_T_in;
+    const size_t Nd = N < (size_t)e->Nd ? N : (size_t)e->Nd;
+    switch (tap) {
+        case 0: src = e->a1_tap; have = N * Tin * 16 * 2; break;
+        case 1: src = e->a2p; have = N * e->Tpitch * 16 * 2; break;
+        case 2: src = e->xa; have = T * N * e->C * 2; break;
+        case 3: src = e->lstm_out; have = T * N * e->C * 2; break;
+        case 4: src = e->bwd; have = Nd * (T + 1) * e->S * 4; break;
+        case 5: src = e->prob_tap; have = Nd * T * 4; break;
+        default: return fail(e, MIBC_ERR_ARG, "unknown tap");
+    }
+    if (!src) return fail(e, MIBC_ERR_ARG, "tap not recorded (set MIBC_TAPS=1 before mibc_create)");
+    if (bytes > have) return fail(e, MIBC_ERR_ARG, "tap: requested more bytes than recorded");
+    HIP_OK(e, hipMemcpy(host_dst, src, bytes, hipMemcpyDeviceToHost));
+    return MIBC_OK;
+}

@@ -1,0 +1,160 @@
+// dorado_amd/csrc/gemm.hip — f16 MFMA GEMM with row maps, used for
+//   (a2) conv3 as an implicit-im2col GEMM: out[t][n][:] = tanh(W3 . a2p[n][stride*t ..][:] + b)
+//        (replaces host_linear "cutlass_conv", dorado/nn/ConvStack.cpp:241-261), and
+//   (a4) the linear CRF head: scores[n][t][:] = [5 tanh](Wl . x[t][n][:] (+ b))
+//        (replaces host_linear at dorado/nn/CRFModules.cpp:112-117).
+//
+// C[m][c] = act( sum_k A(m)[k] * B[c][k] + bias[c] ),  A(m) = A + (m / a_div) * a_outer +
+// (m % a_div) * a_inner (halfs), both operands K-contiguous ("TN").  The output row map has the
+// same form.  Workgroup tile 128 x 128, BK = 32, 4 waves (2 x 2), each wave 64 x 64 as 2 x 2
+// v_mfma_f32_32x32x16_f16 tiles; weights are the MFMA A operand so that every lane owns 4
+// consecutive output columns of one row (packed 8-byte LDS writes), and the tile leaves through
+// LDS as full 256-byte rows (16-byte stores per lane) — the head's scores are the largest HBM
+// stream of the LSTM models (2 KB/step for hac).
+#include "common.h"
+
+struct GemmArgs {
+    const half_t *A;
+    const half_t *B;    // [Ncols][K]
+    const float *bias;  // [Ncols] or nullptr
+    half_t *out;
+    int M, Ncols, K;    // K multiple of 32, Ncols multiple of 128
+    int a_div;
+    long a_outer, a_inner;
+    int o_div;
+    long o_outer, o_inner;
+    int act;            // -1 identity, 0/1/2 as MIBC_ACT_*, 3 = 5*tanh
+};
+
+#define G_BM 128
+#define G_BN 128
+#define G_BK 32
+#define G_LD 40    // LDS row stride (halfs) for the K tiles: 80 B
+#define G_CLD 136  // LDS row stride (halfs) for the output tile: 272 B
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) half_t lds[G_BM * G_CLD];  // 34816 B; K tiles alias it
+    half_t *As = lds;                 // [128][40]
+    half_t *Bs = lds + G_BM * G_LD;   // [128][40]
+    half_t *Cs = lds;                 // [128][136]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware 1-D grid: block b runs on XCD b % 8 (observed placement, speed only).  All column
+    // tiles of one row tile are consecutive blocks of the SAME XCD so the activation tile is
+    // fetched into one L2 once and re-used for every column tile.
+    const int ncol = p.Ncols / G_BN;
+    const int nrow = (p.M + G_BM - 1) / G_BM;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int rowtile = (j / ncol) * 8 + xcd;
+    if (rowtile >= nrow) {
+        return;
+    }
+    const int m0 = rowtile * G_BM;
+    const int c0 = (j % ncol) * G_BN;
+
+    // staging assignment: row = tid >> 1, 16-half segment = tid & 1
+    const int lrow = tid >> 1, lseg = tid & 1;
+    int am = m0 + lrow;
+    if (am >= p.M) am = p.M - 1;
+    const half_t *a_src = p.A + (long)(am / p.a_div) * p.a_outer + (long)(am % p.a_div) * p.a_inner +
+                          lseg * 16;
+    const half_t *b_src = p.B + (long)(c0 + lrow) * p.K + lseg * 16;
+
+    float16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    half8_t ra0 = *(const half8_t *)(a_src);
+    half8_t ra1 = *(const half8_t *)(a_src + 8);
+    half8_t rb0 = *(const half8_t *)(b_src);
+    half8_t rb1 = *(const half8_t *)(b_src + 8);
+
+    const int nk = p.K / G_BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // previous tile's fragment reads are done
+        *(half8_t *)(As + lrow * G_LD + lseg * 16) = ra0;
+        *(half8_t *)(As + lrow * G_LD + lseg * 16 + 8) = ra1;
+        *(half8_t *)(Bs + lrow * G_LD + lseg * 16) = rb0;
+        *(half8_t *)(Bs + lrow * G_LD + lseg * 16 + 8) = rb1;
+        __syncthreads();
+        if (kt + 1 < nk) {
+            const int ko = (kt + 1) * G_BK;
+            ra0 = *(const half8_t *)(a_src + ko);
+            ra1 = *(const half8_t *)(a_src + ko + 8);
+            rb0 = *(const half8_t *)(b_src + ko);
+            rb1 = *(const half8_t *)(b_src + ko + 8);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8_t wf[2], xf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                wf[i] = *(const half8_t *)(Bs + (wn * 64 + i * 32 + (lane & 31)) * G_LD + ks * 16 +
+                                           8 * (lane >> 5));
+                xf[i] = *(const half8_t *)(As + (wm * 64 + i * 32 + (lane & 31)) * G_LD + ks * 16 +
+                                           8 * (lane >> 5));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32x32x16(wf[i], xf[j], acc[i][j]);
+        }
+    }
+    __syncthreads();  // all K-tile reads done before Cs (aliasing) is written
+
+    // epilogue: D rows = output columns (weights), D cols = output rows m
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int mloc = wm * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cloc = wn * 64 + i * 32 + 8 * q + 4 * (lane >> 5);
+                half4_t h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][q * 4 + e];
+                    if (p.bias != nullptr) v += p.bias[c0 + cloc + e];
+                    if (p.act == 3) {
+                        v = 5.0f * fast_tanh(v);
+                    } else if (p.act >= 0) {
+                        v = act_apply(v, p.act);
+                    }
+                    h[e] = (half_t)v;
+                }
+                *(half4_t *)(Cs + mloc * G_CLD + cloc) = h;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int c = tid + 256 * pass;
+        const int row = c >> 4, seg = c & 15;
+        const int m = m0 + row;
+        if (m < p.M) {
+            half_t *dst = p.out + (long)(m / p.o_div) * p.o_outer + (long)(m % p.o_div) * p.o_inner +
+                          c0 + seg * 8;
+            *(half8_t *)dst = *(const half8_t *)(Cs + row * G_CLD + seg * 8);
+        }
+    }
+}
+
+extern "C" int mibc_launch_gemm_tn(hipStream_t s, const GemmArgs *a) {
+    if (a->K % G_BK != 0 || a->Ncols % G_BN != 0 || a->M <= 0) {
+        return 1;
+    }
+    const int ncol = a->Ncols / G_BN;
+    const int nrow = (a->M + G_BM - 1) / G_BM;
+    dim3 grid(((nrow + 7) / 8) * 8 * ncol);
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, s, *a);
+    return 0;
+}

@@ -1,0 +1,134 @@
+/* include/mibc.h — C-ABI of the MI355X-native simplex basecalling engine ("mibc").
+ *
+ * This is the drop-in boundary: plain C, raw pointers and sizes, no torch types.
+ * It replaces what the reference reaches through `extern "C" { #include "koi.h" }` (closed
+ * source; call sites only) plus the libtorch ops around it, for the GPU side of
+ * basecall::ModelRunnerBase (dorado/basecall/include/basecall/ModelRunnerBase.h:20-38).
+ * The host-side C++ mirror of CudaCaller / CudaModelRunner that sits on top of this header is
+ * dorado_amd/host/ (HipCaller, HipModelRunner); INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions (Koi-like): every entry returns int: 0 = MIBC_OK, >0 = not supported (caller may
+ * fall back), <0 = error (text via mibc_last_error).  No exceptions cross this boundary.
+ * All device work of one engine is issued on that engine's own HIP stream; entries marked
+ * (async) return before the work completes — call mibc_sync().
+ */
+#ifndef MIBC_H
+#define MIBC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIBC_OK 0
+#define MIBC_NOT_SUPPORTED 1
+#define MIBC_ERR_ARG (-1)
+#define MIBC_ERR_HIP (-2)
+#define MIBC_ERR_MEM (-3)
+
+/* Activation ids == dorado/config/include/config/common.h:19 (enum Activation order). */
+#define MIBC_ACT_SWISH 0
+#define MIBC_ACT_SWISH_CLAMP 1
+#define MIBC_ACT_TANH 2
+
+/* The fields of config::BasecallModelConfig the hot path reads
+ * (dorado/config/include/config/BasecallModelConfig.h:99-160; ConvParams common.h:41-49). */
+typedef struct mibc_model_desc {
+    int n_convs;
+    int conv_insize[8], conv_size[8], conv_winlen[8], conv_stride[8];
+    int conv_act[8];
+    int lstm_size, lstm_layers;
+    int state_len, outsize;
+    int bias;         /* linear1 has a bias (pre-v4 / decomposed head) */
+    int clamp;        /* clamp scores to [-5,5] (folded into the decoder's score read, as
+                         CUDADecoder does: basecall/model/CRFModel.cpp:107-109) */
+    float scale;      /* 5.0 => head applies 5*tanh */
+    int out_features; /* >0: two-stage head (linear1 -> linear2); -1: single */
+    int num_features;
+    /* transformer (sup@v5) fields; tx_d_model <= 0 selects the LSTM-CRF path */
+    int tx_d_model, tx_nhead, tx_depth, tx_dim_ff, tx_win_upper, tx_win_lower, tx_max_seq_len;
+    float tx_deepnorm_alpha, tx_theta;
+    int up_size, up_scale_factor;
+    float crf_scale, crf_blank_score;
+    int crf_expand_blanks;
+} mibc_model_desc;
+
+/* basecall::decode::DecoderOptions (dorado/basecall/include/basecall/DecodedChunk.h:15-23). */
+typedef struct mibc_decode_opts {
+    int beam_width;    /* 32 */
+    float beam_cut;    /* 100.0 */
+    float blank_score; /* 2.0 (fixed stay score) */
+    float q_shift;     /* config qbias */
+    float q_scale;     /* config qscale */
+} mibc_decode_opts;
+
+/* Per-stage GPU time of the last mibc_call*/
+typedef struct mibc_stage_ms {
+    float conv, lstm, head, decode, total;
+    float lstm_layer[8]; /* per LSTM layer */
+    float h2d, d2h;
+} mibc_stage_ms;
+
+typedef struct mibc_engine mibc_engine;
+
+/* ---- devices (replaces torch_utils/cuda_utils.cpp:224-248,364-384 device discovery) ---- */
+int mibc_device_count(void);
+const char *mibc_last_error(const mibc_engine *e); /* e may be NULL: last global error */
+
+/* ---- lifetime (replaces CudaCaller ctor: basecall/CudaCaller.cpp:149-200) ----
+ * weights: host f32 tensors in module.parameters() order (basecall/crf_utils.cpp:34-88):
+ * conv{1..3}.{weight[Cout,Cin,W],bias}, rnn{1..L}.{weight_ih,weight_hh,bias_ih,bias_hh},
+ * linear1.weight [,linear1.bias] [,linear2.weight].  Converted to f16 device layouts once. */
+int mibc_create(int device_id, const mibc_model_desc *desc, const float *const *weights,
+                int n_weights, mibc_engine **out);
+void mibc_destroy(mibc_engine *e);
+
+/* ---- memory (replaces CudaCaller memory model :323-369 and WorkingMemory arena) ---- */
+int mibc_query_memory(const mibc_engine *e, int T_in, size_t *bytes_per_chunk, size_t *bytes_fixed);
+int mibc_reserve(mibc_engine *e, int N_max, int T_in); /* (re)allocates the device workspace */
+int mibc_output_steps(const mibc_engine *e, int T_in); /* T = number of output steps */
+int mibc_batch_granularity(const mibc_engine *e);      /* N must be a multiple of this */
+
+void *mibc_host_alloc(size_t bytes); /* pinned host memory (CudaCaller.cpp:289-314) */
+void mibc_host_free(void *p);
+void *mibc_device_alloc(mibc_engine *e, size_t bytes);
+void mibc_device_free(mibc_engine *e, void *p);
+int mibc_memcpy_h2d(mibc_engine *e, void *dst_dev, const void *src_host, size_t bytes); /* sync */
+int mibc_memcpy_d2h(mibc_engine *e, void *dst_host, const void *src_dev, size_t bytes); /* sync */
+
+/* ---- the hot path ----
+ * in:     f16 [N, 1, T_in]                (what BasecallerNode hands accept_chunk)
+ * scores: f16 [N, T, K], K = 4^(state_len+1)   (CRFModel.cpp:111: NTC f16)
+ * out:    int8 [3][N][T] = moves | bases (ASCII, packed at the front, NUL padded) | qstring
+ *         (identical to the reference's CUDADecoder buffer: decode/CUDADecoder.cpp:66-71,153-168)
+ */
+int mibc_forward(mibc_engine *e, const uint16_t *in_dev, int N, int T_in,
+                 uint16_t *scores_dev); /* (async) network only; replaces CRFModelImpl::run_koi */
+int mibc_decode(mibc_engine *e, const uint16_t *scores_dev, int N, int T,
+                const mibc_decode_opts *opts,
+                int8_t *out_dev); /* (async) replaces CUDADecoder::beam_search_part_1 */
+int mibc_call_device(mibc_engine *e, const uint16_t *in_dev, int N, int T_in,
+                     const mibc_decode_opts *opts, int8_t *out_dev); /* (async) forward+decode */
+int mibc_call(mibc_engine *e, const uint16_t *in_host, int N, int T_in,
+              const mibc_decode_opts *opts,
+              int8_t *out_host); /* H2D + forward + decode + D2H, synchronous
+                                    (CudaCaller::call_chunks, CudaCaller.cpp:224-271) */
+int mibc_sync(mibc_engine *e);
+
+/* ---- measurement (replaces CudaCaller.cpp:552-569 timing + gpu_profiling.h ranges) ---- */
+int mibc_time_forward(mibc_engine *e, int N, int T_in, float *ms); /* min of 2 runs, like :552-569 */
+int mibc_get_stage_ms(mibc_engine *e, mibc_stage_ms *out);         /* hipEvent times, last call */
+int mibc_set_profile(mibc_engine *e, int level);                   /* 0 off, 1 per-stage events */
+
+/* ---- parity taps (test-only; copy an intermediate of the LAST call to the host) ----
+ * tap: 0 conv1 out [N,T_in,16] f16 | 1 conv2 out (padded rows) | 2 conv3 out [T,N,C] f16
+ *      3 LSTM stack out [T,N,C] f16 | 4 back-guides [N,T+1,S] f32 (first decode sub-batch)
+ *      5 per-block quality prob [N,T] f32 */
+int mibc_debug_tap(mibc_engine *e, int tap, void *host_dst, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIBC_H */

@@ -1,0 +1,177 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).  Everything goes through the C-ABI
+(dorado_amd/libmibc.so via dorado_amd.capi); the CPU oracle (oracle/) is only the checker.
+
+Tolerances (stated contract):
+  * conv / LSTM activations (f16 storage, fp32 accumulate) vs the f32 oracle: max-abs <= 0.02
+    on tanh-bounded activations after 5 layers, rms <= 0.004
+  * CRF scores vs f32 oracle after clamp [-5,5]: max-abs <= 0.06, rms <= 0.01
+  * decoder on IDENTICAL f16 scores: back-guides bit-exact vs oracle(det=1), moves and bases
+    bit-exact, qstring within +-1
+  * end to end: per-chunk identity vs the oracle call >= 0.98 (median >= 0.995)
+"""
+import os
+
+import numpy as np
+import pytest
+
+from dorado_amd import capi, config, synth
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _identity(a: str, b: str) -> float:
+    """Alignment identity = 1 - edit_distance / max(len)."""
+    if not a and not b:
+        return 1.0
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return 1.0 - prev[-1] / max(len(a), len(b))
+
+
+def _cfg(C, state_len, layers):
+    cfg = config.tiny(C, state_len)
+    cfg.lstm_layers = layers
+    return cfg
+
+
+def _err(a, b):
+    d = np.abs(a.astype(np.float32) - b.astype(np.float32))
+    return float(d.max()), float(np.sqrt((d ** 2).mean()))
+
+
+@pytest.mark.parametrize("layers", [0, 1, 2, 5])
+def test_encoder_activations_vs_oracle(layers):
+    """conv1+conv2+conv3 (layers=0) and the LSTM stack layer by layer."""
+    cfg = _cfg(128, 3, layers)
+    ws = synth.make_weights(cfg, seed=5)
+    N, T_in = 64, 606
+    x16 = synth.make_signal(N, T_in, seed=6)
+    eng = capi.Engine(cfg, ws)
+    scores = eng.forward(x16)
+    T = eng.output_steps(T_in)
+    act = eng.tap(3, (T, N, cfg.lstm_size), np.float16)  # [T][N][C]
+    s_o, layer_o = O.lstm_crf_forward(cfg, ws, x16.astype(np.float32)[:, None, :], want_layer=True)
+    assert layer_o.shape == (N, T, cfg.lstm_size)
+    mx, rms = _err(act.transpose(1, 0, 2), layer_o)
+    print(f"layers={layers} activation max-abs {mx:.4f} rms {rms:.5f}")
+    assert mx <= 0.02 and rms <= 0.004
+    mx, rms = _err(np.clip(scores.astype(np.float32), -5, 5), s_o)
+    print(f"layers={layers} scores max-abs {mx:.4f} rms {rms:.5f}")
+    assert mx <= 0.06 and rms <= 0.01
+    eng.close()
+
+
+@pytest.mark.parametrize("C,state_len", [(128, 4), (256, 3), (384, 4)])
+def test_scores_vs_oracle_shapes(C, state_len):
+    cfg = _cfg(C, state_len, 5)
+    ws = synth.make_weights(cfg, seed=15)
+    N, T_in = 64, 366
+    x16 = synth.make_signal(N, T_in, seed=16)
+    eng = capi.Engine(cfg, ws)
+    scores = eng.forward(x16)
+    s_o = O.lstm_crf_forward(cfg, ws, x16.astype(np.float32)[:, None, :])
+    mx, rms = _err(np.clip(scores.astype(np.float32), -5, 5), s_o)
+    print(f"C={C} L={state_len} scores max-abs {mx:.4f} rms {rms:.5f}")
+    assert mx <= 0.06 and rms <= 0.01
+    eng.close()
+
+
+@pytest.mark.parametrize("name,state_len", [("dec_s3", 3), ("dec_s4", 4), ("dec_s5", 5)])
+def test_decoder_alone_vs_reference_fixture_and_oracle(name, state_len):
+    """Identical f16 scores in; compare with the REFERENCE's outputs (fixture) and oracle(det=1)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    s16 = g["scores_f16"]
+    n, T, K = s16.shape
+    cfg = _cfg(128, state_len, 0)
+    cfg.qscale, cfg.qbias = 1.1, -1.1
+    eng = capi.Engine(cfg, synth.make_weights(cfg, seed=1), taps=True)
+    dec = eng.decode(s16)
+    # back-guides: bit-exact against the oracle in det mode (same fixed fmaf sequence)
+    bwd_gpu = eng.tap(4, (n, T + 1, K // 4), np.float32)
+    sc = np.clip(s16.astype(np.float32), -5, 5)
+    _, bwd_o, _ = O.scans(sc, det=1)
+    assert np.array_equal(bwd_gpu.view(np.uint32), bwd_o.view(np.uint32)), \
+        f"back-guides not bit-exact: max diff {np.abs(bwd_gpu - bwd_o).max()}"
+    dec_o = O.decode(sc, q_shift=-1.1, q_scale=1.1, det=1)
+    for i, (seq, qs, mv) in enumerate(dec):
+        L = int(g["seqlen"][i])
+        want_seq = g["seq"][i, :L].tobytes().decode()
+        assert (mv == dec_o[i][2]).all() and seq == dec_o[i][0], f"chunk {i}: differs from oracle(det)"
+        assert (mv == g["moves"][i]).all() and seq == want_seq, f"chunk {i}: differs from reference"
+        dq = np.abs(np.frombuffer(qs.encode(), np.uint8).astype(int) - g["qstr"][i, :L].astype(int))
+        assert dq.max() <= 1, f"chunk {i}: qstring off by {dq.max()}"
+    eng.close()
+
+
+def test_decoder_of_network_scores_fixture():
+    """Scores produced by the REFERENCE network (f32) rounded to f16 -> GPU decoder == oracle(det)."""
+    g = np.load(os.path.join(GOLDEN, "net_tiny128_s4.npz"))
+    s16 = g["scores"].astype(np.float16)
+    cfg = _cfg(128, 4, 0)
+    eng = capi.Engine(cfg, synth.make_weights(cfg, seed=1))
+    dec = eng.decode(s16)
+    dec_o = O.decode(s16.astype(np.float32), det=1)
+    for (seq, qs, mv), (so, qo, mo) in zip(dec, dec_o):
+        assert seq == so and (mv == mo).all()
+        dq = np.abs(np.frombuffer(qs.encode(), np.uint8).astype(int) -
+                    np.frombuffer(qo.encode(), np.uint8).astype(int))
+        assert dq.max() <= 1
+    eng.close()
+
+
+def test_end_to_end_identity_vs_oracle():
+    """mibc_call (H2D + forward + decode + D2H) vs the oracle's full CPU path."""
+    cfg = _cfg(128, 4, 5)
+    cfg.qscale, cfg.qbias = 1.1, -1.1
+    ws = synth.make_weights(cfg, seed=25)
+    N, T_in = 64, 1206
+    x16 = synth.make_signal(N, T_in, seed=26)
+    eng = capi.Engine(cfg, ws)
+    eng.opts.q_shift, eng.opts.q_scale = cfg.qbias, cfg.qscale
+    got = eng.call(x16)
+    s_o = O.lstm_crf_forward(cfg, ws, x16.astype(np.float32)[:, None, :])
+    want = O.decode(s_o, q_shift=cfg.qbias, q_scale=cfg.qscale, det=0)
+    ids = np.array([_identity(a[0], b[0]) for a, b in zip(got, want)])
+    print("identity min/median/mean", ids.min(), np.median(ids), ids.mean(),
+          "mean len", np.mean([len(a[0]) for a in got]))
+    assert np.median(ids) >= 0.995 and ids.min() >= 0.98
+    # decoder exactness on the GPU's own scores
+    sc = eng.forward(x16)
+    want2 = O.decode(np.clip(sc.astype(np.float32), -5, 5), q_shift=cfg.qbias, q_scale=cfg.qscale, det=1)
+    for a, b in zip(got, want2):
+        assert a[0] == b[0] and (a[2] == b[2]).all()
+    eng.close()
+
+
+def test_round_trip_properties_full_chunk_hac():
+    """BASELINE-size chunk (T_in 9996, hac) — size-independent properties instead of the oracle:
+    moves sum == sequence length, moves[0] == 1, bases in ACGT, q in [33+1, 33+50], determinism."""
+    cfg = config.hac_v43()
+    ws = synth.make_weights(cfg, seed=42)
+    N, T_in = 64, cfg.chunk_size
+    x16 = synth.make_signal(N, T_in, seed=43)
+    eng = capi.Engine(cfg, ws)
+    a = eng.call(x16)
+    b = eng.call(x16)
+    T = eng.output_steps(T_in)
+    assert T == 1666
+    for (s1, q1, m1), (s2, q2, m2) in zip(a, b):
+        assert s1 == s2 and q1 == q2 and (m1 == m2).all()
+        assert m1[0] == 1 and int(m1.sum()) == len(s1) == len(q1)
+        assert set(s1) <= set("ACGT")
+        assert all(34 <= ord(c) <= 83 for c in q1)
+    print("bases/step", np.mean([len(s) for s, _, _ in a]) / T)
+    eng.close()
+
+
+def test_unsupported_shapes_fail_loudly():
+    cfg = _cfg(64, 3, 5)  # C=64 has no kernel yet
+    with pytest.raises(capi.MibcNotSupported):
+        capi.Engine(cfg, synth.make_weights(cfg, seed=1))
