@@ -554,6 +554,8 @@ extern "C" int mibc_decode(mibc_engine *e, const uint16_t *scores_dev, int N, in
                                           e->prob_tap);
         if (rc != 0) return fail(e, MIBC_NOT_SUPPORTED, "decoder: beam_width must be 1..32");
     }
+    e->last_N = N;
+    e->last_T = T;
     HIP_OK(e, hipGetLastError());
     return MIBC_OK;
 }
