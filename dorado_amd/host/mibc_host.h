@@ -1,0 +1,176 @@
+// dorado_amd/host/mibc_host.h — C++ host layer above the C-ABI (include/mibc.h).
+//
+// Mirrors, tensor-free and libtorch-free, the reference classes on either side of the drop-in
+// boundary:
+//   ModelRunnerBase   dorado/basecall/include/basecall/ModelRunnerBase.h:20-38 (same methods; the
+//                     only signature change is accept_chunk(idx, const uint16_t* f16, n) instead
+//                     of an at::Tensor — INTEGRATION.md shows the one-line adapter)
+//   HipModelRunner    dorado/basecall/CudaModelRunner.cpp:13-79 (pinned in/out, delegates to caller)
+//   HipCaller         dorado/basecall/CudaCaller.cpp:149-287,634-720 (1 per device: engine, FIFO,
+//                     one GPU thread, stats, terminate/restart)
+//   create_basecall_runners  dorado/api/runner_creation.cpp:46-133 ([device][runner] order)
+//   generate_chunks / stitch_chunks  dorado/read_pipeline/base/{chunk,stitch}.cpp
+//   SimplexBasecaller  the chunk -> batch -> call -> stitch loop of
+//                     dorado/read_pipeline/nodes/BasecallerNode.cpp:96-171,289-457,205-287
+//                     (one worker thread per runner, repeat-padding of short tails)
+#pragma once
+#include "../../include/mibc.h"
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+namespace dorado_amd::host {
+
+// basecall/include/basecall/DecodedChunk.h:9-13
+struct DecodedChunk {
+    std::string sequence;
+    std::string qstring;
+    std::vector<uint8_t> moves;
+};
+
+using NamedStats = std::map<std::string, double>;  // utils/include/utils/stats.h:25
+
+class ModelRunnerBase {
+public:
+    virtual ~ModelRunnerBase() = default;
+    virtual void accept_chunk(int chunk_idx, const uint16_t *chunk_f16, size_t n_samples) = 0;
+    virtual std::vector<DecodedChunk> call_chunks(int num_chunks) = 0;
+    virtual const mibc_model_desc &config() const = 0;
+    virtual size_t chunk_size() const = 0;
+    virtual size_t batch_size() const = 0;
+    virtual bool variable_chunk_sizes() const { return false; }
+    virtual std::pair<int, int> batch_timeouts_ms() const { return {100, 5000}; }  // ModelRunnerBase.cpp:6-9
+    virtual bool is_low_latency() const { return false; }
+    virtual void terminate() = 0;
+    virtual void restart() = 0;
+    virtual std::string get_name() const = 0;
+    virtual NamedStats sample_stats() const = 0;
+};
+using RunnerPtr = std::unique_ptr<ModelRunnerBase>;
+
+// torch_utils/cuda_utils.cpp:224-248,364-384 — accepts "hip:" and, for drop-in use, "cuda:".
+// Returns false (and sets error) exactly where the reference's try_parse_device_ids does.
+bool try_parse_device_ids(const std::string &device_string, size_t num_devices,
+                          std::vector<int> &device_ids, std::string &error_message);
+
+std::vector<size_t> generate_chunks(size_t num_samples, size_t chunk_size, size_t stride,
+                                    size_t overlap);  // throws like chunk.cpp:11-30
+
+struct Chunk {  // read_pipeline/base/include/read_pipeline/base/messages.h (utils::Chunk)
+    size_t input_offset = 0;
+    size_t raw_chunk_size = 0;
+    std::string seq, qstring;
+    std::vector<uint8_t> moves;
+};
+struct StitchedRead {
+    std::string seq, qstring;
+    std::vector<uint8_t> moves;
+};
+StitchedRead stitch_chunks(const std::vector<const Chunk *> &called_chunks, size_t raw_samples,
+                           int model_stride);  // stitch.cpp:12-96
+
+class HipCaller {
+public:
+    HipCaller(const mibc_model_desc &desc, const float *const *weights, int n_weights, int device,
+              int chunk_size, int batch_size, const mibc_decode_opts &opts);
+    ~HipCaller();
+    // Blocks until decoded (CudaCaller::call_chunks, CudaCaller.cpp:224-271).
+    // in: pinned f16 [batch][chunk]; out: pinned int8 [3][batch][T].
+    std::vector<DecodedChunk> call_chunks(const uint16_t *in_pinned, int8_t *out_pinned, int num_chunks);
+    void terminate();
+    void restart();
+    const mibc_model_desc &config() const { return m_desc; }
+    int chunk_size() const { return m_chunk_size; }
+    int batch_size() const { return m_batch_size; }
+    int output_steps() const { return m_T; }
+    int device() const { return m_device; }
+    std::pair<int, int> batch_timeouts_ms() const { return {300000, 30000}; }  // CudaCaller.cpp:126-132
+    NamedStats sample_stats() const;
+    std::string get_name() const { return "HipCaller_hip:" + std::to_string(m_device); }
+
+private:
+    struct NNTask {
+        const uint16_t *in;
+        int8_t *out;
+        int num_chunks;
+        int rc = 0;
+        bool done = false;
+        std::mutex mut;
+        std::condition_variable cv;
+    };
+    void start_thread();
+    void gpu_thread_fn();
+    mibc_model_desc m_desc;
+    mibc_decode_opts m_opts;
+    mibc_engine *m_engine = nullptr;
+    int m_device, m_chunk_size, m_batch_size, m_T = 0;
+    std::deque<std::shared_ptr<NNTask>> m_queue;
+    std::mutex m_mutex;
+    std::condition_variable m_cv;
+    std::thread m_thread;
+    std::atomic<bool> m_terminate{false};
+    std::atomic<int64_t> m_batches{0};
+    std::atomic<int64_t> m_model_decode_us{0};
+};
+
+class HipModelRunner final : public ModelRunnerBase {
+public:
+    explicit HipModelRunner(std::shared_ptr<HipCaller> caller);
+    ~HipModelRunner() override;
+    void accept_chunk(int chunk_idx, const uint16_t *chunk_f16, size_t n_samples) override;
+    std::vector<DecodedChunk> call_chunks(int num_chunks) override;
+    const mibc_model_desc &config() const override { return m_caller->config(); }
+    size_t chunk_size() const override { return size_t(m_caller->chunk_size()); }
+    size_t batch_size() const override { return size_t(m_caller->batch_size()); }
+    std::pair<int, int> batch_timeouts_ms() const override { return m_caller->batch_timeouts_ms(); }
+    void terminate() override { m_caller->terminate(); }
+    void restart() override { m_caller->restart(); }
+    std::string get_name() const override;
+    NamedStats sample_stats() const override;
+
+private:
+    std::shared_ptr<HipCaller> m_caller;
+    uint16_t *m_in = nullptr;  // pinned [batch][chunk]
+    int8_t *m_out = nullptr;   // pinned [3][batch][T]
+    int m_id;
+    std::atomic<int64_t> m_batches{0};
+};
+
+// [device][runner]; one caller per device, num_runners runners sharing it
+// (api/runner_creation.cpp:85-124; utils/include/utils/parameters.h:11 num_runners = 2).
+std::vector<std::vector<RunnerPtr>> create_basecall_runners(
+        const mibc_model_desc &desc, const float *const *weights, int n_weights,
+        const std::string &device_string, int num_runners, int chunk_size, int batch_size,
+        const mibc_decode_opts &opts);
+
+struct CalledRead {
+    std::string seq, qstring;
+    std::vector<uint8_t> moves;
+    std::vector<size_t> chunk_offsets;
+};
+
+// Chunk -> batch -> call -> stitch over a set of reads, one worker thread per runner pulling
+// from one shared chunk queue (BasecallerNode semantics without the message plumbing).
+class SimplexBasecaller {
+public:
+    SimplexBasecaller(std::vector<RunnerPtr> runners, int overlap, int model_stride);
+    std::vector<CalledRead> basecall(const std::vector<std::vector<uint16_t>> &reads_f16);
+    NamedStats sample_stats() const;
+
+private:
+    std::vector<RunnerPtr> m_runners;
+    int m_overlap, m_stride;
+    std::atomic<int64_t> m_samples_processed{0}, m_samples_incl_padding{0}, m_batches{0},
+            m_partial_batches{0};
+};
+
+}  // namespace dorado_amd::host

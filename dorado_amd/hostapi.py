@@ -1,0 +1,117 @@
+"""ctypes binding of the C++ host layer (dorado_amd/libmibc_host.so = dorado_amd/host/):
+chunking / stitching / device-string parsing (CPU-only entry points) and whole-read basecalling
+through create_basecall_runners + SimplexBasecaller (needs a GPU)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import capi
+from .config import ModelConfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmibc_host.so")
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def build() -> None:
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "host")])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        capi.lib()  # libmibc.so first (and torch's HIP runtime when available)
+        if not os.path.exists(LIB_PATH):
+            raise capi.MibcError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
+        L = C.CDLL(LIB_PATH)
+        L.mibch_last_error.restype = C.c_char_p
+        L.mibch_generate_chunks.restype = C.c_long
+        L.mibch_stitch_chunks.restype = C.c_long
+        _lib = L
+    return _lib
+
+
+def generate_chunks(num_samples, chunk_size, stride, overlap):
+    cap = 1 << 16
+    out = (C.c_uint64 * cap)()
+    n = lib().mibch_generate_chunks(C.c_uint64(num_samples), C.c_uint64(chunk_size), C.c_uint64(stride),
+                                    C.c_uint64(overlap), out, C.c_long(cap))
+    if n < 0:
+        raise ValueError(lib().mibch_last_error().decode())
+    return [int(out[i]) for i in range(n)]
+
+
+def parse_device_ids(s: str, num_devices: int):
+    ids = (C.c_int * 64)()
+    n = C.c_int(0)
+    ok = lib().mibch_parse_device_ids(s.encode(), C.c_uint64(num_devices), ids, 64, C.byref(n))
+    return bool(ok), [int(ids[i]) for i in range(n.value)]
+
+
+def stitch_chunks(offsets, raw_chunk_sizes, moves_list, seqs, qstrs, raw_samples, stride):
+    n = len(offsets)
+    moves = np.concatenate([np.asarray(m, np.uint8) for m in moves_list])
+    mlen = np.array([len(m) for m in moves_list], np.int64)
+    moff = np.concatenate([[0], np.cumsum(mlen)[:-1]]).astype(np.int64)
+    slen = np.array([len(s) for s in seqs], np.int64)
+    soff = np.concatenate([[0], np.cumsum(slen)[:-1]]).astype(np.int64)
+    cap = int(slen.sum()) + 8
+    so, qo = C.create_string_buffer(cap), C.create_string_buffer(cap)
+    mo = np.zeros(int(mlen.sum()) + 8, np.uint8)
+    nm = C.c_int64(0)
+    io, rc = np.asarray(offsets, np.int64), np.asarray(raw_chunk_sizes, np.int64)
+    L = lib().mibch_stitch_chunks(C.c_int(n), io.ctypes.data_as(_i64p), rc.ctypes.data_as(_i64p),
+                                  moves.ctypes.data_as(_u8p), moff.ctypes.data_as(_i64p),
+                                  mlen.ctypes.data_as(_i64p), "".join(seqs).encode(),
+                                  "".join(qstrs).encode(), soff.ctypes.data_as(_i64p),
+                                  slen.ctypes.data_as(_i64p), C.c_int64(raw_samples), C.c_int(stride),
+                                  so, qo, mo.ctypes.data_as(_u8p), C.byref(nm))
+    if L < 0:
+        raise ValueError(lib().mibch_last_error().decode())
+    return so.raw[:L].decode(), qo.raw[:L].decode(), mo[: nm.value].copy()
+
+
+def basecall_reads(cfg: ModelConfig, weights, reads_f16, device="hip:0", num_runners=2, batch_size=64,
+                   beam_width=32):
+    """reads_f16: list of 1-D f16 arrays.  Returns (list of (seq, qstr, moves, chunk_offsets), stats)."""
+    L = lib()
+    d = cfg.to_desc()
+    ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+    arr = (C.POINTER(C.c_float) * len(ws))(*[w.ctypes.data_as(C.POINTER(C.c_float)) for w in ws])
+    opts = capi.DecodeOptsC(beam_width, 100.0, 2.0, cfg.qbias, cfg.qscale)
+    sig = np.ascontiguousarray(np.concatenate(reads_f16).astype(np.float16))
+    lens = np.array([len(r) for r in reads_f16], np.int64)
+    n = len(reads_f16)
+    tot_steps = int(sum(l // cfg.stride + 2 for l in lens))
+    seq = C.create_string_buffer(tot_steps + 8)
+    qs = C.create_string_buffer(tot_steps + 8)
+    mv = np.zeros(tot_steps + 8, np.uint8)
+    sl = np.zeros(n, np.int64)
+    ml = np.zeros(n, np.int64)
+    max_off = int(sum(l // (cfg.chunk_size - cfg.overlap) + 3 for l in lens))
+    offs = np.zeros(max_off, np.int64)
+    noff = np.zeros(n, np.int64)
+    stats = (C.c_double * 4)()
+    rc = L.mibch_basecall_reads(C.byref(d), arr, len(ws), device.encode(), num_runners, cfg.chunk_size,
+                                cfg.overlap, batch_size, C.byref(opts), sig.ctypes.data_as(C.c_void_p),
+                                lens.ctypes.data_as(_i64p), n, seq, qs, sl.ctypes.data_as(_i64p),
+                                mv.ctypes.data_as(_u8p), ml.ctypes.data_as(_i64p),
+                                offs.ctypes.data_as(_i64p), noff.ctypes.data_as(_i64p), stats)
+    if rc != 0:
+        raise capi.MibcError(L.mibch_last_error().decode())
+    out = []
+    so = mo = oo = 0
+    for r in range(n):
+        out.append((seq.raw[so:so + sl[r]].decode(), qs.raw[so:so + sl[r]].decode(),
+                    mv[mo:mo + ml[r]].copy(), offs[oo:oo + noff[r]].tolist()))
+        so += int(sl[r]); mo += int(ml[r]); oo += int(noff[r])
+    return out, {"samples_processed": stats[0], "samples_incl_padding": stats[1],
+                 "batches_called": stats[2], "partial_batches_called": stats[3]}

@@ -18,7 +18,7 @@ import os
 import numpy as np
 import pytest
 
-from dorado_amd import capi, config, synth
+from dorado_amd import capi, config, hostapi, synth
 from oracle import oracle_py as O
 
 pytestmark = pytest.mark.gpu
@@ -182,3 +182,52 @@ def test_unsupported_shapes_fail_loudly():
     cfg = _cfg(64, 3, 5)  # C=64 has no kernel yet
     with pytest.raises(capi.MibcNotSupported):
         capi.Engine(cfg, synth.make_weights(cfg, seed=1))
+
+
+def test_host_layer_whole_reads_vs_oracle_pipeline():
+    """C++ host layer (create_basecall_runners -> HipCaller/HipModelRunner -> SimplexBasecaller):
+    chunk offsets bit-exact, stitched reads == oracle stitch of the same per-chunk calls, and
+    identity vs the all-f32 oracle pipeline."""
+    cfg = _cfg(128, 4, 5)
+    cfg.chunk_size, cfg.overlap = 1200, 120
+    cfg.normalise_basecaller_params()
+    ws = synth.make_weights(cfg, seed=31)
+    lens = [300, 1200, 1201, 2500, 3333, 5000, 799, 4096]
+    reads = [synth.make_signal(1, L, seed=100 + i)[0] for i, L in enumerate(lens)]
+    got, stats = hostapi.basecall_reads(cfg, ws, reads, device="hip:0", num_runners=2, batch_size=64)
+    assert stats["samples_processed"] == sum(lens)
+    # per-chunk reference pipeline: same chunking + repeat padding, GPU engine for the per-chunk
+    # calls, oracle stitch
+    eng = capi.Engine(cfg, ws)
+    eng.opts.q_shift, eng.opts.q_scale = cfg.qbias, cfg.qscale
+    all_chunks, owner = [], []
+    for r, sig in enumerate(reads):
+        offs = O.generate_chunks(len(sig), cfg.chunk_size, cfg.stride, cfg.overlap)
+        assert got[r][3] == offs                       # bit-exact chunk offsets
+        for o in offs:
+            sl = sig[o:o + cfg.chunk_size]
+            if len(sl) != cfg.chunk_size:              # BasecallerNode.cpp:432-440
+                n, ov = divmod(cfg.chunk_size, len(sl))
+                sl = np.concatenate([np.tile(sl, n), sl[:ov]])
+            all_chunks.append(sl)
+            owner.append((r, o))
+    x = np.zeros((64, cfg.chunk_size), np.float16)
+    x[:len(all_chunks)] = np.stack(all_chunks)
+    calls = eng.call(x)
+    s_o = O.lstm_crf_forward(cfg, ws, x[:len(all_chunks)].astype(np.float32)[:, None, :])
+    calls_o = O.decode(s_o, q_shift=cfg.qbias, q_scale=cfg.qscale)
+    ids = []
+    for r, sig in enumerate(reads):
+        idx = [i for i, (rr, _) in enumerate(owner) if rr == r]
+        offs = [owner[i][1] for i in idx]
+        st = O.stitch_chunks(offs, [cfg.chunk_size] * len(idx), [calls[i][2] for i in idx],
+                             [calls[i][0] for i in idx], [calls[i][1] for i in idx], len(sig), cfg.stride)
+        assert got[r][0] == st[0] and got[r][1] == st[1] and (got[r][2] == st[2]).all()
+        st_o = O.stitch_chunks(offs, [cfg.chunk_size] * len(idx), [calls_o[i][2] for i in idx],
+                               [calls_o[i][0] for i in idx], [calls_o[i][1] for i in idx], len(sig),
+                               cfg.stride)
+        ids.append(_identity(got[r][0], st_o[0]))
+        assert len(got[r][2]) == len(sig) // cfg.stride
+    print("whole-read identity vs f32 oracle pipeline:", np.round(ids, 3))
+    assert np.mean(ids) >= 0.95
+    eng.close()
