@@ -33,8 +33,8 @@ extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w
                                   const float *w2, const float *b2, half_t *a2p, half_t *a1_tap,
                                   int N, int T_in, int Tpitch, int pad, int act1, int act2);
 extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, half_t *Xout,
-                                      const half_t *Wf, const float *biasf, int T, int N,
-                                      int reverse);
+                                      const half_t *Wf, const float *biasf, const float *biasn,
+                                      int T, int N, int reverse);
 extern "C" int mibc_launch_decode(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
                                   float beam_cut, float stay, float clampv, float q_shift,
                                   float q_scale, float *bwd, uint32_t *trace,
@@ -54,6 +54,7 @@ struct mibc_engine {
     int K3 = 0, K3pad = 0;
     std::vector<half_t *> lstm_w;
     std::vector<float *> lstm_b;
+    std::vector<float *> lstm_bn;  // natural hidden-unit order (v2 kernel)
     half_t *head_w1 = nullptr, *head_w2 = nullptr;
     float *head_b1 = nullptr;
     int head_act1 = -1, head_act2 = -1;
@@ -224,11 +225,17 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
                         const int hid = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                         bf[(((size_t)j * 4 + g) * 2 + lhi) * 16 + r] = bih[g * C + hid] + bhh[g * C + hid];
                     }
+        std::vector<float> bn((size_t)4 * C);
+        for (int j = 0; j < C / 32; ++j)
+            for (int g = 0; g < 4; ++g)
+                for (int h = 0; h < 32; ++h)
+                    bn[((size_t)j * 4 + g) * 32 + h] = bih[g * C + 32 * j + h] + bhh[g * C + 32 * j + h];
         half_t *dw = nullptr;
-        float *db = nullptr;
-        if (upload(e, &dw, wf) || upload(e, &db, bf)) return MIBC_ERR_HIP;
+        float *db = nullptr, *dbn = nullptr;
+        if (upload(e, &dw, wf) || upload(e, &db, bf) || upload(e, &dbn, bn)) return MIBC_ERR_HIP;
         e->lstm_w.push_back(dw);
         e->lstm_b.push_back(db);
+        e->lstm_bn.push_back(dbn);
     }
     // head (basecall/model/CRFModel.cpp:43-61)
     const int tanh_x5 = (d.scale == 5.0f) ? 3 : -1;
@@ -288,6 +295,7 @@ extern "C" void mibc_destroy(mibc_engine *e) {
         if (p) (void)hipFree(p);
     for (auto p : e->lstm_w) (void)hipFree(p);
     for (auto p : e->lstm_b) (void)hipFree(p);
+    for (auto p : e->lstm_bn) (void)hipFree(p);
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -442,8 +450,8 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     for (int l = 0; l < d.lstm_layers; ++l) {
         // LSTMStack(layers, size, reverse_first = true): nn/LSTMStack.cpp:29-41, CRFModel.cpp:41
         const int reverse = (l % 2 == 0) ? 1 : 0;
-        if (mibc_launch_lstm_layer(e->stream, e->C, cur, nxt, e->lstm_w[l], e->lstm_b[l], T, N,
-                                   reverse) != 0)
+        if (mibc_launch_lstm_layer(e->stream, e->C, cur, nxt, e->lstm_w[l], e->lstm_b[l], e->lstm_bn[l], T,
+                                   N, reverse) != 0)
             return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
         if (prof && l < 8) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_LSTM0 + l], e->stream));
         half_t *t = cur;

@@ -22,6 +22,7 @@
 //     for HBM as whole 16-byte-per-lane rows after the step barrier.
 // Wave w owns hidden tiles [w*HT, (w+1)*HT), HT = C/128 (hac: 3, sup: 8).
 #include "common.h"
+#include <stdlib.h>
 
 #define L_NB 64
 #define L_PF 4  // weight ring depth (k-steps in flight)
@@ -190,13 +191,196 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// v2: x_t staged through LDS (each row read from HBM once per workgroup, fully coalesced, fetched
+// one step ahead into registers), weights through buffer loads with scalar offsets (no per-load
+// VALU address math) and a deeper ring.  Used for C <= 384 (LDS: 2 h buffers + 1 x buffer).
+// ---------------------------------------------------------------------------------------------
+
+template <int C, int PF>
+__global__ __launch_bounds__(256, 1) void lstm_layer_v2_kernel(
+        const half_t *__restrict__ Xin,   // [T][N][C]
+        half_t *__restrict__ Xout,        // [T][N][C]
+        const half_t *__restrict__ Wf,    // [C/32][2C/16][4][64][8]
+        const float *__restrict__ biasn,  // [C/32][4][32]  (b_ih + b_hh), hidden-unit order
+        int T, int N, int reverse) {
+    constexpr int HT = C / 128;
+    constexpr int KS = 2 * C / 16;
+    constexpr int KSX = C / 16;
+    constexpr int LD = C + 8;
+    constexpr int XPF = C / 32;  // 16-byte chunks per thread for one x_t block (64 rows)
+    constexpr int KTOT = HT * KS;
+    __shared__ __attribute__((aligned(16))) half_t hbuf[2][L_NB * LD];
+    __shared__ __attribute__((aligned(16))) half_t xbuf[L_NB * LD];
+    __shared__ __attribute__((aligned(16))) float bias_s[4 * C];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int n0 = blockIdx.x * L_NB;
+
+    for (int i = tid; i < L_NB * LD / 8; i += 256) ((half8_t *)hbuf[0])[i] = (half8_t)(0);
+    for (int i = tid; i < 4 * C; i += 256) bias_s[i] = biasn[i];
+
+    float16_t cst[HT][2];
+#pragma unroll
+    for (int a = 0; a < HT; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cst[a][b][r] = 0.0f;
+
+    // weights: one buffer resource per wave (its HT hidden tiles), scalar offset per k-step
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(Wf + (size_t)wave * HT * KS * 4 * 64 * 8), 0, HT * KS * 4 * 64 * 16, 0x00020000);
+    const int wvoff = lane * 16;
+    half8_t wr[PF][4];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            wr[u][g] = __builtin_bit_cast(
+                    half8_t, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, (u * 4 + g) * 1024, 0));
+    int kpre = PF;
+
+    // x_{t0} -> LDS
+    {
+        const int t_first = reverse ? (T - 1) : 0;
+        const half_t *xg = Xin + ((size_t)t_first * N + n0) * C;
+#pragma unroll
+        for (int p = 0; p < XPF; ++p) {
+            const int c = tid + 256 * p;
+            const int row = c / (C / 8), col8 = c % (C / 8);
+            *(half8_t *)(xbuf + row * LD + col8 * 8) = *(const half8_t *)(xg + (size_t)c * 8);
+        }
+    }
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int t = reverse ? (T - 1 - step) : step;
+        const int tn = (step + 1 < T) ? (reverse ? (t - 1) : (t + 1)) : t;
+        const half_t *hprev = hbuf[step & 1];
+        half_t *hnext = hbuf[(step + 1) & 1];
+
+        // fetch x_{t+1} now, park it in registers, store it to LDS after this step's barrier
+        half8_t xpf[XPF];
+        {
+            const half_t *xg = Xin + ((size_t)tn * N + n0) * C;
+#pragma unroll
+            for (int p = 0; p < XPF; ++p) xpf[p] = *(const half8_t *)(xg + (size_t)(tid + 256 * p) * 8);
+        }
+
+#pragma unroll
+        for (int jj = 0; jj < HT; ++jj) {
+            const int j = wave * HT + jj;
+            float16_t acc[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float *bp = bias_s + (j * 4 + g) * 32 + 4 * lhi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4_t v = *(const float4_t *)(bp + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[g][0][q * 4 + e] = v[e];
+                        acc[g][1][q * 4 + e] = v[e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int phase = 0; phase < 2; ++phase) {
+                const half_t *bsrc = (phase == 0 ? xbuf : hprev) + l31 * LD + 8 * lhi;
+#pragma nounroll
+                for (int ks0 = 0; ks0 < KSX; ks0 += PF) {
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {
+                        const int ks = ks0 + u;
+                        const half8_t b0 = *(const half8_t *)(bsrc + ks * 16);
+                        const half8_t b1 = *(const half8_t *)(bsrc + 32 * LD + ks * 16);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            acc[g][0] = mfma32x32x16(wr[u][g], b0, acc[g][0]);
+                            acc[g][1] = mfma32x32x16(wr[u][g], b1, acc[g][1]);
+                        }
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            wr[u][g] = __builtin_bit_cast(
+                                    half8_t, __builtin_amdgcn_raw_buffer_load_b128(
+                                                     wrs, wvoff, (kpre * 4 + g) * 1024, 0));
+                        kpre = (kpre + 1 == KTOT) ? 0 : kpre + 1;
+                    }
+                }
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                half_t *hdst = hnext + (nb * 32 + l31) * LD + j * 32 + 4 * lhi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    half4_t hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = q * 4 + e;
+                        const float ig = fast_sigmoid(acc[0][nb][r]);
+                        const float fg = fast_sigmoid(acc[1][nb][r]);
+                        const float gg = fast_tanh(acc[2][nb][r]);
+                        const float og = fast_sigmoid(acc[3][nb][r]);
+                        const float c = fmaf(fg, cst[jj][nb][r], ig * gg);
+                        cst[jj][nb][r] = c;
+                        hv[e] = (half_t)(og * fast_tanh(c));
+                    }
+                    *(half4_t *)(hdst + 8 * q) = hv;
+                }
+            }
+        }
+        __syncthreads();  // h_t complete; nobody reads x_t / h_{t-1} any more
+#pragma unroll
+        for (int p = 0; p < XPF; ++p) {
+            const int c = tid + 256 * p;
+            const int row = c / (C / 8), col8 = c % (C / 8);
+            *(half8_t *)(xbuf + row * LD + col8 * 8) = xpf[p];
+        }
+        half_t *orow = Xout + ((size_t)t * N + n0) * C;
+#pragma unroll
+        for (int p = 0; p < XPF; ++p) {
+            const int c = tid + 256 * p;
+            const int row = c / (C / 8), col8 = c % (C / 8);
+            *(half8_t *)(orow + (size_t)c * 8) = *(const half8_t *)(hnext + row * LD + col8 * 8);
+        }
+        __syncthreads();  // x_{t+1} visible
+    }
+}
+
 extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, half_t *Xout,
-                                      const half_t *Wf, const float *biasf, int T, int N,
-                                      int reverse) {
+                                      const half_t *Wf, const float *biasf, const float *biasn,
+                                      int T, int N, int reverse) {
+    static const int ver = getenv("MIBC_LSTM_V") ? atoi(getenv("MIBC_LSTM_V")) : 2;
     if (N % L_NB != 0) {
         return 1;
     }
     dim3 grid(N / L_NB), block(256);
+    if (ver >= 2 && C <= 384) {
+        static const int pf = getenv("MIBC_LSTM_PF") ? atoi(getenv("MIBC_LSTM_PF")) : 4;
+        switch (C) {
+            case 128:
+                hipLaunchKernelGGL((lstm_layer_v2_kernel<128, 8>), grid, block, 0, s, Xin, Xout, Wf, biasn, T, N, reverse);
+                return 0;
+            case 256:
+                hipLaunchKernelGGL((lstm_layer_v2_kernel<256, 8>), grid, block, 0, s, Xin, Xout, Wf, biasn, T, N, reverse);
+                return 0;
+            case 384:
+                if (pf == 6)
+                    hipLaunchKernelGGL((lstm_layer_v2_kernel<384, 6>), grid, block, 0, s, Xin, Xout, Wf, biasn, T, N, reverse);
+                else if (pf == 3)
+                    hipLaunchKernelGGL((lstm_layer_v2_kernel<384, 3>), grid, block, 0, s, Xin, Xout, Wf, biasn, T, N, reverse);
+                else
+                    hipLaunchKernelGGL((lstm_layer_v2_kernel<384, 4>), grid, block, 0, s, Xin, Xout, Wf, biasn, T, N, reverse);
+                return 0;
+            default:
+                break;
+        }
+    }
 #define LSTM_CASE(CC)                                                                          \
     case CC:                                                                                   \
         hipLaunchKernelGGL((lstm_layer_kernel<CC>), grid, block, 0, s, Xin, Xout, Wf, biasf, T, N, \

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Print hipEvent stage times of one hot-path call (hac shape by default).
+    python tools/stage_times.py [--batch N] [--steps K] [--model hac]
+Env knobs are read by libmibc (e.g. MIBC_LSTM_ABLATE, MIBC_DECODE_SUB)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dorado_amd import capi, config, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=16384)
+ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--model", default="hac")
+ap.add_argument("--tin", type=int, default=0)
+a = ap.parse_args()
+cfg = config.hac_v43() if a.model == "hac" else config.tiny(128, 4)
+t_in = a.tin or cfg.chunk_size
+eng = capi.Engine(cfg, synth.make_weights(cfg, seed=42))
+T = eng.output_steps(t_in)
+n = a.batch
+eng.reserve(n, t_in)
+base = synth.make_signal(min(n, 128), t_in, seed=1)
+x = np.tile(base, ((n + base.shape[0] - 1) // base.shape[0], 1))[:n]
+d_in = eng.device_alloc(x.nbytes)
+d_out = eng.device_alloc(3 * n * T)
+eng.h2d(d_in, x)
+eng.set_profile(1)
+res = None
+for _ in range(a.steps):
+    eng.call_device(d_in, n, t_in, d_out)
+    res = eng.stage_ms()
+res["lstm_layer"] = [round(v, 2) for v in res["lstm_layer"][: cfg.lstm_layers]]
+res = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}
+res["env"] = {k: v for k, v in os.environ.items() if k.startswith("MIBC_")}
+print(json.dumps(res))
