@@ -124,6 +124,8 @@ def main():
 
     if args.model == "hac":
         cfg = config.hac_v43()
+    elif args.model == "sup":
+        cfg = config.sup_v43()
     elif args.model == "tiny":
         cfg = config.tiny(128, 4)
     else:
@@ -139,7 +141,8 @@ def main():
         per_chunk, fixed = eng.query_memory(t_in)
         free_b, total_b = torch.cuda.mem_get_info(local_rank)
         cap = int((free_b * 0.8 - fixed) // per_chunk)
-        n = max(64, min(16384, (cap // 64) * 64))
+        g = eng.batch_granularity()
+        n = max(g, min(256 * g, (cap // g) * g))   # one LSTM workgroup per CU
     eng.reserve(n, t_in)
 
     # synthetic signal: 256 distinct seeded chunks tiled to the batch, resident in HBM

@@ -148,6 +148,9 @@ class Engine:
         except Exception:
             pass
 
+    def batch_granularity(self) -> int:
+        return int(lib().mibc_batch_granularity(self._h))
+
     def output_steps(self, t_in: int) -> int:
         return int(lib().mibc_output_steps(self._h, t_in))
 
@@ -236,7 +239,8 @@ class Engine:
         n, t, k = s.shape
         t_in = t_in_for_reserve if t_in_for_reserve is not None else t * self.cfg.stride
         assert self.output_steps(t_in) == t
-        self.reserve(max(64, (n + 63) // 64 * 64), t_in)
+        g = int(lib().mibc_batch_granularity(self._h))
+        self.reserve(max(g, (n + g - 1) // g * g), t_in)
         d_sc = self.device_alloc(s.nbytes)
         d_out = self.device_alloc(3 * n * t)
         try:

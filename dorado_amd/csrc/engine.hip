@@ -33,8 +33,8 @@ extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w
                                   const float *w2, const float *b2, half_t *a2p, half_t *a1_tap,
                                   int N, int T_in, int Tpitch, int pad, int act1, int act2);
 extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, half_t *Xout,
-                                      const half_t *Wf, const float *biasf, const float *biasn,
-                                      int T, int N, int reverse);
+                                      const half_t *Wf, const float *biasn, int T, int N, int reverse);
+extern "C" int mibc_lstm_rows_per_wg(int C);
 extern "C" int mibc_launch_decode(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
                                   float beam_cut, float stay, float clampv, float q_shift,
                                   float q_scale, float *bwd, uint32_t *trace,
@@ -53,8 +53,7 @@ struct mibc_engine {
     half_t *w3 = nullptr;  // [C][K3pad]
     int K3 = 0, K3pad = 0;
     std::vector<half_t *> lstm_w;
-    std::vector<float *> lstm_b;
-    std::vector<float *> lstm_bn;  // natural hidden-unit order (v2 kernel)
+    std::vector<float *> lstm_bn;  // b_ih + b_hh, [C/32][4][32]
     half_t *head_w1 = nullptr, *head_w2 = nullptr;
     float *head_b1 = nullptr;
     int head_act1 = -1, head_act2 = -1;
@@ -132,8 +131,9 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
                     "conv front-end must be 1->16 (w5,s1) ->16 (w5,s1) ->C (v4 LSTM-CRF models)");
     }
     const int C = d.lstm_size;
-    if (d.conv_size[2] != C || (C != 128 && C != 256 && C != 384 && C != 512)) {
-        return fail(nullptr, MIBC_NOT_SUPPORTED, "lstm_size must be one of 128/256/384/512 for now");
+    if (d.conv_size[2] != C || mibc_lstm_rows_per_wg(C) == 0) {
+        return fail(nullptr, MIBC_NOT_SUPPORTED,
+                    "lstm_size must be one of 128/256/384/512/768/1024 for now");
     }
     const int S = 1 << (2 * d.state_len);
     if (S != 64 && S != 256 && S != 1024) {
@@ -217,24 +217,15 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
                                                     : Whh[(size_t)row * C + (k - C)];
                             wf[((((size_t)j * KS + ks) * 4 + g) * 64 + lane) * 8 + i] = (half_t)v;
                         }
-        std::vector<float> bf((size_t)4 * C * 2);
-        for (int j = 0; j < C / 32; ++j)
-            for (int g = 0; g < 4; ++g)
-                for (int lhi = 0; lhi < 2; ++lhi)
-                    for (int r = 0; r < 16; ++r) {
-                        const int hid = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        bf[(((size_t)j * 4 + g) * 2 + lhi) * 16 + r] = bih[g * C + hid] + bhh[g * C + hid];
-                    }
         std::vector<float> bn((size_t)4 * C);
         for (int j = 0; j < C / 32; ++j)
             for (int g = 0; g < 4; ++g)
                 for (int h = 0; h < 32; ++h)
                     bn[((size_t)j * 4 + g) * 32 + h] = bih[g * C + 32 * j + h] + bhh[g * C + 32 * j + h];
         half_t *dw = nullptr;
-        float *db = nullptr, *dbn = nullptr;
-        if (upload(e, &dw, wf) || upload(e, &db, bf) || upload(e, &dbn, bn)) return MIBC_ERR_HIP;
+        float *dbn = nullptr;
+        if (upload(e, &dw, wf) || upload(e, &dbn, bn)) return MIBC_ERR_HIP;
         e->lstm_w.push_back(dw);
-        e->lstm_b.push_back(db);
         e->lstm_bn.push_back(dbn);
     }
     // head (basecall/model/CRFModel.cpp:43-61)
@@ -294,7 +285,6 @@ extern "C" void mibc_destroy(mibc_engine *e) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto p : e->lstm_w) (void)hipFree(p);
-    for (auto p : e->lstm_b) (void)hipFree(p);
     for (auto p : e->lstm_bn) (void)hipFree(p);
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -307,11 +297,11 @@ extern "C" int mibc_output_steps(const mibc_engine *e, int T_in) {
     return (T_in + 2 * e->pad3 - W3) / e->stride + 1;
 }
 
-extern "C" int mibc_batch_granularity(const mibc_engine *) { return 64; }
+extern "C" int mibc_batch_granularity(const mibc_engine *e) { return mibc_lstm_rows_per_wg(e->C); }
 
 static int decode_sub(const mibc_engine *e, int N) {
     const char *s = getenv("MIBC_DECODE_SUB");
-    int nd = s ? atoi(s) : 4096;
+    int nd = s ? atoi(s) : (e->K > 1024 ? 2048 : 4096);  // keeps scores+guides per sub-batch <= ~45 GB
     if (nd < 64) nd = 64;
     nd = (nd / 64) * 64;
     return N < nd ? N : nd;
@@ -337,7 +327,8 @@ extern "C" int mibc_query_memory(const mibc_engine *e, int T_in, size_t *bytes_p
 
 extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
     if (!e || N_max <= 0 || T_in <= 0) return MIBC_ERR_ARG;
-    if (N_max % 64 != 0) return fail(e, MIBC_ERR_ARG, "N_max must be a multiple of 64");
+    if (N_max % mibc_lstm_rows_per_wg(e->C) != 0)
+        return fail(e, MIBC_ERR_ARG, "N_max must be a multiple of mibc_batch_granularity()");
     HIP_OK(e, hipSetDevice(e->device));
     if (e->N_res >= N_max && e->T_in_res == T_in) return MIBC_OK;
     HIP_OK(e, hipStreamSynchronize(e->stream));
@@ -450,8 +441,7 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     for (int l = 0; l < d.lstm_layers; ++l) {
         // LSTMStack(layers, size, reverse_first = true): nn/LSTMStack.cpp:29-41, CRFModel.cpp:41
         const int reverse = (l % 2 == 0) ? 1 : 0;
-        if (mibc_launch_lstm_layer(e->stream, e->C, cur, nxt, e->lstm_w[l], e->lstm_b[l], e->lstm_bn[l], T,
-                                   N, reverse) != 0)
+        if (mibc_launch_lstm_layer(e->stream, e->C, cur, nxt, e->lstm_w[l], e->lstm_bn[l], T, N, reverse) != 0)
             return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
         if (prof && l < 8) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_LSTM0 + l], e->stream));
         half_t *t = cur;
@@ -515,7 +505,8 @@ static int run_head(mibc_engine *e, int N, int T, int n0, int ns, half_t *scores
 
 static int check_call(mibc_engine *e, int N, int T_in) {
     if (!e) return MIBC_ERR_ARG;
-    if (N <= 0 || N % 64 != 0) return fail(e, MIBC_ERR_ARG, "N must be a positive multiple of 64");
+    if (N <= 0 || N % mibc_lstm_rows_per_wg(e->C) != 0)
+        return fail(e, MIBC_ERR_ARG, "N must be a positive multiple of mibc_batch_granularity()");
     if (e->N_res < N || e->T_in_res != T_in) {
         const int rc = mibc_reserve(e, N, T_in);
         if (rc != MIBC_OK) return rc;

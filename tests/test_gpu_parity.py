@@ -72,11 +72,12 @@ def test_encoder_activations_vs_oracle(layers):
     eng.close()
 
 
-@pytest.mark.parametrize("C,state_len", [(128, 4), (256, 3), (384, 4)])
+@pytest.mark.parametrize("C,state_len", [(128, 4), (256, 3), (384, 4), (512, 5), (1024, 5)])
 def test_scores_vs_oracle_shapes(C, state_len):
+    """All LSTM kernel instantiations: xl (C<=384), xg RT=2 (512), xg RT=1/8 waves (sup, 1024)."""
     cfg = _cfg(C, state_len, 5)
     ws = synth.make_weights(cfg, seed=15)
-    N, T_in = 64, 366
+    N, T_in = (64, 366) if C < 1024 else (32, 246)
     x16 = synth.make_signal(N, T_in, seed=16)
     eng = capi.Engine(cfg, ws)
     scores = eng.forward(x16)
@@ -175,6 +176,23 @@ def test_round_trip_properties_full_chunk_hac():
         assert set(s1) <= set("ACGT")
         assert all(34 <= ord(c) <= 83 for c in q1)
     print("bases/step", np.mean([len(s) for s, _, _ in a]) / T)
+    eng.close()
+
+
+def test_sup_v43_shape_end_to_end():
+    """sup@v4.3-shaped model (C=1024, S=1024 states): decoder bit-exact on the GPU's own scores."""
+    cfg = config.sup_v43()
+    ws = synth.make_weights(cfg, seed=52)
+    N, T_in = 32, 606
+    x16 = synth.make_signal(N, T_in, seed=53)
+    eng = capi.Engine(cfg, ws)
+    assert eng.batch_granularity() == 32
+    got = eng.call(x16)
+    sc = eng.forward(x16)
+    want = O.decode(np.clip(sc.astype(np.float32), -5, 5), det=1)
+    for a, b in zip(got, want):
+        assert a[0] == b[0] and (a[2] == b[2]).all()
+    print("sup bases/step", np.mean([len(s) for s, _, _ in got]) / eng.output_steps(T_in))
     eng.close()
 
 
