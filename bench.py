@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — Samples/s of the simplex-basecalling hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--model hac|tiny]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--model hac|sup|tiny] [--also-sup]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = one pass of the whole hot path (conv -> 5x LSTM -> CRF head -> beam-search decode)
@@ -34,6 +34,26 @@ if ROOT not in sys.path:
 
 MFMA_F16_PEAK = 2.5e15  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
+
+
+def pmc_traffic(kernel_prefix, model, n, t_in):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r*_pmc_traffic_*.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 correction on
+    FETCH_SIZE).  Only reported when the profiled workload matches this run; else null."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_*.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if (w.get("model"), w.get("N"), w.get("T_in")) != (model, n, t_in):
+            continue
+        for k, v in d.get("kernels", {}).items():
+            if kernel_prefix in k:
+                best = {"hbm_bytes": v["hbm_bytes_corrected"], "source": os.path.relpath(path, ROOT)}
+    return best
 
 
 def lstm_flops_per_launch(cfg, n, t):
@@ -106,6 +126,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="chunks per GPU per step (0 = auto)")
     ap.add_argument("--model", default="hac")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--also-sup", type=int, default=1,
+                    help="N=1 only: after the headline (hac) run, time 2 steps of the sup@v4.3 shape and "
+                         "report it under extra.sup_v43 (BASELINE metric names hac & sup)")
     args = ap.parse_args()
 
     import torch
@@ -190,6 +213,7 @@ def main():
         k_ms = float(np.mean(lstm_ms))
         fl = lstm_flops_per_launch(cfg, n, T)
         achieved = fl / (k_ms * 1e-3)
+        tr = pmc_traffic("lstm_layer_x", args.model, n, t_in)
         line = {
             "metric": "Samples/s (whole node), simplex basecalling hot path",
             "value": value,
@@ -213,9 +237,11 @@ def main():
             "stage_ms_last_step": stage,
             "network_tflops": value * network_flops_per_sample(cfg) / 1e12,
             "roofline": {
-                "kernel": "lstm_layer_kernel<%d>" % cfg.lstm_size,
+                "kernel": "lstm_layer_%s_kernel<%d>" % ("xl" if cfg.lstm_size <= 384 else "xg", cfg.lstm_size),
                 "bound": "mfma", "achieved": achieved / 1e12, "peak": MFMA_F16_PEAK / 1e12,
-                "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK,
+                "traffic": (tr or {}).get("hbm_bytes"), "traffic_source": (tr or {}).get("source"),
+                "traffic_algorithmic": 2.0 * n * T * cfg.lstm_size * 2,  # read x_t + write h_t, f16
                 "launch_ms": k_ms, "flops_per_launch": fl,
             },
         }
@@ -224,12 +250,54 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(cfg, ws, t_in)
             except Exception as ex:  # the checker must never take the bench line down
                 line["cpu_baseline"] = {"value": None, "error": repr(ex)}
-        print(json.dumps(line))
     eng.device_free(d_in)
     eng.device_free(d_out)
     eng.close()
+    if rank == 0:
+        if world == 1 and args.also_sup and args.model == "hac":
+            try:
+                line["extra"] = {"sup_v43": side_run(capi, config.sup_v43(), synth, local_rank)}
+            except Exception as ex:
+                line["extra"] = {"sup_v43": {"error": repr(ex)}}
+        print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def side_run(capi, cfg, synth, device, steps=2):
+    """Secondary measurement (not the headline value): same hot path, another model shape."""
+    t_in = cfg.chunk_size
+    eng = capi.Engine(cfg, synth.make_weights(cfg, seed=42), device=device)
+    T = eng.output_steps(t_in)
+    n = 256 * eng.batch_granularity()
+    eng.reserve(n, t_in)
+    base = synth.make_signal(64, t_in, seed=7)
+    x = np.tile(base, (n // 64, 1))
+    d_in, d_out = eng.device_alloc(x.nbytes), eng.device_alloc(3 * n * T)
+    eng.h2d(d_in, x)
+    eng.set_profile(1)
+    eng.call_device(d_in, n, t_in, d_out)
+    eng.sync()
+    t0 = time.perf_counter()
+    lstm = []
+    for _ in range(steps):
+        eng.call_device(d_in, n, t_in, d_out)
+        st = eng.stage_ms()
+        lstm.extend(st["lstm_layer"][: cfg.lstm_layers])
+    eng.sync()
+    el = time.perf_counter() - t0
+    k_ms = float(np.mean(lstm))
+    fl = lstm_flops_per_launch(cfg, n, T)
+    res = {"workload": f"{cfg.name}, chunksize {t_in}, batch {n}", "samples_per_s": n * t_in * steps / el,
+           "ms_per_step": el / steps * 1e3, "stage_ms_last_step": st,
+           "network_tflops": n * t_in * steps / el * network_flops_per_sample(cfg) / 1e12,
+           "roofline": {"kernel": "lstm_layer_xg_kernel<%d>" % cfg.lstm_size, "bound": "mfma",
+                        "achieved": fl / (k_ms * 1e-3) / 1e12, "peak": MFMA_F16_PEAK / 1e12,
+                        "unit": "TFLOP/s", "frac": fl / (k_ms * 1e-3) / MFMA_F16_PEAK, "launch_ms": k_ms}}
+    eng.device_free(d_in)
+    eng.device_free(d_out)
+    eng.close()
+    return res
 
 
 if __name__ == "__main__":
