@@ -213,7 +213,7 @@ def main():
         k_ms = float(np.mean(lstm_ms))
         fl = lstm_flops_per_launch(cfg, n, T)
         achieved = fl / (k_ms * 1e-3)
-        tr = pmc_traffic("lstm_layer_x", args.model, n, t_in)
+        tr = pmc_traffic("lstm_layer_x8", args.model, n, t_in)
         line = {
             "metric": "Samples/s (whole node), simplex basecalling hot path",
             "value": value,
@@ -237,7 +237,7 @@ def main():
             "stage_ms_last_step": stage,
             "network_tflops": value * network_flops_per_sample(cfg) / 1e12,
             "roofline": {
-                "kernel": "lstm_layer_%s_kernel<%d>" % ("xl" if cfg.lstm_size <= 384 else "xg", cfg.lstm_size),
+                "kernel": "lstm_layer_%s_kernel<%d>" % ("x8" if cfg.lstm_size <= 384 else "xg", cfg.lstm_size),
                 "bound": "mfma", "achieved": achieved / 1e12, "peak": MFMA_F16_PEAK / 1e12,
                 "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK,
                 "traffic": (tr or {}).get("hbm_bytes"), "traffic_source": (tr or {}).get("source"),

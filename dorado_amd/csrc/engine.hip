@@ -33,7 +33,8 @@ extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w
                                   const float *w2, const float *b2, half_t *a2p, half_t *a1_tap,
                                   int N, int T_in, int Tpitch, int pad, int act1, int act2);
 extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, half_t *Xout,
-                                      const half_t *Wf, const float *biasn, int T, int N, int reverse);
+                                      const half_t *Wf, const half_t *Wf16, const float *biasn, int T, int N,
+                                      int reverse);
 extern "C" int mibc_lstm_rows_per_wg(int C);
 extern "C" int mibc_launch_decode(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
                                   float beam_cut, float stay, float clampv, float q_shift,
@@ -52,7 +53,8 @@ struct mibc_engine {
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *b3 = nullptr;
     half_t *w3 = nullptr;  // [C][K3pad]
     int K3 = 0, K3pad = 0;
-    std::vector<half_t *> lstm_w;
+    std::vector<half_t *> lstm_w;    // 32-unit tiles, k-steps of 16 (v_mfma 32x32x16)
+    std::vector<half_t *> lstm_w16;  // 16-unit tiles, k-steps of 32 (v_mfma 16x16x32); C <= 384 only
     std::vector<float *> lstm_bn;  // b_ih + b_hh, [C/32][4][32]
     half_t *head_w1 = nullptr, *head_w2 = nullptr;
     float *head_b1 = nullptr;
@@ -217,6 +219,24 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
                                                     : Whh[(size_t)row * C + (k - C)];
                             wf[((((size_t)j * KS + ks) * 4 + g) * 64 + lane) * 8 + i] = (half_t)v;
                         }
+        half_t *dw16 = nullptr;
+        if (C <= 384) {
+            const int KS32 = 2 * C / 32;
+            std::vector<half_t> w16((size_t)4 * C * 2 * C);
+            for (int j = 0; j < C / 16; ++j)
+                for (int ks = 0; ks < KS32; ++ks)
+                    for (int g = 0; g < 4; ++g)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int i = 0; i < 8; ++i) {
+                                const int row = g * C + 16 * j + (lane & 15);
+                                const int k = ks * 32 + 8 * (lane >> 4) + i;
+                                const float v = (k < C) ? Wih[(size_t)row * C + k]
+                                                        : Whh[(size_t)row * C + (k - C)];
+                                w16[((((size_t)j * KS32 + ks) * 4 + g) * 64 + lane) * 8 + i] = (half_t)v;
+                            }
+            if (upload(e, &dw16, w16)) return MIBC_ERR_HIP;
+        }
+        e->lstm_w16.push_back(dw16);
         std::vector<float> bn((size_t)4 * C);
         for (int j = 0; j < C / 32; ++j)
             for (int g = 0; g < 4; ++g)
@@ -285,6 +305,8 @@ extern "C" void mibc_destroy(mibc_engine *e) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto p : e->lstm_w) (void)hipFree(p);
+    for (auto p : e->lstm_w16)
+        if (p) (void)hipFree(p);
     for (auto p : e->lstm_bn) (void)hipFree(p);
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -441,7 +463,8 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     for (int l = 0; l < d.lstm_layers; ++l) {
         // LSTMStack(layers, size, reverse_first = true): nn/LSTMStack.cpp:29-41, CRFModel.cpp:41
         const int reverse = (l % 2 == 0) ? 1 : 0;
-        if (mibc_launch_lstm_layer(e->stream, e->C, cur, nxt, e->lstm_w[l], e->lstm_bn[l], T, N, reverse) != 0)
+        if (mibc_launch_lstm_layer(e->stream, e->C, cur, nxt, e->lstm_w[l], e->lstm_w16[l], e->lstm_bn[l], T, N,
+                                   reverse) != 0)
             return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
         if (prof && l < 8) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_LSTM0 + l], e->stream));
         half_t *t = cur;
