@@ -488,10 +488,19 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
             bnext = bn[(size_t)(t + 2) * S + s];
         }
         const float *a = alpha + p * S;
-        const float v = dm_lse5(mine + stay, a[pred] + clampf((float)m4[0], clampv),
-                                a[pred + Q] + clampf((float)m4[1], clampv),
-                                a[pred + 2 * Q] + clampf((float)m4[2], clampv),
-                                a[pred + 3 * Q] + clampf((float)m4[3], clampv));
+        // The forward scan only feeds the posteriors (-> qstring, +-1 contract), not the called
+        // bases, so it uses the hardware exp/log (v_exp_f32 / v_log_f32) instead of detmath.
+        float v;
+        {
+            const float v0 = mine + stay, v1 = a[pred] + clampf((float)m4[0], clampv),
+                        v2 = a[pred + Q] + clampf((float)m4[1], clampv),
+                        v3 = a[pred + 2 * Q] + clampf((float)m4[2], clampv),
+                        v4 = a[pred + 3 * Q] + clampf((float)m4[3], clampv);
+            const float m = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), v4);
+            const float sum = __expf(v0 - m) + __expf(v1 - m) + __expf(v2 - m) + __expf(v3 - m) +
+                              __expf(v4 - m);
+            v = m + __logf(sum);
+        }
         mine = v;
         alpha[(p ^ 1) * S + s] = v;
         p ^= 1;
@@ -500,7 +509,7 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
         const bool in_set = (s == st) ||
                             ((s & (Q - 1)) == (st >> 2)) ||  // left-shifted:  (st >> 2) + b * Q
                             ((s >> 2) == (st & (Q - 1)));    // right-shifted: ((st << 2) % S) + b
-        const float e = dm_expf((v + bw) - logZ);
+        const float e = __expf((v + bw) - logZ);
         float e_all = e, e_sel = in_set ? e : 0.0f;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -512,16 +521,19 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
             red[(t & 1) * 32 + 16 + wave] = e_sel;
         }
         __syncthreads();  // alpha[p] and red[] visible
-        if (s == 0) {
-            float ta = 0.0f, ts = 0.0f;
-            for (int i = 0; i < nw; ++i) {
-                ta += red[(t & 1) * 32 + i];
-                ts += red[(t & 1) * 32 + 16 + i];
-            }
-            float pr = ts / ta;
-            pr = fminf(fmaxf(pr, 0.0f), 1.0f);
-            prob[t] = powf(pr, 0.4f);
+        // every wave folds the partials itself (broadcast LDS reads): no single thread becomes the
+        // straggler that the next barrier waits for; clamp and the ^0.4 happen after the scan
+        float ta = 0.0f, ts = 0.0f;
+        for (int i = 0; i < nw; ++i) {
+            ta += red[(t & 1) * 32 + i];
+            ts += red[(t & 1) * 32 + 16 + i];
         }
+        if (s == (t & (S - 1))) prob[t] = ts / ta;
+    }
+    __syncthreads();
+    for (int i = s; i < T; i += S) {  // beam_search.cpp:505-506
+        const float pr = fminf(fmaxf(prob[i], 0.0f), 1.0f);
+        prob[i] = powf(pr, 0.4f);
     }
     __syncthreads();
     // ---- sequence / per-base error accumulation (beam_search.cpp:54-102), sequential ----

@@ -29,6 +29,17 @@ struct GemmArgs {
     int act;
 };
 extern "C" int mibc_launch_gemm_tn(hipStream_t s, const GemmArgs *a);
+struct WsArgs {
+    const half_t *A;
+    const half_t *Wf;
+    const float *bias;
+    half_t *out;
+    int cols;
+    int act;
+    int N, Ns, n0, T;
+    int Tpitch, stride;
+};
+extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mode);
 extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w1, const float *b1,
                                   const float *w2, const float *b2, half_t *a2p, half_t *a1_tap,
                                   int N, int T_in, int Tpitch, int pad, int act1, int act2);
@@ -52,6 +63,8 @@ struct mibc_engine {
     // weights (device)
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *b3 = nullptr;
     half_t *w3 = nullptr;  // [C][K3pad]
+    half_t *w3f = nullptr, *head_w1f = nullptr;  // 16x32 MFMA-fragment order (wsgemm.hip)
+    int use_ws = 1;
     int K3 = 0, K3pad = 0;
     std::vector<half_t *> lstm_w;    // 32-unit tiles, k-steps of 16 (v_mfma 32x32x16)
     std::vector<half_t *> lstm_w16;  // 16-unit tiles, k-steps of 32 (v_mfma 16x16x32); C <= 384 only
@@ -108,6 +121,19 @@ extern "C" int mibc_device_count(void) {
 
 extern "C" const char *mibc_last_error(const mibc_engine *e) {
     return e ? e->err.c_str() : g_err.c_str();
+}
+
+// [cols][K] row-major -> [cols/16][K/32][64 lanes][8]: lane holds W[16*ct + (lane & 15)][32*ks + 8*(lane >> 4) ..]
+static std::vector<half_t> to_frag16(const std::vector<half_t> &w, int cols, int K) {
+    std::vector<half_t> f((size_t)cols * K);
+    const int KT = K / 32;
+    for (int ct = 0; ct < cols / 16; ++ct)
+        for (int ks = 0; ks < KT; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i)
+                    f[(((size_t)ct * KT + ks) * 64 + lane) * 8 + i] =
+                            w[(size_t)(16 * ct + (lane & 15)) * K + 32 * ks + 8 * (lane >> 4) + i];
+    return f;
 }
 
 template <typename T>
@@ -201,6 +227,8 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
                     w[(size_t)co * e->K3pad + k * 16 + ci] = (half_t)W[((size_t)co * 16 + ci) * W3 + k];
         std::vector<float> b(B, B + C);
         if (upload(e, &e->w3, w) || upload(e, &e->b3, b)) return MIBC_ERR_HIP;
+        if (e->K3pad % 32 == 0 && C % 64 == 0)
+            if (upload(e, &e->w3f, to_frag16(w, C, e->K3pad))) return MIBC_ERR_HIP;
     }
     // LSTM layers: [W_ih | W_hh] in MFMA-fragment order + summed biases in D-register order
     for (int l = 0; l < d.lstm_layers; ++l) {
@@ -266,14 +294,21 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
         e->head_act1 = -1;
         e->head_act2 = tanh_x5;
     } else if (v4_single) {
-        if (upload(e, &e->head_w1, to_half(weights[wi++], (size_t)e->K * C))) return MIBC_ERR_HIP;
+        const auto hw = to_half(weights[wi++], (size_t)e->K * C);
+        if (upload(e, &e->head_w1, hw)) return MIBC_ERR_HIP;
+        if (C % 32 == 0 && C <= 512)
+            if (upload(e, &e->head_w1f, to_frag16(hw, e->K, C))) return MIBC_ERR_HIP;
         e->head_act1 = tanh_x5;
     } else {
-        if (upload(e, &e->head_w1, to_half(weights[wi++], (size_t)e->K * C))) return MIBC_ERR_HIP;
+        const auto hw = to_half(weights[wi++], (size_t)e->K * C);
+        if (upload(e, &e->head_w1, hw)) return MIBC_ERR_HIP;
+        if (C % 32 == 0 && C <= 512)
+            if (upload(e, &e->head_w1f, to_frag16(hw, e->K, C))) return MIBC_ERR_HIP;
         const float *B = weights[wi++];
         if (upload(e, &e->head_b1, std::vector<float>(B, B + e->K))) return MIBC_ERR_HIP;
         e->head_act1 = 3;
     }
+    if (const char *wsv = getenv("MIBC_WSGEMM")) e->use_ws = atoi(wsv);
     const char *tp = getenv("MIBC_TAPS");
     e->taps = tp ? atoi(tp) : 0;
     *out = e;
@@ -301,7 +336,7 @@ extern "C" void mibc_destroy(mibc_engine *e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     free_ws(e);
-    void *ptrs[] = {e->w1, e->b1, e->w2, e->b2, e->b3, e->w3, e->head_w1, e->head_w2, e->head_b1};
+    void *ptrs[] = {e->w1, e->b1, e->w2, e->b2, e->b3, e->w3, e->head_w1, e->head_w2, e->head_b1, e->w3f, e->head_w1f};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto p : e->lstm_w) (void)hipFree(p);
@@ -442,6 +477,21 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     if (mibc_launch_conv12(e->stream, in_dev, e->w1, e->b1, e->w2, e->b2, e->a2p, e->a1_tap, N, T_in,
                            e->Tpitch, e->pad3, d.conv_act[0], d.conv_act[1]) != 0)
         return fail(e, MIBC_NOT_SUPPORTED, "conv activation combination not supported");
+    bool conv3_done = false;
+    if (e->use_ws && e->w3f) {
+        WsArgs w{};
+        w.A = e->a2p;
+        w.Wf = e->w3f;
+        w.bias = e->b3;
+        w.out = e->xa;
+        w.cols = e->C;
+        w.act = d.conv_act[2];
+        w.N = N;
+        w.T = T;
+        w.Tpitch = e->Tpitch;
+        w.stride = e->stride;
+        conv3_done = (mibc_launch_wsgemm(e->stream, &w, e->K3pad, 1) == 0);
+    }
     GemmArgs g{};
     g.A = e->a2p;
     g.B = e->w3;
@@ -457,7 +507,8 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     g.o_outer = e->C;             // n
     g.o_inner = (long)N * e->C;   // t
     g.act = d.conv_act[2];
-    if (mibc_launch_gemm_tn(e->stream, &g) != 0) return fail(e, MIBC_NOT_SUPPORTED, "conv3 gemm shape");
+    if (!conv3_done && mibc_launch_gemm_tn(e->stream, &g) != 0)
+        return fail(e, MIBC_NOT_SUPPORTED, "conv3 gemm shape");
     if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_CONV], e->stream));
     half_t *cur = e->xa, *nxt = e->xb;
     for (int l = 0; l < d.lstm_layers; ++l) {
@@ -514,6 +565,20 @@ static int run_head(mibc_engine *e, int N, int T, int n0, int ns, half_t *scores
         h.act = e->head_act2;
         if (mibc_launch_gemm_tn(e->stream, &h) != 0) return fail(e, MIBC_NOT_SUPPORTED, "head gemm 2");
     } else {
+        if (e->use_ws && e->head_w1f) {
+            WsArgs w{};
+            w.A = e->lstm_out;
+            w.Wf = e->head_w1f;
+            w.bias = e->head_b1;
+            w.out = scores_out;
+            w.cols = e->K;
+            w.act = e->head_act1;
+            w.N = N;
+            w.Ns = ns;
+            w.n0 = n0;
+            w.T = T;
+            if (mibc_launch_wsgemm(e->stream, &w, e->C, 0) == 0) return MIBC_OK;
+        }
         g.B = e->head_w1;
         g.bias = e->head_b1;
         g.out = scores_out;

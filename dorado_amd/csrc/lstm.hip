@@ -347,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_x8_kernel(
     constexpr int HT = C / 16 / 8;   // 16-unit hidden tiles per wave
     constexpr int KS = 2 * C / 32;   // k-steps of 32 over [x ; h]
     constexpr int KSX = C / 32;
-    constexpr int LD = C + 8;
+    constexpr int LD = C + 16;       // +32 B: conflict-free ds_read_b128 for the 16x32 fragment pattern
     constexpr int XPF = C / 64;      // 16-byte chunks per thread for one x_t block
     constexpr int KTOT = HT * KS;
     constexpr int UN = (PF & 1) ? 2 * PF : PF;  // unroll: ring slot u % PF, fragment parity u & 1
