@@ -64,6 +64,24 @@ class ConvParams:
 
 
 @dataclasses.dataclass
+class TxParams:
+    """config::TxEncoderParams + LinearUpsampleParams + CRFEncoderParams
+    (config/include/config/BasecallModelConfig.h:46-97)."""
+
+    d_model: int = 512
+    nhead: int = 8
+    depth: int = 18
+    dim_feedforward: int = 2048
+    attn_window: tuple = (127, 128)
+    deepnorm_alpha: float = 2.4494897
+    theta: float = 10000.0
+    max_seq_len: int = 2048
+    up_scale_factor: int = 2
+    crf_scale: float = 5.0
+    crf_blank_score: float = 2.0
+
+
+@dataclasses.dataclass
 class ModelConfig:
     """The subset of BasecallModelConfig (config/include/config/BasecallModelConfig.h:99-160)
     the hot path reads."""
@@ -84,13 +102,24 @@ class ModelConfig:
     chunk_size: int = DEFAULT_CHUNK_SIZE
     overlap: int = DEFAULT_OVERLAP
     name: str = "synthetic"
+    tx: Optional[TxParams] = None
 
     @property
-    def stride(self) -> int:
+    def is_tx(self) -> bool:
+        return self.tx is not None
+
+    @property
+    def conv_stride(self) -> int:
         s = 1
         for c in self.convs:
             s *= c.stride
         return s
+
+    @property
+    def stride(self) -> int:
+        """Samples per OUTPUT step (BasecallModelConfig.cpp:447-454: conv strides / upsample)."""
+        s = self.conv_stride
+        return s // self.tx.up_scale_factor if self.tx else s
 
     @property
     def outsize(self) -> int:
@@ -103,13 +132,17 @@ class ModelConfig:
     def normalise_basecaller_params(self) -> None:
         """BatchParams::normalise (BatchParams.cpp:89-105): overlap -> multiple of stride,
         chunk -> multiple of the granularity (= stride for LSTM models)."""
-        stride = self.stride
+        # BasecallModelConfig.h:152-159: stride_inner = stride * scale_factor; granularity x16 for Tx
+        stride = self.stride * (self.tx.up_scale_factor if self.tx else 1)
+        gran = stride * (16 if self.tx else 1)
         self.overlap = (self.overlap // stride) * stride
-        self.chunk_size = (self.chunk_size // stride) * stride
+        self.chunk_size = (self.chunk_size // gran) * gran
         if self.chunk_size <= self.overlap:
             raise ValueError("chunk_size must be greater than overlap")
 
     def n_weights(self) -> int:
+        if self.tx:
+            return 2 * len(self.convs) + 7 * self.tx.depth + 3
         n = 2 * len(self.convs) + 4 * self.lstm_layers + 1
         if self.out_features is not None:
             n += 1 + (1 if self.bias else 0)
@@ -136,6 +169,14 @@ class ModelConfig:
         d.out_features = self.out_features if self.out_features is not None else -1
         d.num_features = self.num_features
         d.tx_d_model = 0
+        if self.tx:
+            t = self.tx
+            d.tx_d_model, d.tx_nhead, d.tx_depth, d.tx_dim_ff = t.d_model, t.nhead, t.depth, t.dim_feedforward
+            d.tx_win_upper, d.tx_win_lower = t.attn_window
+            d.tx_max_seq_len = t.max_seq_len
+            d.tx_deepnorm_alpha, d.tx_theta = t.deepnorm_alpha, t.theta
+            d.up_size, d.up_scale_factor = t.d_model, t.up_scale_factor
+            d.crf_scale, d.crf_blank_score, d.crf_expand_blanks = t.crf_scale, t.crf_blank_score, 1
         return d
 
 
@@ -173,6 +214,42 @@ def sup_v43() -> ModelConfig:
         state_len=5,
         clamp=True,
         name="dna_r10.4.1_e8.2_400bps_sup@v4.3.0(inferred)",
+    )
+    cfg.normalise_basecaller_params()
+    return cfg
+
+
+def sup_v50() -> ModelConfig:
+    """dna_r10.4.1_e8.2_400bps_sup@v5.0.0 (tests/data/model_configs/.../config.toml)."""
+    cfg = ModelConfig(
+        convs=[
+            ConvParams(1, 64, 5, 1, ACT_SWISH),
+            ConvParams(64, 64, 5, 1, ACT_SWISH),
+            ConvParams(64, 128, 9, 3, ACT_SWISH),
+            ConvParams(128, 128, 9, 2, ACT_SWISH),
+            ConvParams(128, 512, 5, 2, ACT_SWISH),
+        ],
+        lstm_size=0, lstm_layers=0, state_len=5, clamp=False, tx=TxParams(),
+        chunk_size=12288, overlap=600, name="dna_r10.4.1_e8.2_400bps_sup@v5.0.0",
+    )
+    cfg.normalise_basecaller_params()
+    return cfg
+
+
+def tiny_tx(d_model: int = 128, nhead: int = 2, depth: int = 2, ff: int = 256, state_len: int = 3,
+            window=(15, 16)) -> ModelConfig:
+    """Small same-topology transformer model for fast parity tests."""
+    cfg = ModelConfig(
+        convs=[
+            ConvParams(1, 64, 5, 1, ACT_SWISH),
+            ConvParams(64, 64, 5, 1, ACT_SWISH),
+            ConvParams(64, 128, 9, 3, ACT_SWISH),
+            ConvParams(128, 128, 9, 2, ACT_SWISH),
+            ConvParams(128, d_model, 5, 2, ACT_SWISH),
+        ],
+        lstm_size=0, lstm_layers=0, state_len=state_len, clamp=False,
+        tx=TxParams(d_model=d_model, nhead=nhead, depth=depth, dim_feedforward=ff, attn_window=window),
+        chunk_size=1536, overlap=192, name=f"tiny-tx-{d_model}-{depth}",
     )
     cfg.normalise_basecaller_params()
     return cfg

@@ -17,6 +17,8 @@ def make_weights(cfg: ModelConfig, seed: int = 42, conv_gain: float = 3.0, ih_ga
     """Returns a list of f32 arrays in module.parameters() order
     (dorado/basecall/crf_utils.cpp:34-88): conv{w,b}*, rnn{w_ih,w_hh,b_ih,b_hh}*, linear*."""
     rng = np.random.default_rng(seed)
+    if cfg.tx is not None:
+        return _make_tx_weights(cfg, rng)
     ws = []
     for c in cfg.convs:
         k = 1.0 / np.sqrt(c.insize * c.winlen)
@@ -61,3 +63,30 @@ def make_signal(n_chunks: int, t_in: int, seed: int = 0xD0AD0, mean_dwell: float
             sig = np.pad(sig, (0, t_in - sig.size), mode="edge")
         out[i] = sig + 0.35 * rng.standard_normal(t_in).astype(np.float32)
     return np.clip(out, -5.0, 5.0).astype(np.float16)
+
+
+def _make_tx_weights(cfg: ModelConfig, rng):
+    """Parameter order of TxModel (dorado/basecall/crf_utils.cpp:100-147): conv{1..5}.{w,b};
+    per layer {wqkv.w, out_proj.w, out_proj.b, fc1.w, fc2.w, norm1.w, norm2.w}; upsample.{w,b}; crf.w.
+    torch-default-shaped init (the SURVEY probe found default init already gives ~0.6 bases/step)."""
+    t = cfg.tx
+    ws = []
+    for c in cfg.convs:
+        k = 1.0 / np.sqrt(c.insize * c.winlen)
+        ws.append((rng.uniform(-k, k, size=(c.size, c.insize, c.winlen)) * 2.0).astype(np.float32))
+        ws.append(rng.uniform(-k, k, size=(c.size,)).astype(np.float32))
+    C, F = t.d_model, t.dim_feedforward
+    k = 1.0 / np.sqrt(C)
+    kf = 1.0 / np.sqrt(F)
+    for _ in range(t.depth):
+        ws.append(rng.uniform(-k, k, size=(3 * C, C)).astype(np.float32) * 2.0)
+        ws.append(rng.uniform(-k, k, size=(C, C)).astype(np.float32))
+        ws.append(rng.uniform(-k, k, size=(C,)).astype(np.float32))
+        ws.append(rng.uniform(-k, k, size=(2 * F, C)).astype(np.float32))
+        ws.append(rng.uniform(-kf, kf, size=(C, F)).astype(np.float32))
+        ws.append((1.0 + 0.1 * rng.standard_normal(C)).astype(np.float32))
+        ws.append((1.0 + 0.1 * rng.standard_normal(C)).astype(np.float32))
+    ws.append(rng.uniform(-k, k, size=(t.up_scale_factor * C, C)).astype(np.float32))
+    ws.append(rng.uniform(-k, k, size=(t.up_scale_factor * C,)).astype(np.float32))
+    ws.append(rng.uniform(-k, k, size=(cfg.outsize, C)).astype(np.float32))
+    return [np.ascontiguousarray(w, np.float32) for w in ws]

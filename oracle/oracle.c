@@ -866,3 +866,180 @@ ORC_API void orc_decode_batch(const float *scores, int N, int T, int K, int beam
                                      seq + (size_t)n * T, qstr + (size_t)n * T, NULL, NULL, det);
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * a5-a6: transformer model (sup@v5): conv stack -> TxEncoder x depth -> LinearUpsample ->
+ * LinearScaledCRF.  Follows basecall/model/TxModel.cpp:20-41 and nn/TxModules.cpp.
+ * ---------------------------------------------------------------------------------------- */
+static inline float siluf_(float x) { return x / (1.0f + expf(-x)); }
+
+/* nn/RMSNorm.cpp:14-18 applied to (in + alpha * x): x <- (in + alpha x) * rsqrt(mean(.^2) + 1e-5) * w
+ * (nn/TxModules.cpp:881: norm(in + (x * deepnorm_alpha))) */
+static void residual_rmsnorm(float *x, const float *in, const float *w, long rows, int C, float alpha) {
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < rows; ++r) {
+        float *xr = x + (size_t)r * C;
+        const float *ir = in + (size_t)r * C;
+        float ss = 0.f;
+        for (int c = 0; c < C; ++c) {
+            xr[c] = ir[c] + xr[c] * alpha;
+            ss += xr[c] * xr[c];
+        }
+        const float rstd = 1.0f / sqrtf(ss / (float)C + 1e-5f);
+        for (int c = 0; c < C; ++c) {
+            xr[c] = (xr[c] * rstd) * w[c];
+        }
+    }
+}
+
+/* nn/TxModules.cpp:184-250 (RotaryEmbedding, "evens/odds" = first/second half of head_dim) +
+ * :279-426 (MultiHeadAttention CPU path: wqkv, rotary, windowed SDPA evaluated in num_splits = 12
+ * query splits whose K/V slice is [qb - win_lower, qe + win_upper) — :398-411 — out_proj). */
+static void tx_attention(const float *x, int N, int T, int C, int H, const float *Wqkv, const float *Wo,
+                         const float *bo, int win_upper, int win_lower, float theta, float *out) {
+    const int D = C / H;
+    const long rows = (long)N * T;
+    float *qkv = (float *)malloc((size_t)rows * 3 * C * sizeof(float));
+    orc_linear(x, rows, C, Wqkv, NULL, 3 * C, 0, 1.0f, qkv);
+    /* rotary tables */
+    float *cs = (float *)malloc((size_t)T * (D / 2) * sizeof(float));
+    float *sn = (float *)malloc((size_t)T * (D / 2) * sizeof(float));
+    for (int i = 0; i < D / 2; ++i) {
+        const float fi = (float)(2 * i);
+        const double p = pow((double)theta, (double)(fi / (float)D));
+        const float inv = 1.0f / (float)p;
+        for (int t = 0; t < T; ++t) {
+            const float f = (float)t * inv;
+            cs[(size_t)t * (D / 2) + i] = cosf(f);
+            sn[(size_t)t * (D / 2) + i] = sinf(f);
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < rows; ++r) {
+        const int t = (int)(r % T);
+        for (int which = 0; which < 2; ++which) {
+            for (int h = 0; h < H; ++h) {
+                float *v = qkv + (size_t)r * 3 * C + (size_t)which * C + (size_t)h * D;
+                for (int i = 0; i < D / 2; ++i) {
+                    const float e = v[i], o = v[D / 2 + i];
+                    const float c = cs[(size_t)t * (D / 2) + i], s = sn[(size_t)t * (D / 2) + i];
+                    v[i] = c * e - s * o;
+                    v[D / 2 + i] = s * e + c * o;
+                }
+            }
+        }
+    }
+    const int num_splits = 12;
+    int es = (T + num_splits - 1) / num_splits;
+    es = (es + 3) / 4 * 4; /* utils::pad_to(div_round_up(T, 12), 4) */
+    const float scale = 1.0f / sqrtf((float)D);
+    float *att = (float *)malloc((size_t)rows * C * sizeof(float));
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n) {
+        for (int i = 0; i < T; ++i) {
+            float w[1024];
+            const int qe = ((i / es + 1) * es < T) ? (i / es + 1) * es : T;
+            const int qb = (i / es) * es;
+            int jlo = i - win_upper, jhi = i + win_lower;           /* band: -win_upper <= j - i <= win_lower */
+            const int kvb = (qb - win_lower > 0) ? qb - win_lower : 0; /* slice [kvb, kve) */
+            const int kve = (qe + win_upper < T) ? qe + win_upper : T;
+            if (jlo < kvb) jlo = kvb;
+            if (jhi > kve - 1) jhi = kve - 1;
+            const int nk = jhi - jlo + 1;
+            for (int h = 0; h < H; ++h) {
+                const float *q = qkv + ((size_t)n * T + i) * 3 * C + (size_t)h * D;
+                float m = -3.0e38f;
+                for (int jj = 0; jj < nk; ++jj) {
+                    const float *k = qkv + ((size_t)n * T + jlo + jj) * 3 * C + C + (size_t)h * D;
+                    float a = 0.f;
+                    for (int d = 0; d < D; ++d) a += q[d] * k[d];
+                    a *= scale;
+                    w[jj] = a;
+                    m = a > m ? a : m;
+                }
+                float sum = 0.f;
+                for (int jj = 0; jj < nk; ++jj) {
+                    w[jj] = expf(w[jj] - m);
+                    sum += w[jj];
+                }
+                float *o = att + ((size_t)n * T + i) * C + (size_t)h * D;
+                for (int d = 0; d < D; ++d) o[d] = 0.f;
+                for (int jj = 0; jj < nk; ++jj) {
+                    const float *v = qkv + ((size_t)n * T + jlo + jj) * 3 * C + 2 * C + (size_t)h * D;
+                    const float p = w[jj] / sum;
+                    for (int d = 0; d < D; ++d) o[d] += p * v[d];
+                }
+            }
+        }
+    }
+    orc_linear(att, rows, C, Wo, bo, C, 0, 1.0f, out);
+    free(qkv); free(cs); free(sn); free(att);
+}
+
+/* weights in module.parameters() order (basecall/crf_utils.cpp:100-147): conv{1..n}.{w,b};
+ * per layer {wqkv.w, out_proj.w, out_proj.b, fc1.w, fc2.w, norm1.w, norm2.w}; upsample.{w,b}; crf.w.
+ * in [N, F, T_in]; scores_out [N, up_scale*T, outsize]; tokens_out (optional) = encoder-stack
+ * output [N, T, d_model].  Returns the number of output steps (up_scale * T). */
+ORC_API int orc_tx_forward(const orc_model_desc *d, const float *const *weights, const float *in_NCT,
+                           int N, int T_in, float *scores_out, float *tokens_out) {
+    int wi = 0;
+    const int F = d->num_features;
+    float *cur = (float *)malloc((size_t)N * T_in * F * sizeof(float));
+    for (int n = 0; n < N; ++n)
+        for (int f = 0; f < F; ++f)
+            for (int t = 0; t < T_in; ++t)
+                cur[((size_t)n * T_in + t) * F + f] = in_NCT[((size_t)n * F + f) * T_in + t];
+    int T = T_in, C = F;
+    for (int i = 0; i < d->n_convs; ++i) {
+        const int To = orc_conv1d(cur, N, T, C, NULL, NULL, d->conv_size[i], d->conv_winlen[i],
+                                  d->conv_stride[i], d->conv_act[i], NULL);
+        float *nxt = (float *)malloc((size_t)N * To * d->conv_size[i] * sizeof(float));
+        orc_conv1d(cur, N, T, C, weights[wi], weights[wi + 1], d->conv_size[i], d->conv_winlen[i],
+                   d->conv_stride[i], d->conv_act[i], nxt);
+        wi += 2;
+        free(cur);
+        cur = nxt;
+        T = To;
+        C = d->conv_size[i];
+    }
+    if (T > 1024 || C != d->tx_d_model) {
+        free(cur);
+        return -1;
+    }
+    const long rows = (long)N * T;
+    const int FF = d->tx_dim_ff;
+    float *attn = (float *)malloc((size_t)rows * C * sizeof(float));
+    float *t1 = (float *)malloc((size_t)rows * 2 * FF * sizeof(float));
+    float *t2 = (float *)malloc((size_t)rows * FF * sizeof(float));
+    for (int l = 0; l < d->tx_depth; ++l) {
+        const float *Wqkv = weights[wi++], *Wo = weights[wi++], *bo = weights[wi++];
+        const float *Wfc1 = weights[wi++], *Wfc2 = weights[wi++];
+        const float *n1 = weights[wi++], *n2 = weights[wi++];
+        tx_attention(cur, N, T, C, d->tx_nhead, Wqkv, Wo, bo, d->tx_win_upper, d->tx_win_lower,
+                     d->tx_theta, attn);
+        residual_rmsnorm(cur, attn, n1, rows, C, d->tx_deepnorm_alpha);
+        /* GatedMLP (nn/TxModules.cpp:140-182): y = first half, gate = second half */
+        orc_linear(cur, rows, C, Wfc1, NULL, 2 * FF, 0, 1.0f, t1);
+#pragma omp parallel for schedule(static)
+        for (long r = 0; r < rows; ++r)
+            for (int j = 0; j < FF; ++j)
+                t2[(size_t)r * FF + j] = siluf_(t1[(size_t)r * 2 * FF + FF + j]) * t1[(size_t)r * 2 * FF + j];
+        orc_linear(t2, rows, FF, Wfc2, NULL, C, 0, 1.0f, attn);
+        residual_rmsnorm(cur, attn, n2, rows, C, d->tx_deepnorm_alpha);
+    }
+    if (tokens_out) memcpy(tokens_out, cur, (size_t)rows * C * sizeof(float));
+    free(attn); free(t1); free(t2);
+    /* LinearUpsample (nn/LinearUpsample.cpp:17-23): linear C -> sf*C (+bias), reshape [N, sf*T, C] */
+    const int sf = d->up_scale_factor;
+    float *up = (float *)malloc((size_t)rows * sf * C * sizeof(float));
+    orc_linear(cur, rows, C, weights[wi], weights[wi + 1], sf * C, 0, 1.0f, up);
+    wi += 2;
+    free(cur);
+    /* LinearScaledCRF (nn/TxModules.cpp:1010-1016): weight *= scale once, then linear, no bias */
+    const int K = d->outsize;
+    float *ws = (float *)malloc((size_t)K * C * sizeof(float));
+    for (size_t i = 0; i < (size_t)K * C; ++i) ws[i] = weights[wi][i] * d->crf_scale;
+    orc_linear(up, rows * sf, C, ws, NULL, K, 0, 1.0f, scores_out);
+    free(ws); free(up);
+    return T * sf;
+}

@@ -136,6 +136,38 @@ def lstm_crf_forward(cfg, weights, x_f32_NCT, use_ref=False, want_layer=False):
     return s
 
 
+def tx_forward(cfg, weights, x_f32_NCT, use_ref=False, want_tokens=False):
+    """Transformer model: x [N, F, T_in] f32 -> scores [N, T_out, K] f32 (+ encoder tokens)."""
+    x = np.ascontiguousarray(x_f32_NCT, np.float32)
+    N, F, T_in = x.shape
+    T_tok = T_in // cfg.conv_stride + 2
+    T_out = T_tok * cfg.tx.up_scale_factor
+    K = cfg.outsize
+    d = cfg.to_desc()
+    ws, arr = _wptrs(weights)
+    scores = np.zeros((N, T_out, K), np.float32)
+    if use_ref:
+        r = ref()
+        T = r.ref_forward(C.byref(d), arr, len(ws), _fp(x), N, T_in, _fp(scores), C.c_int64(scores.size))
+        if T < 0:
+            raise RuntimeError(r.ref_last_error().decode())
+        return scores.reshape(-1)[: N * T * K].reshape(N, T, K).copy()
+    lib().orc_tx_forward.restype = C.c_int
+    tok = np.zeros((N, T_tok, cfg.tx.d_model), np.float32) if want_tokens else None
+    T = lib().orc_tx_forward(C.byref(d), arr, _fp(x), N, T_in, _fp(scores), _fp(tok) if want_tokens else None)
+    if T < 0:
+        raise RuntimeError("orc_tx_forward failed")
+    s = scores.reshape(-1)[: N * T * K].reshape(N, T, K).copy()
+    if want_tokens:
+        Tt = T // cfg.tx.up_scale_factor
+        return s, tok.reshape(-1)[: N * Tt * cfg.tx.d_model].reshape(N, Tt, -1).copy()
+    return s
+
+
+def forward(cfg, weights, x_f32_NCT, use_ref=False):
+    return (tx_forward if cfg.tx is not None else lstm_crf_forward)(cfg, weights, x_f32_NCT, use_ref=use_ref)
+
+
 # ---------------------------------------------------------------- decoder
 def scans(scores_NTK, blank=2.0, use_ref=False, det=0):
     s = np.ascontiguousarray(scores_NTK, np.float32)

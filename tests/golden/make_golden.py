@@ -44,7 +44,7 @@ def network_case(name, cfg, N, T_in, seed):
     ws = synth.make_weights(cfg, seed=seed)
     x16 = synth.make_signal(N, T_in, seed=seed + 1)
     x = x16.astype(np.float32)[:, None, :]
-    scores = O.lstm_crf_forward(cfg, ws, x, use_ref=True)
+    scores = O.forward(cfg, ws, x, use_ref=True)
     fwd, bwd, posts = O.scans(scores, use_ref=True)
     dec = O.decode(scores, q_shift=cfg.qbias, q_scale=cfg.qscale, use_ref=True)
     seq, qs, mv, ln = planes(dec, scores.shape[1])
@@ -94,6 +94,7 @@ if __name__ == "__main__":
     chunk_cases()
     network_case("net_tiny64_s3", config.tiny(64, 3), N=3, T_in=1200, seed=11)
     network_case("net_tiny128_s4", config.tiny(128, 4), N=2, T_in=900, seed=12)
+    network_case("net_tx_tiny", config.tiny_tx(), N=2, T_in=1536, seed=13)
     decoder_case("dec_s3", 3, N=4, T=300, seed=21)
     decoder_case("dec_s4", 4, N=3, T=250, seed=22)
     decoder_case("dec_s5", 5, N=2, T=120, seed=23)

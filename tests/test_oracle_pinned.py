@@ -90,13 +90,14 @@ def _wcrc(ws):
 
 
 @pytest.mark.parametrize("name,cfg", [("net_tiny64_s3", config.tiny(64, 3)),
-                                      ("net_tiny128_s4", config.tiny(128, 4))])
+                                      ("net_tiny128_s4", config.tiny(128, 4)),
+                                      ("net_tx_tiny", config.tiny_tx())])
 def test_network_matches_reference_fixture(golden_dir, name, cfg):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     ws = synth.make_weights(cfg, seed=int(g["seed"]))
     assert _wcrc(ws) == int(g["weights_crc"]), "synthetic weight generator drifted; regenerate goldens"
     x = g["signal_f16"].astype(np.float32)[:, None, :]
-    s = O.lstm_crf_forward(cfg, ws, x)
+    s = O.forward(cfg, ws, x)
     assert s.shape == g["scores"].shape
     # f32 restatement vs f32 libtorch: only summation order differs
     assert np.abs(s - g["scores"]).max() < 2e-4
@@ -104,7 +105,7 @@ def test_network_matches_reference_fixture(golden_dir, name, cfg):
 
 # ---------------------------------------------------------------- a7-a10: decoder
 @pytest.mark.parametrize("det", [0, 1])
-@pytest.mark.parametrize("name", ["net_tiny64_s3", "net_tiny128_s4"])
+@pytest.mark.parametrize("name", ["net_tiny64_s3", "net_tiny128_s4", "net_tx_tiny"])
 def test_decode_of_reference_scores_matches_fixture(golden_dir, name, det):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     s = g["scores"]
