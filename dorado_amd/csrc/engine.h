@@ -1,0 +1,157 @@
+// dorado_amd/csrc/engine.h — internal declarations shared by engine.hip (C-ABI, LSTM-CRF path)
+// and engine_tx.hip (transformer path).  Not part of the public ABI (that is include/mibc.h).
+#pragma once
+#include "../../include/mibc.h"
+#include "common.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+struct GemmArgs {
+    const half_t *A;
+    const half_t *B;
+    const float *bias;
+    half_t *out;
+    int M, Ncols, K;
+    int a_div;
+    long a_outer, a_inner;
+    int o_div;
+    long o_outer, o_inner;
+    int act;
+    int ncols_valid;
+    int epi_mode;
+    const float *rope;
+    int rope_T, rope_cols;
+};
+extern "C" int mibc_launch_gemm_tn(hipStream_t s, const GemmArgs *a);
+struct WsArgs {
+    const half_t *A;
+    const half_t *Wf;
+    const float *bias;
+    half_t *out;
+    int cols;
+    int act;
+    int N, Ns, n0, T;
+    int Tpitch, stride;
+};
+extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mode);
+extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w1, const float *b1,
+                                  const float *w2, const float *b2, half_t *a2p, half_t *a1_tap,
+                                  int N, int T_in, int Tpitch, int pad, int act1, int act2);
+extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, half_t *Xout,
+                                      const half_t *Wf, const half_t *Wf16, const float *biasn, int T, int N,
+                                      int reverse);
+extern "C" int mibc_lstm_rows_per_wg(int C);
+extern "C" int mibc_launch_decode(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
+                                  float beam_cut, float stay, float clampv, float q_shift,
+                                  float q_scale, float *bwd, uint32_t *trace,
+                                  uint16_t *path_state, int8_t *out3, size_t plane_stride,
+                                  float *prob_tap);
+
+std::string &mibc_gerr();
+#define g_err (mibc_gerr())
+
+struct mibc_engine {
+    int device = 0;
+    mibc_model_desc d{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    // weights (device)
+    float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *b3 = nullptr;
+    half_t *w3 = nullptr;  // [C][K3pad]
+    half_t *w3f = nullptr, *head_w1f = nullptr;  // 16x32 MFMA-fragment order (wsgemm.hip)
+    int use_ws = 1;
+    int K3 = 0, K3pad = 0;
+    std::vector<half_t *> lstm_w;    // 32-unit tiles, k-steps of 16 (v_mfma 32x32x16)
+    std::vector<half_t *> lstm_w16;  // 16-unit tiles, k-steps of 32 (v_mfma 16x16x32); C <= 384 only
+    std::vector<float *> lstm_bn;  // b_ih + b_hh, [C/32][4][32]
+    half_t *head_w1 = nullptr, *head_w2 = nullptr;
+    float *head_b1 = nullptr;
+    int head_act1 = -1, head_act2 = -1;
+    // geometry
+    int C = 0, S = 0, K = 0, stride = 1, pad3 = 0;
+    // workspace
+    int N_res = 0, T_in_res = 0, T_res = 0, Tpitch = 0, Nd = 0;
+    half_t *in_stage = nullptr, *a2p = nullptr, *xa = nullptr, *xb = nullptr, *scores = nullptr,
+           *mid = nullptr, *a1_tap = nullptr;
+    float *bwd = nullptr, *prob_tap = nullptr;
+    uint32_t *trace = nullptr;
+    uint16_t *path_state = nullptr;
+    int8_t *out3 = nullptr;
+    size_t ws_bytes = 0;
+    // last call
+    half_t *lstm_out = nullptr;
+    int last_N = 0, last_T = 0, last_T_in = 0;
+    int profile = 0, taps = 0;
+    enum { EV_START, EV_CONV, EV_LSTM0, EV_HEAD_BASE = EV_LSTM0 + 8, EV_END = EV_HEAD_BASE + 1, EV_N };
+    hipEvent_t ev[16] = {};
+    float head_ms = 0, dec_ms = 0;
+    std::vector<hipEvent_t> sub_ev;  // per decode sub-batch: head start, head end, decode end
+    bool timed = false;
+    // ---- transformer model (engine_tx.hip) ----
+    bool is_tx = false;
+    struct TxConv {
+        int cin, cout, cout_pad, w, stride, pad, act;
+        half_t *wB = nullptr;   // [cout_pad][w*cin] f16 (im2col order k = tap*cin + ci)
+        float *bias = nullptr;  // [cout_pad]
+    };
+    struct TxLayer {
+        half_t *wqkv = nullptr, *wo = nullptr, *wfc1 = nullptr, *wfc2 = nullptr;
+        float *bo = nullptr, *n1 = nullptr, *n2 = nullptr;
+    };
+    struct Tx {
+        float *c1w = nullptr, *c1b = nullptr;  // conv1 [5][C1], [C1]
+        std::vector<TxConv> convs;             // conv2..n as implicit-im2col GEMMs
+        std::vector<TxLayer> layers;
+        half_t *wup = nullptr, *wcrf = nullptr;
+        float *bup = nullptr, *rope = nullptr;
+        int D = 0, H = 0, FF = 0, depth = 0, sf = 1, conv_stride = 1;
+        // workspace
+        std::vector<half_t *> cbuf;   // padded conv outputs (NTC)
+        std::vector<int> ctp, ct;     // row pitch and valid steps per conv buffer
+        half_t *x = nullptr, *qkv = nullptr, *attn = nullptr, *tmp = nullptr, *ff = nullptr, *up = nullptr;
+        int T_tok = 0;
+        hipEvent_t ev_conv = nullptr, ev_layers = nullptr;
+    } tx;
+};
+
+#define HIP_OK(e_, call)                                                                  \
+    do {                                                                                  \
+        hipError_t rc_ = (call);                                                          \
+        if (rc_ != hipSuccess) {                                                          \
+            std::string m_ = std::string(#call) + ": " + hipGetErrorString(rc_);          \
+            if (e_) (e_)->err = m_;                                                       \
+            g_err = m_;                                                                   \
+            return MIBC_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+inline int fail(mibc_engine *e, int code, const std::string &m) {
+    if (e) e->err = m;
+    g_err = m;
+    return code;
+}
+
+
+// engine_tx.hip
+int tx_create(mibc_engine *e, const mibc_model_desc &d, const float *const *weights, int n_weights);
+void tx_destroy(mibc_engine *e);
+void tx_free_ws(mibc_engine *e);
+int tx_tokens(const mibc_engine *e, int T_in);
+int tx_reserve(mibc_engine *e, int N, int T_in, size_t *total);
+size_t tx_bytes_per_chunk(const mibc_engine *e, int T_in);
+int tx_run_network(mibc_engine *e, const half_t *in_dev, int N, int T_in);
+int tx_run_head(mibc_engine *e, int N, int n0, int ns, half_t *scores_out);
+
+template <typename T>
+inline int mibc_upload(mibc_engine *e, T **dst, const std::vector<T> &src) {
+    HIP_OK(e, hipMalloc((void **)dst, src.size() * sizeof(T)));
+    HIP_OK(e, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+

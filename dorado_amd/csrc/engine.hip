@@ -5,110 +5,11 @@
 // (dorado/basecall/CudaCaller.cpp:149-200 ctor, :224-271 call_chunks, :323-369 memory model,
 // :552-569 forward timing) minus its libtorch/Koi dependencies.  The thread/queue half
 // (per-device FIFO, runners, pinned batch buffers) lives in dorado_amd/host/.
-#include "../../include/mibc.h"
-#include "common.h"
+#include "engine.h"
 
-#include <math.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include <string>
-#include <vector>
-
-struct GemmArgs {
-    const half_t *A;
-    const half_t *B;
-    const float *bias;
-    half_t *out;
-    int M, Ncols, K;
-    int a_div;
-    long a_outer, a_inner;
-    int o_div;
-    long o_outer, o_inner;
-    int act;
-};
-extern "C" int mibc_launch_gemm_tn(hipStream_t s, const GemmArgs *a);
-struct WsArgs {
-    const half_t *A;
-    const half_t *Wf;
-    const float *bias;
-    half_t *out;
-    int cols;
-    int act;
-    int N, Ns, n0, T;
-    int Tpitch, stride;
-};
-extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mode);
-extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w1, const float *b1,
-                                  const float *w2, const float *b2, half_t *a2p, half_t *a1_tap,
-                                  int N, int T_in, int Tpitch, int pad, int act1, int act2);
-extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, half_t *Xout,
-                                      const half_t *Wf, const half_t *Wf16, const float *biasn, int T, int N,
-                                      int reverse);
-extern "C" int mibc_lstm_rows_per_wg(int C);
-extern "C" int mibc_launch_decode(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
-                                  float beam_cut, float stay, float clampv, float q_shift,
-                                  float q_scale, float *bwd, uint32_t *trace,
-                                  uint16_t *path_state, int8_t *out3, size_t plane_stride,
-                                  float *prob_tap);
-
-static thread_local std::string g_err;
-
-struct mibc_engine {
-    int device = 0;
-    mibc_model_desc d{};
-    hipStream_t stream = nullptr;
-    std::string err;
-    // weights (device)
-    float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *b3 = nullptr;
-    half_t *w3 = nullptr;  // [C][K3pad]
-    half_t *w3f = nullptr, *head_w1f = nullptr;  // 16x32 MFMA-fragment order (wsgemm.hip)
-    int use_ws = 1;
-    int K3 = 0, K3pad = 0;
-    std::vector<half_t *> lstm_w;    // 32-unit tiles, k-steps of 16 (v_mfma 32x32x16)
-    std::vector<half_t *> lstm_w16;  // 16-unit tiles, k-steps of 32 (v_mfma 16x16x32); C <= 384 only
-    std::vector<float *> lstm_bn;  // b_ih + b_hh, [C/32][4][32]
-    half_t *head_w1 = nullptr, *head_w2 = nullptr;
-    float *head_b1 = nullptr;
-    int head_act1 = -1, head_act2 = -1;
-    // geometry
-    int C = 0, S = 0, K = 0, stride = 1, pad3 = 0;
-    // workspace
-    int N_res = 0, T_in_res = 0, T_res = 0, Tpitch = 0, Nd = 0;
-    half_t *in_stage = nullptr, *a2p = nullptr, *xa = nullptr, *xb = nullptr, *scores = nullptr,
-           *mid = nullptr, *a1_tap = nullptr;
-    float *bwd = nullptr, *prob_tap = nullptr;
-    uint32_t *trace = nullptr;
-    uint16_t *path_state = nullptr;
-    int8_t *out3 = nullptr;
-    size_t ws_bytes = 0;
-    // last call
-    half_t *lstm_out = nullptr;
-    int last_N = 0, last_T = 0, last_T_in = 0;
-    int profile = 0, taps = 0;
-    enum { EV_START, EV_CONV, EV_LSTM0, EV_HEAD_BASE = EV_LSTM0 + 8, EV_END = EV_HEAD_BASE + 1, EV_N };
-    hipEvent_t ev[16] = {};
-    float head_ms = 0, dec_ms = 0;
-    std::vector<hipEvent_t> sub_ev;  // per decode sub-batch: head start, head end, decode end
-    bool timed = false;
-};
-
-#define HIP_OK(e_, call)                                                                  \
-    do {                                                                                  \
-        hipError_t rc_ = (call);                                                          \
-        if (rc_ != hipSuccess) {                                                          \
-            std::string m_ = std::string(#call) + ": " + hipGetErrorString(rc_);          \
-            if (e_) (e_)->err = m_;                                                       \
-            g_err = m_;                                                                   \
-            return MIBC_ERR_HIP;                                                          \
-        }                                                                                 \
-    } while (0)
-
-static int fail(mibc_engine *e, int code, const std::string &m) {
-    if (e) e->err = m;
-    g_err = m;
-    return code;
+std::string &mibc_gerr() {
+    static thread_local std::string g;
+    return g;
 }
 
 extern "C" int mibc_device_count(void) {
@@ -150,7 +51,28 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
     }
     const mibc_model_desc &d = *desc;
     if (d.tx_d_model > 0) {
-        return fail(nullptr, MIBC_NOT_SUPPORTED, "transformer models are not supported yet");
+        const int S_ = 1 << (2 * d.state_len);
+        if (S_ != 64 && S_ != 256 && S_ != 1024) return fail(nullptr, MIBC_NOT_SUPPORTED, "state_len must be 3, 4 or 5");
+        if (d.outsize != 4 * S_) return fail(nullptr, MIBC_ERR_ARG, "outsize must be 4^(state_len+1)");
+        if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, MIBC_ERR_HIP, "hipSetDevice failed");
+        mibc_engine *e = new mibc_engine();
+        e->device = device_id;
+        e->d = d;
+        e->C = d.tx_d_model;
+        e->S = S_;
+        e->K = 4 * S_;
+        HIP_OK(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        for (auto &ev : e->ev) HIP_OK(e, hipEventCreate(&ev));
+        const int rc = tx_create(e, d, weights, n_weights);
+        if (rc != MIBC_OK) {
+            g_err = e->err;
+            mibc_destroy(e);
+            return rc;
+        }
+        const char *tp = getenv("MIBC_TAPS");
+        e->taps = tp ? atoi(tp) : 0;
+        *out = e;
+        return MIBC_OK;
     }
     if (d.n_convs != 3 || d.num_features != 1 || d.conv_insize[0] != 1 || d.conv_size[0] != 16 ||
         d.conv_size[1] != 16 || d.conv_winlen[0] != 5 || d.conv_winlen[1] != 5 ||
@@ -316,6 +238,7 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
 }
 
 static void free_ws(mibc_engine *e) {
+    if (e->is_tx) tx_free_ws(e);
     void *ptrs[] = {e->in_stage, e->a2p, e->xa, e->xb, e->scores, e->mid, e->a1_tap, e->bwd,
                     e->prob_tap, e->trace, e->path_state, e->out3};
     for (void *p : ptrs)
@@ -336,6 +259,7 @@ extern "C" void mibc_destroy(mibc_engine *e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     free_ws(e);
+    if (e->is_tx) tx_destroy(e);
     void *ptrs[] = {e->w1, e->b1, e->w2, e->b2, e->b3, e->w3, e->head_w1, e->head_w2, e->head_b1, e->w3f, e->head_w1f};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -350,15 +274,19 @@ extern "C" void mibc_destroy(mibc_engine *e) {
 }
 
 extern "C" int mibc_output_steps(const mibc_engine *e, int T_in) {
+    if (e->is_tx) return tx_tokens(e, T_in) * e->tx.sf;
     const int W3 = e->d.conv_winlen[2];
     return (T_in + 2 * e->pad3 - W3) / e->stride + 1;
 }
 
-extern "C" int mibc_batch_granularity(const mibc_engine *e) { return mibc_lstm_rows_per_wg(e->C); }
+extern "C" int mibc_batch_granularity(const mibc_engine *e) {
+    return e->is_tx ? 1 : mibc_lstm_rows_per_wg(e->C);
+}
 
 static int decode_sub(const mibc_engine *e, int N) {
     const char *s = getenv("MIBC_DECODE_SUB");
     int nd = s ? atoi(s) : (e->K > 1024 ? 2048 : 4096);  // keeps scores+guides per sub-batch <= ~45 GB
+    if (e->is_tx && !s) nd = 1024;                        // 16 MB of scores per chunk (T = 2048, K = 4096)
     if (nd < 64) nd = 64;
     nd = (nd / 64) * 64;
     return N < nd ? N : nd;
@@ -369,6 +297,12 @@ extern "C" int mibc_query_memory(const mibc_engine *e, int T_in, size_t *bytes_p
                                  size_t *bytes_fixed) {
     if (!e || T_in <= 0) return MIBC_ERR_ARG;
     const size_t T = (size_t)mibc_output_steps(e, T_in);
+    if (e->is_tx) {
+        const size_t per_dec = T * e->K * 2 + (T + 1) * e->S * 4 + (T + 1) * 32 * 4 + T * 2 + T * 4;
+        if (bytes_per_chunk) *bytes_per_chunk = tx_bytes_per_chunk(e, T_in);
+        if (bytes_fixed) *bytes_fixed = per_dec * 1024;
+        return MIBC_OK;
+    }
     const size_t Tpitch = (size_t)T_in + 2 * e->pad3 + 2;
     size_t per = 0;
     per += (size_t)T_in * 2;                 // staged input
@@ -384,7 +318,7 @@ extern "C" int mibc_query_memory(const mibc_engine *e, int T_in, size_t *bytes_p
 
 extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
     if (!e || N_max <= 0 || T_in <= 0) return MIBC_ERR_ARG;
-    if (N_max % mibc_lstm_rows_per_wg(e->C) != 0)
+    if (N_max % mibc_batch_granularity(e) != 0)
         return fail(e, MIBC_ERR_ARG, "N_max must be a multiple of mibc_batch_granularity()");
     HIP_OK(e, hipSetDevice(e->device));
     if (e->N_res >= N_max && e->T_in_res == T_in) return MIBC_OK;
@@ -403,10 +337,17 @@ extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
         return 0;
     };
     if (alloc((void **)&e->in_stage, N * T_in * 2)) return MIBC_ERR_MEM;
-    if (alloc((void **)&e->a2p, (N * e->Tpitch + 64) * 16 * 2)) return MIBC_ERR_MEM;
-    HIP_OK(e, hipMemset(e->a2p, 0, (N * e->Tpitch + 64) * 16 * 2));
-    if (alloc((void **)&e->xa, T * N * e->C * 2)) return MIBC_ERR_MEM;
-    if (alloc((void **)&e->xb, T * N * e->C * 2)) return MIBC_ERR_MEM;
+    if (e->is_tx) {
+        size_t txb = 0;
+        const int rc = tx_reserve(e, N_max, T_in, &txb);
+        if (rc != MIBC_OK) return rc;
+        total += txb;
+    } else {
+        if (alloc((void **)&e->a2p, (N * e->Tpitch + 64) * 16 * 2)) return MIBC_ERR_MEM;
+        HIP_OK(e, hipMemset(e->a2p, 0, (N * e->Tpitch + 64) * 16 * 2));
+        if (alloc((void **)&e->xa, T * N * e->C * 2)) return MIBC_ERR_MEM;
+        if (alloc((void **)&e->xb, T * N * e->C * 2)) return MIBC_ERR_MEM;
+    }
     if (alloc((void **)&e->scores, Nd * T * e->K * 2)) return MIBC_ERR_MEM;
     if (e->d.out_features > 0)
         if (alloc((void **)&e->mid, Nd * T * e->d.out_features * 2)) return MIBC_ERR_MEM;
@@ -593,7 +534,7 @@ static int run_head(mibc_engine *e, int N, int T, int n0, int ns, half_t *scores
 
 static int check_call(mibc_engine *e, int N, int T_in) {
     if (!e) return MIBC_ERR_ARG;
-    if (N <= 0 || N % mibc_lstm_rows_per_wg(e->C) != 0)
+    if (N <= 0 || N % mibc_batch_granularity(e) != 0)
         return fail(e, MIBC_ERR_ARG, "N must be a positive multiple of mibc_batch_granularity()");
     if (e->N_res < N || e->T_in_res != T_in) {
         const int rc = mibc_reserve(e, N, T_in);
@@ -608,12 +549,14 @@ extern "C" int mibc_forward(mibc_engine *e, const uint16_t *in_dev, int N, int T
     int rc = check_call(e, N, T_in);
     if (rc != MIBC_OK) return rc;
     const int T = mibc_output_steps(e, T_in);
-    rc = run_encoder(e, (const half_t *)in_dev, N, T_in);
+    rc = e->is_tx ? tx_run_network(e, (const half_t *)in_dev, N, T_in)
+                  : run_encoder(e, (const half_t *)in_dev, N, T_in);
     if (rc != MIBC_OK) return rc;
     // the two-stage head uses the sub-batch sized `mid` buffer
     for (int n0 = 0; n0 < N; n0 += e->Nd) {
         const int ns = (N - n0 < e->Nd) ? (N - n0) : e->Nd;
-        rc = run_head(e, N, T, n0, ns, (half_t *)scores_dev + (size_t)n0 * T * e->K);
+        half_t *so = (half_t *)scores_dev + (size_t)n0 * T * e->K;
+        rc = e->is_tx ? tx_run_head(e, N, n0, ns, so) : run_head(e, N, T, n0, ns, so);
         if (rc != MIBC_OK) return rc;
     }
     if (e->profile > 0) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_END], e->stream));
@@ -654,13 +597,14 @@ extern "C" int mibc_call_device(mibc_engine *e, const uint16_t *in_dev, int N, i
     if (rc != MIBC_OK) return rc;
     const int T = mibc_output_steps(e, T_in);
     const bool prof = e->profile > 0;
-    rc = run_encoder(e, (const half_t *)in_dev, N, T_in);
+    rc = e->is_tx ? tx_run_network(e, (const half_t *)in_dev, N, T_in)
+                  : run_encoder(e, (const half_t *)in_dev, N, T_in);
     if (rc != MIBC_OK) return rc;
     int si = 0;
     for (int n0 = 0; n0 < N; n0 += e->Nd, ++si) {
         const int ns = (N - n0 < e->Nd) ? (N - n0) : e->Nd;
         if (prof) HIP_OK(e, hipEventRecord(e->sub_ev[si * 3 + 0], e->stream));
-        rc = run_head(e, N, T, n0, ns, e->scores);
+        rc = e->is_tx ? tx_run_head(e, N, n0, ns, e->scores) : run_head(e, N, T, n0, ns, e->scores);
         if (rc != MIBC_OK) return rc;
         if (prof) HIP_OK(e, hipEventRecord(e->sub_ev[si * 3 + 1], e->stream));
         if (mibc_launch_decode(e->stream, e->scores, ns, T, e->S, o->beam_width, o->beam_cut,
@@ -703,7 +647,11 @@ extern "C" int mibc_get_stage_ms(mibc_engine *e, mibc_stage_ms *out) {
     HIP_OK(e, hipEventElapsedTime(&ms, e->ev[mibc_engine::EV_START], e->ev[mibc_engine::EV_CONV]));
     out->conv = ms;
     hipEvent_t prev = e->ev[mibc_engine::EV_CONV];
-    for (int l = 0; l < e->d.lstm_layers && l < 8; ++l) {
+    if (e->is_tx) {  // the whole encoder stack + upsample is reported in the "lstm" slot
+        HIP_OK(e, hipEventElapsedTime(&ms, prev, e->ev[mibc_engine::EV_LSTM0]));
+        out->lstm = out->lstm_layer[0] = ms;
+    }
+    for (int l = 0; !e->is_tx && l < e->d.lstm_layers && l < 8; ++l) {
         HIP_OK(e, hipEventElapsedTime(&ms, prev, e->ev[mibc_engine::EV_LSTM0 + l]));
         out->lstm_layer[l] = ms;
         out->lstm += ms;
@@ -735,10 +683,12 @@ extern "C" int mibc_time_forward(mibc_engine *e, int N, int T_in, float *ms_out)
     e->profile = 0;
     for (int it = 0; it < 3; ++it) {
         HIP_OK(e, hipEventRecord(a, e->stream));
-        rc = run_encoder(e, e->in_stage, N, T_in);
+        rc = e->is_tx ? tx_run_network(e, e->in_stage, N, T_in) : run_encoder(e, e->in_stage, N, T_in);
         if (rc == MIBC_OK)
-            for (int n0 = 0; n0 < N && rc == MIBC_OK; n0 += e->Nd)
-                rc = run_head(e, N, T, n0, (N - n0 < e->Nd) ? (N - n0) : e->Nd, e->scores);
+            for (int n0 = 0; n0 < N && rc == MIBC_OK; n0 += e->Nd) {
+                const int ns = (N - n0 < e->Nd) ? (N - n0) : e->Nd;
+                rc = e->is_tx ? tx_run_head(e, N, n0, ns, e->scores) : run_head(e, N, T, n0, ns, e->scores);
+            }
         HIP_OK(e, hipEventRecord(b, e->stream));
         HIP_OK(e, hipEventSynchronize(b));
         float ms = 0;
@@ -765,7 +715,10 @@ extern "C" int mibc_debug_tap(mibc_engine *e, int tap, void *host_dst, size_t by
         case 0: src = e->a1_tap; have = N * Tin * 16 * 2; break;
         case 1: src = e->a2p; have = N * e->Tpitch * 16 * 2; break;
         case 2: src = e->xa; have = T * N * e->C * 2; break;
-        case 3: src = e->lstm_out; have = T * N * e->C * 2; break;
+        case 3:
+            src = e->lstm_out;
+            have = e->is_tx ? (size_t)N * e->tx.T_tok * e->C * 2 : T * N * e->C * 2;
+            break;
         case 4: src = e->bwd; have = Nd * (T + 1) * e->S * 4; break;
         case 5: src = e->prob_tap; have = Nd * T * 4; break;
         default: return fail(e, MIBC_ERR_ARG, "unknown tap");

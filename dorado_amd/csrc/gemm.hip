@@ -24,6 +24,15 @@ struct GemmArgs {
     int o_div;
     long o_outer, o_inner;
     int act;            // -1 identity, 0/1/2 as MIBC_ACT_*, 3 = 5*tanh
+    int ncols_valid;    // 0 = all; else columns >= ncols_valid are computed (zero weights) but not stored
+    // epilogue fusions of the transformer path (tx.hip):
+    //  mode 1: rotary embedding on q and k (columns < rope_cols), head_dim 64, half-split pairs
+    //          (c, c+32); table rope[t][32] = {cos, sin} interleaved as float2, t = m % rope_T
+    //  mode 2: SwiGLU: each 128-column tile holds 64 "y" then 64 "gate" features; writes
+    //          silu(gate) * y to 64 output columns (out row stride = Ncols / 2)
+    int epi_mode;
+    const float *rope;
+    int rope_T, rope_cols;
 };
 
 #define G_BM 128
@@ -135,15 +144,53 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p) {
         }
     }
     __syncthreads();
+    if (p.epi_mode == 2) {
+        // SwiGLU: 64 output features per tile
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int c = tid + 256 * pass;
+            const int row = c >> 3, seg = c & 7;
+            const int m = m0 + row;
+            if (m < p.M) {
+                const half8_t y = *(const half8_t *)(Cs + row * G_CLD + seg * 8);
+                const half8_t g = *(const half8_t *)(Cs + row * G_CLD + 64 + seg * 8);
+                half8_t o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gf = (float)g[e];
+                    o[e] = (half_t)(gf * fast_sigmoid(gf) * (float)y[e]);
+                }
+                half_t *dst = p.out + (long)(m / p.o_div) * p.o_outer + (long)(m % p.o_div) * p.o_inner +
+                              (c0 >> 1) + seg * 8;
+                *(half8_t *)dst = o;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
         const int c = tid + 256 * pass;
         const int row = c >> 4, seg = c & 15;
         const int m = m0 + row;
-        if (m < p.M) {
+        if (m < p.M && (p.ncols_valid == 0 || c0 + seg * 8 < p.ncols_valid)) {
             half_t *dst = p.out + (long)(m / p.o_div) * p.o_outer + (long)(m % p.o_div) * p.o_inner +
                           c0 + seg * 8;
-            *(half8_t *)dst = *(const half8_t *)(Cs + row * G_CLD + seg * 8);
+            half8_t v = *(const half8_t *)(Cs + row * G_CLD + seg * 8);
+            if (p.epi_mode == 1 && c0 + seg * 8 < p.rope_cols) {
+                // rotary: partner 8 columns are 32 columns away inside the same 64-wide head
+                const int cin = (seg * 8) & 63;               // column inside the head
+                const bool lo = cin < 32;
+                const half8_t w = *(const half8_t *)(Cs + row * G_CLD + seg * 8 + (lo ? 32 : -32));
+                const float2 *tab = (const float2 *)p.rope + (size_t)(m % p.rope_T) * 32 + (cin & 31);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float2 cs = tab[e];
+                    const float a = (float)v[e], b = (float)w[e];
+                    // evens' = cos*e - sin*o ; odds' = sin*e + cos*o   (nn/TxModules.cpp:241-244)
+                    v[e] = (half_t)(lo ? (cs.x * a - cs.y * b) : (cs.y * b + cs.x * a));
+                }
+            }
+            *(half8_t *)dst = v;
         }
     }
 }

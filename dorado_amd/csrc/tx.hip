@@ -1,0 +1,279 @@
+// dorado_amd/csrc/tx.hip — transformer-model (sup@v5) kernels that are not plain GEMMs
+// (SURVEY.md §8 a5/a6).  GEMMs (convs 2-5 as implicit im2col, QKV+RoPE, out-proj, FC1+SwiGLU, FC2,
+// upsample, CRF) run on gemm.hip's MFMA kernel with fused epilogues.
+//
+//   conv1_tx_kernel        1 -> C1 (w5, s1) + swish, NTC output with zero pad rows for conv2's window
+//                          (replaces torch Conv1d, nn/ConvStack.cpp:146-163)
+//   window_attention_kernel  sliding-window attention, window (win_upper back, win_lower forward),
+//                          head_dim 64, scores and probabilities stay in registers, QK^T and PV on
+//                          v_mfma_f32_16x16x32_f16 (replaces at::scaled_dot_product_attention in
+//                          nn/TxModules.cpp:392-420 and Koi's host_masked_attention_f16, :381).
+//                          Reproduces the CPU reference's split quirk: the K/V slice of query split
+//                          [qb, qe) is [qb - win_lower, qe + win_upper) (:405-406), so the last query
+//                          of each split does not see key i + win_lower.
+//   residual_rmsnorm_kernel  x <- RMSNorm(in + alpha * x) * w  (nn/TxModules.cpp:881, nn/RMSNorm.cpp:14-18;
+//                          replaces host_fused_residual_rmsnorm_f16, :875)
+#include "common.h"
+
+typedef float float4a __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+template <int C1>
+__global__ __launch_bounds__(256) void conv1_tx_kernel(const half_t *__restrict__ x,   // [N][T_in]
+                                                       const float *__restrict__ w,    // [5][C1]
+                                                       const float *__restrict__ b,    // [C1]
+                                                       half_t *__restrict__ out,       // [N][Tpitch][C1]
+                                                       int T_in, int Tpitch, int pad_out, int act) {
+    __shared__ float xs[256 + 8];
+    const int n = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
+    const half_t *xn = x + (size_t)n * T_in;
+    for (int i = tid; i < 256 + 4; i += 256) {
+        const int t = t0 - 2 + i;
+        xs[i] = (t >= 0 && t < T_in) ? (float)xn[t] : 0.0f;
+    }
+    __syncthreads();
+    const int t = t0 + tid;
+    if (t >= T_in) return;
+    float xv[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) xv[k] = xs[tid + k];
+    half_t *dst = out + ((size_t)n * Tpitch + pad_out + t) * C1;
+#pragma unroll
+    for (int c8 = 0; c8 < C1 / 8; ++c8) {
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c8 * 8 + e;
+            float a = b[c];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) a = fmaf(w[k * C1 + c], xv[k], a);
+            o[e] = (half_t)act_apply(a, act);
+        }
+        *(half8_t *)(dst + c8 * 8) = o;
+    }
+}
+
+extern "C" int mibc_launch_conv1_tx(hipStream_t s, const half_t *x, const float *w, const float *b,
+                                    half_t *out, int N, int T_in, int Tpitch, int pad_out, int C1, int act) {
+    dim3 grid((T_in + 255) / 256, N);
+    if (C1 == 64) {
+        hipLaunchKernelGGL((conv1_tx_kernel<64>), grid, dim3(256), 0, s, x, w, b, out, T_in, Tpitch, pad_out, act);
+        return 0;
+    }
+    return 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sliding-window attention.  Workgroup = (chunk n, head h, 64 queries q0..q0+63), 4 waves x 16
+// queries.  Keys q0-WU .. q0+63+WL (<= 64 + WU + WL, rounded up to a multiple of 32) staged in LDS:
+// K row-major [key][64 + 8 pad], V transposed [d][keys + 8 pad].
+//   S^T tile  = K_tile (A: 16 keys x 32 dims)  x  Q (B: 16 queries x 32 dims)  -> D[key][query]
+//   O^T tile  = V^T   (A: 16 dims x 32 keys)   x  P (B: 16 queries x 32 keys)  -> D[dim][query]
+// A lane therefore owns one query (lane & 15) and, per 16-key tile, keys 4*(lane>>4)+r: exactly
+// the operand slots the PV MFMA needs when its 32-key k-index is enumerated as
+// k = 8*lq + i  <->  key = 16*(2*blk + (i >> 2)) + 4*lq + (i & 3), so P never leaves registers.
+#define WA_Q 64
+#define WA_MAXKT 20   // up to 320 keys
+
+template <int KT>   // number of 16-key tiles staged (even)
+__global__ __launch_bounds__(256) void window_attention_kernel(
+        const half_t *__restrict__ qkv,  // [N*T][3*C]  q | k | v, head h at h*64
+        half_t *__restrict__ out,        // [N*T][C]
+        int T, int C, int H, int win_upper, int win_lower, int split) {
+    constexpr int NK = KT * 16;
+    constexpr int KLD = 64 + 8;
+    constexpr int VLD = NK + 8;
+    __shared__ __attribute__((aligned(16))) half_t Ks[NK * KLD];
+    __shared__ __attribute__((aligned(16))) half_t Vt[64 * VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int qtiles = (T + WA_Q - 1) / WA_Q;
+    const int qt = blockIdx.x % qtiles;
+    const int h = (blockIdx.x / qtiles) % H;
+    const int n = blockIdx.x / (qtiles * H);
+    const int q0 = qt * WA_Q;
+    const int k0 = q0 - win_upper;  // key index of staged row 0
+    const size_t row0 = (size_t)n * T;
+    const int ld = 3 * C;
+
+    // stage K (row-major) and V (transposed); keys outside [0, T) are zero (and masked below)
+    for (int c = tid; c < NK * 8; c += 256) {
+        const int kk = c >> 3, seg = c & 7;
+        const int key = k0 + kk;
+        half8_t kv = (half8_t)(0), vv = (half8_t)(0);
+        if (key >= 0 && key < T) {
+            const half_t *src = qkv + (row0 + key) * ld + h * 64 + seg * 8;
+            kv = *(const half8_t *)(src + C);
+            vv = *(const half8_t *)(src + 2 * C);
+        }
+        *(half8_t *)(Ks + kk * KLD + seg * 8) = kv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[(seg * 8 + e) * VLD + kk] = vv[e];
+    }
+    // Q fragments for this wave's 16 queries: B operand, lane (l15 = query, lq): dims 8*lq.. of 32-blocks
+    const int qi = q0 + wave * 16 + l15;
+    half8_t qf[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        qf[kb] = (half8_t)(0);
+        if (qi < T) qf[kb] = *(const half8_t *)(qkv + (row0 + qi) * ld + h * 64 + kb * 32 + 8 * lq);
+    }
+    __syncthreads();
+
+    // ---- S^T = K . Q^T, D[row = key 4*lq + r][col = query l15] ----
+    float4a sc[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        float4a acc = (float4a)(0.0f);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const half8_t kf = *(const half8_t *)(Ks + (kt * 16 + l15) * KLD + kb * 32 + 8 * lq);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kb], acc, 0, 0, 0);
+        }
+        sc[kt] = acc;
+    }
+    // ---- mask + softmax over keys (per query = per l15, across the 4 lq groups) ----
+    // visible: -win_upper <= j - i <= win_lower, 0 <= j < T, j < qe(i) + win_upper  (reference split slice)
+    const int qe = min(T, (qi / split + 1) * split);
+    const int jmax = min(min(qi + win_lower, T - 1), qe + win_upper - 1);
+    const int jmin = max(qi - win_upper, 0);
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = k0 + kt * 16 + 4 * lq + r;
+            const bool vis = (j >= jmin) && (j <= jmax);
+            const float v = vis ? sc[kt][r] * 0.125f : -3.0e38f;
+            sc[kt][r] = v;
+            m = fmaxf(m, v);
+        }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = (sc[kt][r] > -1.0e38f) ? __expf(sc[kt][r] - m) : 0.0f;
+            sc[kt][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    // ---- O^T = V^T . P^T over 32-key blocks ----
+    float4a oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = (float4a)(0.0f);
+#pragma unroll
+    for (int blk = 0; blk < KT / 2; ++blk) {
+        half8_t pf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pf[i] = (half_t)(sc[2 * blk][i] * inv);
+            pf[4 + i] = (half_t)(sc[2 * blk + 1][i] * inv);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            // A operand: lane (l15 = dim within the 16-dim tile, lq): keys 16*(2blk)+4lq.., 16*(2blk+1)+4lq..
+            const half_t *vp = Vt + (dt * 16 + l15) * VLD + blk * 32 + 4 * lq;
+            const half4_t v0 = *(const half4_t *)(vp);
+            const half4_t v1 = *(const half4_t *)(vp + 16);
+            half8_t vf;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                vf[i] = v0[i];
+                vf[4 + i] = v1[i];
+            }
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
+        }
+    }
+    // D[row = dim 4*lq + r][col = query l15]
+    if (qi < T) {
+        half_t *orow = out + (row0 + qi) * C + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            half4_t o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (half_t)oacc[dt][r];
+            *(half4_t *)(orow + dt * 16 + 4 * lq) = o;
+        }
+    }
+}
+
+extern "C" int mibc_launch_window_attention(hipStream_t s, const half_t *qkv, half_t *out, int N, int T,
+                                            int C, int H, int win_upper, int win_lower) {
+    if (C != H * 64) return 1;
+    const int nkeys = WA_Q + win_upper + win_lower;
+    const int kt = ((nkeys + 31) / 32) * 2;
+    // utils::pad_to(div_round_up(T, 12), 4)  (nn/TxModules.cpp:398-399)
+    const int split = (((T + 11) / 12) + 3) / 4 * 4;
+    dim3 grid(N * H * ((T + WA_Q - 1) / WA_Q));
+    if (kt <= 6) {
+        hipLaunchKernelGGL((window_attention_kernel<6>), grid, dim3(256), 0, s, qkv, out, T, C, H, win_upper, win_lower, split);
+    } else if (kt <= 20) {
+        hipLaunchKernelGGL((window_attention_kernel<20>), grid, dim3(256), 0, s, qkv, out, T, C, H, win_upper, win_lower, split);
+    } else {
+        return 1;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// x <- RMSNorm(in + alpha * x) * w ; one wave per row, C = 8 * 64 * VPL
+template <int C>
+__global__ __launch_bounds__(256) void residual_rmsnorm_kernel(const half_t *__restrict__ in,
+                                                               half_t *__restrict__ x,
+                                                               const float *__restrict__ w, long rows,
+                                                               float alpha) {
+    constexpr int PER = C / 64;  // halfs per lane (8 for C = 512)
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const half_t *ir = in + row * C + lane * PER;
+    half_t *xr = x + row * C + lane * PER;
+    float v[PER];
+    float ss = 0.0f;
+    if (PER == 8) {
+        const half8_t a = *(const half8_t *)ir, b = *(const half8_t *)xr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = (float)a[e] + (float)b[e] * alpha;
+            ss += v[e] * v[e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            v[e] = (float)ir[e] + (float)xr[e] * alpha;
+            ss += v[e] * v[e];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float rstd = rsqrtf(ss / (float)C + 1e-5f);
+    if (PER == 8) {
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)((v[e] * rstd) * w[lane * PER + e]);
+        *(half8_t *)xr = o;
+    } else {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) xr[e] = (half_t)((v[e] * rstd) * w[lane * PER + e]);
+    }
+}
+
+extern "C" int mibc_launch_residual_rmsnorm(hipStream_t s, const half_t *in, half_t *x, const float *w,
+                                            long rows, int C, float alpha) {
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (C == 512) {
+        hipLaunchKernelGGL((residual_rmsnorm_kernel<512>), grid, dim3(256), 0, s, in, x, w, rows, alpha);
+    } else if (C == 128) {
+        hipLaunchKernelGGL((residual_rmsnorm_kernel<128>), grid, dim3(256), 0, s, in, x, w, rows, alpha);
+    } else if (C == 256) {
+        hipLaunchKernelGGL((residual_rmsnorm_kernel<256>), grid, dim3(256), 0, s, in, x, w, rows, alpha);
+    } else {
+        return 1;
+    }
+    return 0;
+}

@@ -196,6 +196,42 @@ def test_sup_v43_shape_end_to_end():
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["tiny", "sup5_2layers"])
+def test_transformer_model_vs_oracle(name):
+    """sup@v5-style model (a5/a6): conv x5 -> TxEncoder stack -> upsample -> scaled CRF; token
+    activations and scores vs the f32 oracle (which is pinned to the compiled reference, incl. the
+    12-split attention slice quirk), then decoder exactness on the GPU's own scores."""
+    if name == "tiny":
+        cfg = config.tiny_tx()                       # d=128, 2 heads, window (15,16)
+        N, T_in = 4, 1536
+    else:
+        cfg = config.sup_v50()
+        cfg.tx.depth = 2                             # full width / heads / window (127,128), 2 layers
+        N, T_in = 2, 3072
+    ws = synth.make_weights(cfg, seed=61)
+    x16 = synth.make_signal(N, T_in, seed=62)
+    eng = capi.Engine(cfg, ws)
+    scores = eng.forward(x16)
+    T_out = eng.output_steps(T_in)
+    T_tok = T_out // cfg.tx.up_scale_factor
+    tok = eng.tap(3, (N, T_tok, cfg.tx.d_model), np.float16)
+    s_o, tok_o = O.tx_forward(cfg, ws, x16.astype(np.float32)[:, None, :], want_tokens=True)
+    assert s_o.shape == scores.shape
+    mx, rms = _err(tok, tok_o)
+    print(f"tx {name}: tokens max-abs {mx:.4f} rms {rms:.5f} (|x| rms {np.sqrt((tok_o**2).mean()):.3f})")
+    assert rms <= 0.01 and mx <= 0.15
+    mx, rms = _err(scores, s_o)
+    print(f"tx {name}: scores max-abs {mx:.4f} rms {rms:.5f} (range {s_o.min():.1f}..{s_o.max():.1f})")
+    assert rms <= 0.03 and mx <= 0.5
+    got = eng.call(x16)
+    want = O.decode(scores.astype(np.float32), det=1)
+    for a, b in zip(got, want):
+        assert a[0] == b[0] and (a[2] == b[2]).all()
+    ids = [_identity(a[0], b[0]) for a, b in zip(got, O.decode(s_o))]
+    print(f"tx {name}: identity vs f32 oracle {np.round(ids, 3)}, bases/step {np.mean([len(a[0]) for a in got]) / T_out:.2f}")
+    eng.close()
+
+
 def test_unsupported_shapes_fail_loudly():
     cfg = _cfg(64, 3, 5)  # C=64 has no kernel yet
     with pytest.raises(capi.MibcNotSupported):

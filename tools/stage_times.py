@@ -18,7 +18,7 @@ ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--model", default="hac")
 ap.add_argument("--tin", type=int, default=0)
 a = ap.parse_args()
-cfg = {"hac": config.hac_v43, "sup": config.sup_v43}.get(a.model, lambda: config.tiny(128, 4))()
+cfg = {"hac": config.hac_v43, "sup": config.sup_v43, "sup5": config.sup_v50}.get(a.model, lambda: config.tiny(128, 4))()
 t_in = a.tin or cfg.chunk_size
 eng = capi.Engine(cfg, synth.make_weights(cfg, seed=42))
 T = eng.output_steps(t_in)
@@ -34,7 +34,8 @@ res = None
 for _ in range(a.steps):
     eng.call_device(d_in, n, t_in, d_out)
     res = eng.stage_ms()
-res["lstm_layer"] = [round(v, 2) for v in res["lstm_layer"][: cfg.lstm_layers]]
+res["lstm_layer"] = [round(v, 2) for v in res["lstm_layer"][: max(1, cfg.lstm_layers)]]
+res["samples_per_s"] = round(n * t_in / (res["total"] * 1e-3))
 res = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}
 res["env"] = {k: v for k, v in os.environ.items() if k.startswith("MIBC_")}
 print(json.dumps(res))
