@@ -27,6 +27,7 @@ struct GemmArgs {
     int epi_mode;
     const float *rope;
     int rope_T, rope_cols;
+    int dbg;
 };
 extern "C" int mibc_launch_gemm_tn(hipStream_t s, const GemmArgs *a);
 struct WsArgs {

@@ -728,3 +728,30 @@ extern "C" int mibc_debug_tap(mibc_engine *e, int tap, void *host_dst, size_t by
     HIP_OK(e, hipMemcpy(host_dst, src, bytes, hipMemcpyDeviceToHost));
     return MIBC_OK;
 }
+
+
+// Microbenchmark (not part of the public ABI): C[M][N] = A[M][K] . B[N][K]^T, avg ms over `iters`.
+extern "C" int mibc_debug_gemm(int M, int N, int K, int dbg, int iters, float *ms_out) {
+    half_t *A = nullptr, *B = nullptr, *C = nullptr;
+    if (hipMalloc((void **)&A, (size_t)M * K * 2) != hipSuccess) return -1;
+    if (hipMalloc((void **)&B, (size_t)N * K * 2) != hipSuccess) return -1;
+    if (hipMalloc((void **)&C, (size_t)M * N * 2) != hipSuccess) return -1;
+    (void)hipMemset(A, 0x3c, (size_t)M * K * 2);
+    (void)hipMemset(B, 0x2c, (size_t)N * K * 2);
+    GemmArgs g{};
+    g.A = A; g.B = B; g.out = C; g.M = M; g.Ncols = N; g.K = K;
+    g.a_div = 1 << 30; g.a_inner = K; g.o_div = 1 << 30; g.o_inner = N; g.act = -1; g.dbg = dbg;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    mibc_launch_gemm_tn(nullptr, &g);
+    (void)hipEventRecord(a, nullptr);
+    for (int i = 0; i < iters; ++i) mibc_launch_gemm_tn(nullptr, &g);
+    (void)hipEventRecord(b, nullptr);
+    (void)hipEventSynchronize(b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    *ms_out = ms / iters;
+    (void)hipFree(A); (void)hipFree(B); (void)hipFree(C);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

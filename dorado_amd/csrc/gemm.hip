@@ -12,6 +12,7 @@
 // LDS as full 256-byte rows (16-byte stores per lane) — the head's scores are the largest HBM
 // stream of the LSTM models (2 KB/step for hac).
 #include "common.h"
+#include <stdlib.h>
 
 struct GemmArgs {
     const half_t *A;
@@ -33,6 +34,7 @@ struct GemmArgs {
     int epi_mode;
     const float *rope;
     int rope_T, rope_cols;
+    int dbg;            // debug ablation bits (microbenchmark only): 1 no stores, 2 no MFMA, 4 no DMA
 };
 
 #define G_BM 128
@@ -195,6 +197,196 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// gemm_dma_kernel: same tile / epilogue, but the operand tiles go HBM/L2 -> LDS by direct DMA
+// (global_load_lds_dwordx4, 16 B per lane, no staging registers), BK = 64, two LDS stages so the
+// DMA of tile k+1 overlaps the MFMAs of tile k.  The DMA writes LDS lane-linearly, so the 128-byte
+// rows cannot be padded; bank conflicts are avoided instead by an XOR swizzle of the 16-byte column
+// inside each row (phys = col ^ ((row >> 1) & 7)), applied on the SOURCE address when the tile is
+// fetched and on the fragment read (cdna_hip_programming.md §5 "both sides or neither").
+// ---------------------------------------------------------------------------------------------
+#define D_BK 32
+#define D_NST 4                      // LDS stages: 3 K tiles in flight behind the one being multiplied
+#define D_TILE (G_BM * D_BK)         // halfs per operand tile (8 KiB)
+#define D_STAGE (2 * D_TILE)         // A + B (16 KiB)
+
+__device__ __forceinline__ void dma16(const half_t *g, half_t *l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) half_t lds[D_NST * D_STAGE];  // 65536 B
+    half_t *Cs = lds;                                                     // [128][136] aliases the stages
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ncol = p.Ncols / G_BN;
+    const int nrow = (p.M + G_BM - 1) / G_BM;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int rowtile = (j / ncol) * 8 + xcd;
+    if (rowtile >= nrow) {
+        return;
+    }
+    const int m0 = rowtile * G_BM;
+    const int c0 = (j % ncol) * G_BN;
+
+    // DMA assignment (64-byte rows): instruction q of this wave fills 16-byte slots
+    // [(wave*2+q)*64, +64) of the tile: row = (wave*2+q)*16 + lane/4, physical column lane%4 <-
+    // logical column (lane%4) ^ ((row >> 2) & 3)
+    const half_t *a_ptr[2], *b_ptr[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (wave * 2 + q) * 16 + (lane >> 2);
+        const int col = (lane & 3) ^ ((row >> 2) & 3);
+        int am = m0 + row;
+        if (am >= p.M) am = p.M - 1;
+        a_ptr[q] = p.A + (long)(am / p.a_div) * p.a_outer + (long)(am % p.a_div) * p.a_inner + col * 8;
+        b_ptr[q] = p.B + (long)(c0 + row) * p.K + col * 8;
+    }
+    auto issue = [&](int kt) {
+        half_t *As = lds + (kt % D_NST) * D_STAGE, *Bs = As + D_TILE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            dma16(a_ptr[q] + kt * D_BK, As + (wave * 2 + q) * 512);
+            dma16(b_ptr[q] + kt * D_BK, Bs + (wave * 2 + q) * 512);
+        }
+    };
+
+    float16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
+
+    const int nk = p.K / D_BK;
+#pragma unroll
+    for (int s0 = 0; s0 < D_NST - 1; ++s0)
+        if (s0 < nk) issue(s0);
+    int wrow[2], xrow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        wrow[i] = wn * 64 + i * 32 + (lane & 31);
+        xrow[i] = wm * 64 + i * 32 + (lane & 31);
+    }
+    const int lhi = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed when at most the (up to 2) younger stages' DMAs (4 per wave each) are
+        // still outstanding; a raw barrier (no vmcnt(0) drain) then publishes it to all waves and
+        // also proves everybody is done reading the slot that stage kt+3 is about to overwrite
+        if (kt + 2 < nk) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (kt + 1 < nk) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (kt + D_NST - 1 < nk && !(p.dbg & 4)) issue(kt + D_NST - 1);
+        const half_t *As = lds + (kt % D_NST) * D_STAGE, *Bs = As + D_TILE;
+#pragma unroll
+        for (int ks = 0; ks < D_BK / 16; ++ks) {
+            half8_t wf[2], xf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                wf[i] = *(const half8_t *)(Bs + wrow[i] * D_BK + (((2 * ks + lhi) ^ ((wrow[i] >> 2) & 3)) << 3));
+                xf[i] = *(const half8_t *)(As + xrow[i] * D_BK + (((2 * ks + lhi) ^ ((xrow[i] >> 2) & 3)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    if (!(p.dbg & 2)) acc[i][jj] = mfma32x32x16(wf[i], xf[jj], acc[i][jj]);
+        }
+    }
+    __syncthreads();  // all stage reads done before Cs (aliasing) is written
+    if (p.dbg & 1) {
+        if (acc[0][0][0] == 123.456f) p.out[0] = (half_t)1.0f;
+        return;
+    }
+
+    // epilogue: D rows = output columns (weights), D cols = output rows m
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int mloc = wm * 64 + jj * 32 + (lane & 31);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cloc = wn * 64 + i * 32 + 8 * q + 4 * (lane >> 5);
+                half4_t h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][jj][q * 4 + e];
+                    if (p.bias != nullptr) v += p.bias[c0 + cloc + e];
+                    if (p.act == 3) {
+                        v = 5.0f * fast_tanh(v);
+                    } else if (p.act >= 0) {
+                        v = act_apply(v, p.act);
+                    }
+                    h[e] = (half_t)v;
+                }
+                *(half4_t *)(Cs + mloc * G_CLD + cloc) = h;
+            }
+        }
+    }
+    __syncthreads();
+    if (p.epi_mode == 2) {
+        // SwiGLU: 64 output features per tile
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int c = tid + 256 * pass;
+            const int row = c >> 3, seg = c & 7;
+            const int m = m0 + row;
+            if (m < p.M) {
+                const half8_t y = *(const half8_t *)(Cs + row * G_CLD + seg * 8);
+                const half8_t g = *(const half8_t *)(Cs + row * G_CLD + 64 + seg * 8);
+                half8_t o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gf = (float)g[e];
+                    o[e] = (half_t)(gf * fast_sigmoid(gf) * (float)y[e]);
+                }
+                half_t *dst = p.out + (long)(m / p.o_div) * p.o_outer + (long)(m % p.o_div) * p.o_inner +
+                              (c0 >> 1) + seg * 8;
+                *(half8_t *)dst = o;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int c = tid + 256 * pass;
+        const int row = c >> 4, seg = c & 15;
+        const int m = m0 + row;
+        if (m < p.M && (p.ncols_valid == 0 || c0 + seg * 8 < p.ncols_valid)) {
+            half_t *dst = p.out + (long)(m / p.o_div) * p.o_outer + (long)(m % p.o_div) * p.o_inner +
+                          c0 + seg * 8;
+            half8_t v = *(const half8_t *)(Cs + row * G_CLD + seg * 8);
+            if (p.epi_mode == 1 && c0 + seg * 8 < p.rope_cols) {
+                // rotary: partner 8 columns are 32 columns away inside the same 64-wide head
+                const int cin = (seg * 8) & 63;               // column inside the head
+                const bool lo = cin < 32;
+                const half8_t w = *(const half8_t *)(Cs + row * G_CLD + seg * 8 + (lo ? 32 : -32));
+                const float2 *tab = (const float2 *)p.rope + (size_t)(m % p.rope_T) * 32 + (cin & 31);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float2 cs = tab[e];
+                    const float a = (float)v[e], b = (float)w[e];
+                    // evens' = cos*e - sin*o ; odds' = sin*e + cos*o   (nn/TxModules.cpp:241-244)
+                    v[e] = (half_t)(lo ? (cs.x * a - cs.y * b) : (cs.y * b + cs.x * a));
+                }
+            }
+            *(half8_t *)dst = v;
+        }
+    }
+}
+
 extern "C" int mibc_launch_gemm_tn(hipStream_t s, const GemmArgs *a) {
     if (a->K % G_BK != 0 || a->Ncols % G_BN != 0 || a->M <= 0) {
         return 1;
@@ -202,6 +394,11 @@ extern "C" int mibc_launch_gemm_tn(hipStream_t s, const GemmArgs *a) {
     const int ncol = a->Ncols / G_BN;
     const int nrow = (a->M + G_BM - 1) / G_BM;
     dim3 grid(((nrow + 7) / 8) * 8 * ncol);
+    static const int use_dma = getenv("MIBC_GEMM_DMA") ? atoi(getenv("MIBC_GEMM_DMA")) : 1;
+    if (use_dma && a->K % D_BK == 0) {
+        hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(256), 0, s, *a);
+        return 0;
+    }
     hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, s, *a);
     return 0;
 }
