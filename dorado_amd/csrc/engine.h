@@ -27,6 +27,7 @@ struct GemmArgs {
     int epi_mode;
     const float *rope;
     int rope_T, rope_cols;
+    half_t *vT;
     int dbg;
 };
 extern "C" int mibc_launch_gemm_tn(hipStream_t s, const GemmArgs *a);
@@ -116,6 +117,7 @@ struct mibc_engine {
         std::vector<half_t *> cbuf;   // padded conv outputs (NTC)
         std::vector<int> ctp, ct;     // row pitch and valid steps per conv buffer
         half_t *x = nullptr, *qkv = nullptr, *attn = nullptr, *tmp = nullptr, *ff = nullptr, *up = nullptr;
+        half_t *vT = nullptr;         // V transposed [N][H][64][T] (when T % 128 == 0)
         int T_tok = 0;
         hipEvent_t ev_conv = nullptr, ev_layers = nullptr;
     } tx;

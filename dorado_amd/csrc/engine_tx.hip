@@ -10,6 +10,9 @@ extern "C" int mibc_launch_conv1_tx(hipStream_t s, const half_t *x, const float 
                                     half_t *out, int N, int T_in, int Tpitch, int pad_out, int C1, int act);
 extern "C" int mibc_launch_window_attention(hipStream_t s, const half_t *qkv, half_t *out, int N, int T,
                                             int C, int H, int win_upper, int win_lower);
+extern "C" int mibc_launch_window_attention_v2(hipStream_t s, const half_t *qk, const half_t *vT, half_t *out,
+                                               int N, int T, int C, int H, int ld, int win_upper,
+                                               int win_lower);
 extern "C" int mibc_launch_residual_rmsnorm(hipStream_t s, const half_t *in, half_t *x, const float *w,
                                             long rows, int C, float alpha);
 
@@ -131,10 +134,10 @@ void tx_free_ws(mibc_engine *e) {
     tx.cbuf.clear();
     tx.ctp.clear();
     tx.ct.clear();
-    void *ptrs[] = {tx.x, tx.qkv, tx.attn, tx.tmp, tx.ff, tx.up};
+    void *ptrs[] = {tx.x, tx.qkv, tx.attn, tx.tmp, tx.ff, tx.up, tx.vT};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    tx.x = tx.qkv = tx.attn = tx.tmp = tx.ff = tx.up = nullptr;
+    tx.x = tx.qkv = tx.attn = tx.tmp = tx.ff = tx.up = tx.vT = nullptr;
 }
 
 void tx_destroy(mibc_engine *e) {
@@ -210,6 +213,9 @@ int tx_reserve(mibc_engine *e, int N_max, int T_in, size_t *total_out) {
     const size_t R = N * (size_t)T;
     if (alloc(&tx.x, R * tx.D, false)) return MIBC_ERR_MEM;
     if (alloc(&tx.qkv, R * 3 * tx.D, false)) return MIBC_ERR_MEM;
+    static const int att_v2 = getenv("MIBC_ATT_V2") ? atoi(getenv("MIBC_ATT_V2")) : 1;
+    if (att_v2 && T % 128 == 0)
+        if (alloc(&tx.vT, R * tx.D, false)) return MIBC_ERR_MEM;
     if (alloc(&tx.attn, R * tx.D, false)) return MIBC_ERR_MEM;
     if (alloc(&tx.tmp, R * tx.D, false)) return MIBC_ERR_MEM;
     if (alloc(&tx.ff, R * tx.FF, false)) return MIBC_ERR_MEM;
@@ -241,6 +247,7 @@ static int gemm(mibc_engine *e, const half_t *A, const half_t *B, const float *b
         g.rope = e->tx.rope;
         g.rope_T = e->tx.T_tok;
         g.rope_cols = 2 * e->tx.D;
+        g.vT = e->tx.vT;
     }
     return mibc_launch_gemm_tn(e->stream, &g);
 }
@@ -289,9 +296,14 @@ int tx_run_network(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
         const auto &L = tx.layers[l];
         if (gemm(e, tx.x, L.wqkv, nullptr, tx.qkv, R, 3 * C, C, -1, /*rope*/ 1) != 0)
             return fail(e, MIBC_NOT_SUPPORTED, "tx qkv gemm");
-        if (mibc_launch_window_attention(e->stream, tx.qkv, tx.attn, N, T, C, tx.H, d.tx_win_upper,
-                                         d.tx_win_lower) != 0)
-            return fail(e, MIBC_NOT_SUPPORTED, "tx attention shape");
+        int arc;
+        if (tx.vT)
+            arc = mibc_launch_window_attention_v2(e->stream, tx.qkv, tx.vT, tx.attn, N, T, C, tx.H, 3 * C,
+                                                  d.tx_win_upper, d.tx_win_lower);
+        else
+            arc = mibc_launch_window_attention(e->stream, tx.qkv, tx.attn, N, T, C, tx.H, d.tx_win_upper,
+                                               d.tx_win_lower);
+        if (arc != 0) return fail(e, MIBC_NOT_SUPPORTED, "tx attention shape");
         if (gemm(e, tx.attn, L.wo, L.bo, tx.tmp, R, C, C, -1) != 0) return fail(e, MIBC_NOT_SUPPORTED, "tx out_proj");
         if (mibc_launch_residual_rmsnorm(e->stream, tx.tmp, tx.x, L.n1, R, C, d.tx_deepnorm_alpha) != 0)
             return fail(e, MIBC_NOT_SUPPORTED, "tx rmsnorm");

@@ -34,6 +34,7 @@ struct GemmArgs {
     int epi_mode;
     const float *rope;
     int rope_T, rope_cols;
+    half_t *vT;         // epi_mode 1: if set, columns >= 2*rope_cols/2.. (the V third) go to vT[n][h][64][rope_T]
     int dbg;            // debug ablation bits (microbenchmark only): 1 no stores, 2 no MFMA, 4 no DMA
 };
 
@@ -166,6 +167,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p) {
                               (c0 >> 1) + seg * 8;
                 *(half8_t *)dst = o;
             }
+        }
+        return;
+    }
+    if (p.epi_mode == 1 && p.vT != nullptr && c0 >= p.rope_cols) {
+        // V third of the QKV projection: store TRANSPOSED, vT[n][h][d][t] (t contiguous), so the
+        // attention kernel can stage its P.V operand with plain coalesced 16-byte loads.
+        // Requires rope_T % 128 == 0 (a 128-row tile never straddles two chunks).
+        const int n = m0 / p.rope_T, t0 = m0 % p.rope_T;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int c = tid + 256 * pass;          // 128 columns x 16 groups of 8 tokens
+            const int col = c >> 4, tg = c & 15;
+            half8_t v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = Cs[(tg * 8 + e) * G_CLD + col];
+            const int cv = c0 - p.rope_cols + col;   // column inside V: h*64 + d
+            *(half8_t *)(p.vT + ((size_t)n * (p.Ncols - p.rope_cols) + cv) * p.rope_T + t0 + tg * 8) = v;
         }
         return;
     }
@@ -356,6 +374,23 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmArgs p) {
                               (c0 >> 1) + seg * 8;
                 *(half8_t *)dst = o;
             }
+        }
+        return;
+    }
+    if (p.epi_mode == 1 && p.vT != nullptr && c0 >= p.rope_cols) {
+        // V third of the QKV projection: store TRANSPOSED, vT[n][h][d][t] (t contiguous), so the
+        // attention kernel can stage its P.V operand with plain coalesced 16-byte loads.
+        // Requires rope_T % 128 == 0 (a 128-row tile never straddles two chunks).
+        const int n = m0 / p.rope_T, t0 = m0 % p.rope_T;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int c = tid + 256 * pass;          // 128 columns x 16 groups of 8 tokens
+            const int col = c >> 4, tg = c & 15;
+            half8_t v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = Cs[(tg * 8 + e) * G_CLD + col];
+            const int cv = c0 - p.rope_cols + col;   // column inside V: h*64 + d
+            *(half8_t *)(p.vT + ((size_t)n * (p.Ncols - p.rope_cols) + cv) * p.rope_T + t0 + tg * 8) = v;
         }
         return;
     }

@@ -220,6 +220,182 @@ extern "C" int mibc_launch_window_attention(hipStream_t s, const half_t *qkv, ha
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// v2: 128 queries per workgroup (8 waves x 16 queries).  V arrives pre-transposed (vT[n][h][d][t],
+// written by the QKV GEMM epilogue) so both the K window (row-major) and the V^T window are staged
+// into LDS with bulk coalesced 16-byte loads (one memory latency per workgroup instead of one per
+// key tile); each wave only multiplies the KW key tiles its own 16 queries can see.
+//   staged keys: k0 = q0 - back (back = win_upper rounded up to 8), NK = 16 * (7 + KW)
+//   wave w, local tile i  <->  staged tile w + i
+template <int KW>   // key tiles per wave (even): covers back + 15 + win_lower + 1 keys
+__global__ __launch_bounds__(512) void window_attention_v2_kernel(
+        const half_t *__restrict__ qk,   // [N*T][ld]  q | k (| unused), head h at h*64
+        const half_t *__restrict__ vT,   // [N][H][64][T]
+        half_t *__restrict__ out,        // [N*T][C]
+        int T, int C, int H, int ld, int win_upper, int win_lower, int split, int back, int npairs) {
+    constexpr int NK = 16 * (7 + KW);
+    constexpr int KLD = 64 + 8;
+    constexpr int VLD = NK + 8;
+    __shared__ __attribute__((aligned(16))) half_t Ks[NK * KLD];
+    __shared__ __attribute__((aligned(16))) half_t Vt[64 * VLD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    // XCD-aware order: all query tiles of one (chunk, head) pair run on the same XCD back to back
+    const int qtiles = (T + 127) / 128;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int pair = (jb / qtiles) * 8 + xcd;
+    if (pair >= npairs) return;
+    const int qt = jb % qtiles;
+    const int h = pair % H;
+    const int n = pair / H;
+    const int q0 = qt * 128;
+    const int k0 = q0 - back;
+    const size_t row0 = (size_t)n * T;
+
+    // bulk staging: ALL global loads are issued before the first LDS store (one memory latency
+    // per workgroup; a load -> store loop would serialise one HBM round trip per iteration)
+    constexpr int KCH = (NK * 8 + 511) / 512;
+    constexpr int VCH = (64 * (NK / 8) + 511) / 512;
+    const half_t *vrow = vT + ((size_t)n * H + h) * 64 * T;
+    half8_t kreg[KCH], vreg[VCH];
+#pragma unroll
+    for (int it = 0; it < KCH; ++it) {
+        const int c = tid + 512 * it;
+        const int kk = c >> 3, seg = c & 7;
+        const int key = k0 + kk;
+        kreg[it] = (half8_t)(0);
+        if (c < NK * 8 && key >= 0 && key < T)
+            kreg[it] = *(const half8_t *)(qk + (row0 + key) * ld + C + h * 64 + seg * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < VCH; ++it) {
+        const int c = tid + 512 * it;
+        const int d = c / (NK / 8), kg = c % (NK / 8);
+        const int key = k0 + kg * 8;
+        vreg[it] = (half8_t)(0);
+        if (c < 64 * (NK / 8) && key >= 0 && key + 8 <= T) vreg[it] = *(const half8_t *)(vrow + (size_t)d * T + key);
+    }
+    const int qi = q0 + wave * 16 + l15;
+    half8_t qf[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        qf[kb] = (half8_t)(0);
+        if (qi < T) qf[kb] = *(const half8_t *)(qk + (row0 + qi) * ld + h * 64 + kb * 32 + 8 * lq);
+    }
+#pragma unroll
+    for (int it = 0; it < KCH; ++it) {
+        const int c = tid + 512 * it;
+        if (c < NK * 8) *(half8_t *)(Ks + (c >> 3) * KLD + (c & 7) * 8) = kreg[it];
+    }
+#pragma unroll
+    for (int it = 0; it < VCH; ++it) {
+        const int c = tid + 512 * it;
+        if (c < 64 * (NK / 8)) *(half8_t *)(Vt + (c / (NK / 8)) * VLD + (c % (NK / 8)) * 8) = vreg[it];
+    }
+    __syncthreads();
+
+    float4a sc[KW];
+#pragma unroll
+    for (int i = 0; i < KW; ++i) {
+        float4a acc = (float4a)(0.0f);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const half8_t kf = *(const half8_t *)(Ks + ((wave + i) * 16 + l15) * KLD + kb * 32 + 8 * lq);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kb], acc, 0, 0, 0);
+        }
+        sc[i] = acc;
+    }
+    // visible: -win_upper <= j - i <= win_lower, 0 <= j < T, j < qe(i) + win_upper (reference split slice)
+    const int qe = min(T, (qi / split + 1) * split);
+    const int jmax = min(min(qi + win_lower, T - 1), qe + win_upper - 1);
+    const int jmin = max(qi - win_upper, 0);
+    const int jbase = k0 + wave * 16 + 4 * lq;
+    float m = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < KW; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = jbase + i * 16 + r;
+            const bool vis = (j >= jmin) && (j <= jmax);
+            const float v = vis ? sc[i][r] * 0.125f : -3.0e38f;
+            sc[i][r] = v;
+            m = fmaxf(m, v);
+        }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < KW; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = (sc[i][r] > -1.0e38f) ? __expf(sc[i][r] - m) : 0.0f;
+            sc[i][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    float4a oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = (float4a)(0.0f);
+#pragma unroll
+    for (int blk = 0; blk < KW / 2; ++blk) {
+        half8_t pf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pf[i] = (half_t)(sc[2 * blk][i] * inv);
+            pf[4 + i] = (half_t)(sc[2 * blk + 1][i] * inv);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const half_t *vp = Vt + (dt * 16 + l15) * VLD + (wave + 2 * blk) * 16 + 4 * lq;
+            const half4_t v0 = *(const half4_t *)(vp);
+            const half4_t v1 = *(const half4_t *)(vp + 16);
+            half8_t vf;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                vf[i] = v0[i];
+                vf[4 + i] = v1[i];
+            }
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
+        }
+    }
+    if (qi < T) {
+        half_t *orow = out + (row0 + qi) * C + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            half4_t o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (half_t)oacc[dt][r];
+            *(half4_t *)(orow + dt * 16 + 4 * lq) = o;
+        }
+    }
+}
+
+extern "C" int mibc_launch_window_attention_v2(hipStream_t s, const half_t *qk, const half_t *vT, half_t *out,
+                                               int N, int T, int C, int H, int ld, int win_upper,
+                                               int win_lower) {
+    if (C != H * 64 || T % 8 != 0) return 1;
+    const int back = (win_upper + 7) / 8 * 8;
+    // keys a wave can see relative to its first staged tile: [back - win_upper .. back + 15 + win_lower]
+    const int span = back + 15 + win_lower + 1;
+    int kw = (span + 15) / 16;
+    kw += kw & 1;
+    const int split = (((T + 11) / 12) + 3) / 4 * 4;
+    const int npairs = N * H;
+    dim3 grid(((npairs + 7) / 8) * 8 * ((T + 127) / 128));
+    if (kw <= 4) {
+        hipLaunchKernelGGL((window_attention_v2_kernel<4>), grid, dim3(512), 0, s, qk, vT, out, T, C, H, ld, win_upper, win_lower, split, back, npairs);
+    } else if (kw <= 18) {
+        hipLaunchKernelGGL((window_attention_v2_kernel<18>), grid, dim3(512), 0, s, qk, vT, out, T, C, H, ld, win_upper, win_lower, split, back, npairs);
+    } else {
+        return 1;
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // x <- RMSNorm(in + alpha * x) * w ; one wave per row, C = 8 * 64 * VPL
 template <int C>

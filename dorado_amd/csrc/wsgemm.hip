@@ -65,11 +65,20 @@ __global__ __launch_bounds__(512, 2) void wsgemm_kernel(WsArgs p) {
         rows_valid = min(WS_ROWS, p.Ns - nloc);
         out_base = nloc;
         const half_t *src = p.A + ((size_t)t_fix * p.N + p.n0 + nloc) * K;
-        for (int c = tid; c < WS_ROWS * (K / 8); c += 512) {
+        // all global loads first, then the LDS stores (one memory latency, not one per iteration)
+        constexpr int CH = WS_ROWS * (K / 8) / 512;
+        half8_t stg_r[CH];
+#pragma unroll
+        for (int it = 0; it < CH; ++it) {
+            const int c = tid + 512 * it;
             const int row = c / (K / 8), col8 = c % (K / 8);
-            half8_t v = (half8_t)(0);
-            if (row < rows_valid) v = *(const half8_t *)(src + (size_t)row * K + col8 * 8);
-            *(half8_t *)(lds + row * LD + col8 * 8) = v;
+            stg_r[it] = (half8_t)(0);
+            if (row < rows_valid) stg_r[it] = *(const half8_t *)(src + (size_t)row * K + col8 * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < CH; ++it) {
+            const int c = tid + 512 * it;
+            *(half8_t *)(lds + (c / (K / 8)) * LD + (c % (K / 8)) * 8) = stg_r[it];
         }
     } else {
         const int tiles_per_chunk = (p.T + WS_ROWS - 1) / WS_ROWS;
@@ -81,11 +90,20 @@ __global__ __launch_bounds__(512, 2) void wsgemm_kernel(WsArgs p) {
         const half_t *src = p.A + ((size_t)n_fix * p.Tpitch + (size_t)p.stride * t0) * 16;
         const int span_halfs = (WS_ROWS - 1) * p.stride * 16 + K + 16;
         const long avail = ((long)p.Tpitch - (long)p.stride * t0) * 16;  // stay inside this chunk + slack
-        for (int c = tid; c < (span_halfs + 7) / 8; c += 512) {
-            half8_t v = (half8_t)(0);
-            if ((long)c * 8 + 8 <= avail) v = *(const half8_t *)(src + (size_t)c * 8);
+        constexpr int CH1 = 4;  // span <= 4 * 512 * 8 halfs
+        half8_t stg_r[CH1];
+        const int nch = (span_halfs + 7) / 8;
+#pragma unroll
+        for (int it = 0; it < CH1; ++it) {
+            const int c = tid + 512 * it;
+            stg_r[it] = (half8_t)(0);
+            if (c < nch && (long)c * 8 + 8 <= avail) stg_r[it] = *(const half8_t *)(src + (size_t)c * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < CH1; ++it) {
+            const int c = tid + 512 * it;
             const int h = c * 8;
-            *(half8_t *)(lds + (h / SPAN_BLK) * (SPAN_BLK + 16) + (h % SPAN_BLK)) = v;
+            if (c < nch) *(half8_t *)(lds + (h / SPAN_BLK) * (SPAN_BLK + 16) + (h % SPAN_BLK)) = stg_r[it];
         }
     }
     __syncthreads();
