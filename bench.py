@@ -61,8 +61,27 @@ def lstm_flops_per_launch(cfg, n, t):
     return float(n) * t * 2.0 * (4 * c) * (2 * c)
 
 
+def tx_layer_flops(cfg):
+    """2*MAC per token per encoder layer: qkv, attention over the window, out-proj, fc1, fc2."""
+    t = cfg.tx
+    c, f = t.d_model, t.dim_feedforward
+    win = t.attn_window[0] + t.attn_window[1] + 1
+    return 2.0 * (c * 3 * c + 2 * win * c + c * c + c * 2 * f + f * c)
+
+
 def network_flops_per_sample(cfg):
     """2*MAC of conv + LSTM + head per raw sample."""
+    if cfg.tx is not None:
+        per_tok = 0.0
+        up = cfg.conv_stride
+        for cv in cfg.convs:
+            up //= cv.stride
+            per_tok += 2.0 * cv.insize * cv.size * cv.winlen * up
+        t = cfg.tx
+        per_tok += t.depth * tx_layer_flops(cfg)
+        per_tok += 2.0 * t.d_model * t.up_scale_factor * t.d_model
+        per_tok += 2.0 * t.d_model * cfg.outsize * t.up_scale_factor
+        return per_tok / cfg.conv_stride
     per_step = 0.0
     s = 1
     for cv in cfg.convs:
@@ -149,6 +168,8 @@ def main():
         cfg = config.hac_v43()
     elif args.model == "sup":
         cfg = config.sup_v43()
+    elif args.model == "sup5":
+        cfg = config.sup_v50()
     elif args.model == "tiny":
         cfg = config.tiny(128, 4)
     else:
@@ -166,6 +187,8 @@ def main():
         cap = int((free_b * 0.8 - fixed) // per_chunk)
         g = eng.batch_granularity()
         n = max(g, min(256 * g, (cap // g) * g))   # one LSTM workgroup per CU
+        if cfg.tx is not None:
+            n = min(1024, cap)
     eng.reserve(n, t_in)
 
     # synthetic signal: 256 distinct seeded chunks tiled to the batch, resident in HBM
@@ -194,7 +217,7 @@ def main():
         # HIP-event stage times of THIS step on the engine's stream (waits for the step's last
         # event, which the next step would have to wait for anyway: one stream, in order)
         stage = eng.stage_ms()
-        lstm_ms.extend(stage["lstm_layer"][: cfg.lstm_layers])
+        lstm_ms.extend(stage["lstm_layer"][: max(1, cfg.lstm_layers)])
     eng.sync()
     barrier()
     el = time.perf_counter() - t0
@@ -210,8 +233,14 @@ def main():
     if rank == 0:
         total_samples = float(world) * n * t_in * args.steps
         value = total_samples / el
-        k_ms = float(np.mean(lstm_ms))
-        fl = lstm_flops_per_launch(cfg, n, T)
+        if cfg.tx is None:
+            k_ms = float(np.mean(lstm_ms))
+            fl = lstm_flops_per_launch(cfg, n, T)
+            kname = "lstm_layer_%s_kernel<%d>" % ("x8" if cfg.lstm_size <= 384 else "xg", cfg.lstm_size)
+        else:
+            k_ms = float(stage["lstm"])
+            fl = n * (T // cfg.tx.up_scale_factor) * tx_layer_flops(cfg) * cfg.tx.depth
+            kname = "transformer encoder stack (gemm_dma_kernel + window_attention_v2_kernel)"
         achieved = fl / (k_ms * 1e-3)
         tr = pmc_traffic("lstm_layer_x8", args.model, n, t_in)
         line = {
@@ -237,11 +266,11 @@ def main():
             "stage_ms_last_step": stage,
             "network_tflops": value * network_flops_per_sample(cfg) / 1e12,
             "roofline": {
-                "kernel": "lstm_layer_%s_kernel<%d>" % ("x8" if cfg.lstm_size <= 384 else "xg", cfg.lstm_size),
+                "kernel": kname,
                 "bound": "mfma", "achieved": achieved / 1e12, "peak": MFMA_F16_PEAK / 1e12,
                 "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK,
                 "traffic": (tr or {}).get("hbm_bytes"), "traffic_source": (tr or {}).get("source"),
-                "traffic_algorithmic": 2.0 * n * T * cfg.lstm_size * 2,  # read x_t + write h_t, f16
+                "traffic_algorithmic": (2.0 * n * T * cfg.lstm_size * 2) if cfg.tx is None else None,
                 "launch_ms": k_ms, "flops_per_launch": fl,
             },
         }
@@ -259,17 +288,21 @@ def main():
                 line["extra"] = {"sup_v43": side_run(capi, config.sup_v43(), synth, local_rank)}
             except Exception as ex:
                 line["extra"] = {"sup_v43": {"error": repr(ex)}}
+            try:
+                line["extra"]["sup_v50"] = side_run(capi, config.sup_v50(), synth, local_rank, n=1024)
+            except Exception as ex:
+                line["extra"]["sup_v50"] = {"error": repr(ex)}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 
 
-def side_run(capi, cfg, synth, device, steps=2):
+def side_run(capi, cfg, synth, device, steps=2, n=None):
     """Secondary measurement (not the headline value): same hot path, another model shape."""
     t_in = cfg.chunk_size
     eng = capi.Engine(cfg, synth.make_weights(cfg, seed=42), device=device)
     T = eng.output_steps(t_in)
-    n = 256 * eng.batch_granularity()
+    n = n or 256 * eng.batch_granularity()
     eng.reserve(n, t_in)
     base = synth.make_signal(64, t_in, seed=7)
     x = np.tile(base, (n // 64, 1))
@@ -286,14 +319,21 @@ def side_run(capi, cfg, synth, device, steps=2):
         lstm.extend(st["lstm_layer"][: cfg.lstm_layers])
     eng.sync()
     el = time.perf_counter() - t0
-    k_ms = float(np.mean(lstm))
-    fl = lstm_flops_per_launch(cfg, n, T)
     res = {"workload": f"{cfg.name}, chunksize {t_in}, batch {n}", "samples_per_s": n * t_in * steps / el,
            "ms_per_step": el / steps * 1e3, "stage_ms_last_step": st,
-           "network_tflops": n * t_in * steps / el * network_flops_per_sample(cfg) / 1e12,
-           "roofline": {"kernel": "lstm_layer_xg_kernel<%d>" % cfg.lstm_size, "bound": "mfma",
-                        "achieved": fl / (k_ms * 1e-3) / 1e12, "peak": MFMA_F16_PEAK / 1e12,
-                        "unit": "TFLOP/s", "frac": fl / (k_ms * 1e-3) / MFMA_F16_PEAK, "launch_ms": k_ms}}
+           "network_tflops": n * t_in * steps / el * network_flops_per_sample(cfg) / 1e12}
+    if cfg.tx is None:
+        k_ms = float(np.mean(lstm))
+        fl = lstm_flops_per_launch(cfg, n, T)
+        res["roofline"] = {"kernel": "lstm_layer_xg_kernel<%d>" % cfg.lstm_size, "bound": "mfma",
+                           "achieved": fl / (k_ms * 1e-3) / 1e12, "peak": MFMA_F16_PEAK / 1e12,
+                           "unit": "TFLOP/s", "frac": fl / (k_ms * 1e-3) / MFMA_F16_PEAK, "launch_ms": k_ms}
+    else:  # encoder stack (18 layers of GEMMs + attention) reported as one stage
+        enc_ms = st["lstm"]
+        fl = n * (T // cfg.tx.up_scale_factor) * tx_layer_flops(cfg) * cfg.tx.depth
+        res["roofline"] = {"kernel": "transformer encoder stack (gemm_dma_kernel + window_attention_v2_kernel)",
+                           "bound": "mfma", "achieved": fl / (enc_ms * 1e-3) / 1e12, "peak": MFMA_F16_PEAK / 1e12,
+                           "unit": "TFLOP/s", "frac": fl / (enc_ms * 1e-3) / MFMA_F16_PEAK, "stage_ms": enc_ms}
     eng.device_free(d_in)
     eng.device_free(d_out)
     eng.close()
