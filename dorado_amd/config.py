@@ -200,6 +200,38 @@ def hac_v43() -> ModelConfig:
     return cfg
 
 
+def fast_v40() -> ModelConfig:
+    """dna_r10.4.1_e8.2_260bps_fast@v4.0.0 (tests/data/model_configs/.../config.toml): C = 96,
+    conv3 stride 5 + swish, state_len 3, plain linear head, no clamp; qscore scale 1.04, bias -3."""
+    cfg = ModelConfig(
+        convs=[
+            ConvParams(1, 16, 5, 1, ACT_SWISH),
+            ConvParams(16, 16, 5, 1, ACT_SWISH),
+            ConvParams(16, 96, 19, 5, ACT_SWISH),
+        ],
+        lstm_size=96, lstm_layers=5, state_len=3, clamp=False, qscale=1.04, qbias=-3.0,
+        name="dna_r10.4.1_e8.2_260bps_fast@v4.0.0",
+    )
+    cfg.normalise_basecaller_params()
+    return cfg
+
+
+def fast_v43() -> ModelConfig:
+    """dna_r10.4.1_e8.2_400bps_fast@v4.3.0 — config NOT in the reference tree; inferred in
+    SURVEY.md §8 (C = 96, stride 6, state_len 3)."""
+    cfg = ModelConfig(
+        convs=[
+            ConvParams(1, 16, 5, 1, ACT_SWISH),
+            ConvParams(16, 16, 5, 1, ACT_SWISH),
+            ConvParams(16, 96, 19, 6, ACT_TANH),
+        ],
+        lstm_size=96, lstm_layers=5, state_len=3, clamp=True,
+        name="dna_r10.4.1_e8.2_400bps_fast@v4.3.0(inferred)",
+    )
+    cfg.normalise_basecaller_params()
+    return cfg
+
+
 def sup_v43() -> ModelConfig:
     """dna_r10.4.1_e8.2_400bps_sup@v4.3.0 — config NOT in the reference tree; topology
     inferred in SURVEY.md §8 (C=1024, state_len 5)."""

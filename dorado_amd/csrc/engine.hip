@@ -83,7 +83,7 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
     const int C = d.lstm_size;
     if (d.conv_size[2] != C || mibc_lstm_rows_per_wg(C) == 0) {
         return fail(nullptr, MIBC_NOT_SUPPORTED,
-                    "lstm_size must be one of 128/256/384/512/768/1024 for now");
+                    "lstm_size must be one of 96/128/256/384/512/768/1024 for now");
     }
     const int S = 1 << (2 * d.state_len);
     if (S != 64 && S != 256 && S != 1024) {
@@ -142,12 +142,14 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
         e->K3 = W3 * 16;
         e->K3pad = (e->K3 + 31) / 32 * 32;
         const float *W = weights[wi++], *B = weights[wi++];
-        std::vector<half_t> w((size_t)C * e->K3pad, (half_t)0.0f);
+        const int Cpad = (C + 127) / 128 * 128;  // GEMM column tiles are 128 wide (C = 96: masked)
+        std::vector<half_t> w((size_t)Cpad * e->K3pad, (half_t)0.0f);
         for (int co = 0; co < C; ++co)
             for (int ci = 0; ci < 16; ++ci)
                 for (int k = 0; k < W3; ++k)
                     w[(size_t)co * e->K3pad + k * 16 + ci] = (half_t)W[((size_t)co * 16 + ci) * W3 + k];
-        std::vector<float> b(B, B + C);
+        std::vector<float> b((size_t)Cpad, 0.0f);
+        for (int co = 0; co < C; ++co) b[co] = B[co];
         if (upload(e, &e->w3, w) || upload(e, &e->b3, b)) return MIBC_ERR_HIP;
         if (e->K3pad % 32 == 0 && C % 64 == 0)
             if (upload(e, &e->w3f, to_frag16(w, C, e->K3pad))) return MIBC_ERR_HIP;
@@ -439,7 +441,8 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     g.bias = e->b3;
     g.out = e->xa;
     g.M = N * T;
-    g.Ncols = e->C;
+    g.Ncols = (e->C + 127) / 128 * 128;
+    g.ncols_valid = (g.Ncols != e->C) ? e->C : 0;
     g.K = e->K3pad;
     g.a_div = T;
     g.a_outer = (long)e->Tpitch * 16;

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_xl_kernel(
 // ---------------------------------------------------------------------------------------------
 // xg: x_t fragments straight from global/L2 (any C); NB = 32*RT rows, NW waves
 // ---------------------------------------------------------------------------------------------
-template <int C, int RT, int NW>
+template <int C, int RT, int NW, int PF>
 __global__ __launch_bounds__(64 * NW, 1) void lstm_layer_xg_kernel(
         const half_t *__restrict__ Xin, half_t *__restrict__ Xout, const half_t *__restrict__ Wf,
         const float *__restrict__ biasn, int T, int N, int reverse) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_layer_xg_kernel(
     constexpr int KSX = C / 16;
     constexpr int LD = C + 8;
     constexpr int KTOT = HT * KS;
-    constexpr int PF = XG_PF;
+    static_assert((C / 16) % PF == 0, "ring depth must divide the k-steps of each part");
     __shared__ __attribute__((aligned(16))) half_t hbuf[2][NB * LD];
     __shared__ __attribute__((aligned(16))) float bias_s[4 * C];
 
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_x8_kernel(
 
 // batch granularity (rows per workgroup) for a given layer width
 extern "C" int mibc_lstm_rows_per_wg(int C) {
-    if (C == 128 || C == 256 || C == 384 || C == 512) return 64;
+    if (C == 96 || C == 128 || C == 256 || C == 384 || C == 512) return 64;
     if (C == 768 || C == 1024) return 32;
     return 0;
 }
@@ -507,8 +507,9 @@ extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, h
     static const int force_xg = getenv("MIBC_LSTM_XG") ? atoi(getenv("MIBC_LSTM_XG")) : 0;
     dim3 grid(N / nb);
 #define XL(CC, PF) hipLaunchKernelGGL((lstm_layer_xl_kernel<CC, PF>), grid, dim3(256), 0, s, Xin, Xout, Wf, biasn, T, N, reverse)
-#define XG(CC, RT, NW) hipLaunchKernelGGL((lstm_layer_xg_kernel<CC, RT, NW>), grid, dim3(64 * NW), 0, s, Xin, Xout, Wf, biasn, T, N, reverse)
+#define XG(CC, RT, NW) hipLaunchKernelGGL((lstm_layer_xg_kernel<CC, RT, NW, ((CC / 16) % 4 == 0 ? 4 : 2)>), grid, dim3(64 * NW), 0, s, Xin, Xout, Wf, biasn, T, N, reverse)
     switch (C) {
+        case 96: XG(96, 2, 3); return 0;   // fast models: 3 hidden tiles of 32 -> 3 waves
         case 128: if (force_xg) XG(128, 2, 4); else XL(128, 8); return 0;
         case 256: if (force_xg) XG(256, 2, 4); else XL(256, 8); return 0;
         case 384: if (force_xg) XG(384, 2, 4); else XL(384, 4); return 0;

@@ -179,6 +179,28 @@ def test_round_trip_properties_full_chunk_hac():
     eng.close()
 
 
+@pytest.mark.parametrize("which", ["fast_v40", "fast_v43"])
+def test_fast_model_shapes(which):
+    """fast models: C = 96 (3-wave LSTM kernel, masked 128-wide conv3 GEMM tile), S = 64;
+    v4.0.0 additionally has conv3 stride 5 + swish and an un-clamped head."""
+    cfg = getattr(config, which)()
+    ws = synth.make_weights(cfg, seed=71)
+    N, T_in = 64, 600
+    x16 = synth.make_signal(N, T_in, seed=72)
+    eng = capi.Engine(cfg, ws)
+    sc = eng.forward(x16)
+    s_o = O.lstm_crf_forward(cfg, ws, x16.astype(np.float32)[:, None, :])
+    ref = np.clip(sc.astype(np.float32), -5, 5) if cfg.clamp else sc.astype(np.float32)
+    mx, rms = _err(ref, s_o)
+    print(f"{which}: scores max-abs {mx:.4f} rms {rms:.5f}")
+    assert rms <= 0.012 and mx <= 0.2
+    got = eng.call(x16)
+    want = O.decode(ref, q_shift=cfg.qbias, q_scale=cfg.qscale, det=1)
+    for a, b in zip(got, want):
+        assert a[0] == b[0] and (a[2] == b[2]).all()
+    eng.close()
+
+
 def test_sup_v43_shape_end_to_end():
     """sup@v4.3-shaped model (C=1024, S=1024 states): decoder bit-exact on the GPU's own scores."""
     cfg = config.sup_v43()
@@ -233,7 +255,7 @@ def test_transformer_model_vs_oracle(name):
 
 
 def test_unsupported_shapes_fail_loudly():
-    cfg = _cfg(64, 3, 5)  # C=64 has no kernel yet
+    cfg = _cfg(64, 3, 5)  # C=64 has no kernel
     with pytest.raises(capi.MibcNotSupported):
         capi.Engine(cfg, synth.make_weights(cfg, seed=1))
 

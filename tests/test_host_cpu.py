@@ -115,6 +115,18 @@ def test_config_matches_reference_config_tests():
     assert (cfg.chunk_size, cfg.overlap) == (9996, 498)  # BatchParams.cpp:89-105 normalisation
 
 
+def test_fast_config_matches_reference_toml():
+    p = "/root/reference/tests/data/model_configs/dna_r10.4.1_e8.2_260bps_fast@v4.0.0"
+    if not os.path.isdir(p):
+        pytest.skip("reference tree not present")
+    a, b = config.load_model_config(p), config.fast_v40()
+    assert [(c.insize, c.size, c.winlen, c.stride, c.activation) for c in a.convs] == \
+        [(c.insize, c.size, c.winlen, c.stride, c.activation) for c in b.convs]
+    assert (a.lstm_size, a.lstm_layers, a.state_len, a.clamp, a.out_features) == \
+        (b.lstm_size, b.lstm_layers, b.state_len, b.clamp, b.out_features)
+    assert abs(a.scale - b.scale) < 1e-6 and abs(a.qscale - b.qscale) < 1e-6 and abs(a.qbias - b.qbias) < 1e-6
+
+
 def test_shard_range_partitions_exactly():
     for n in (0, 1, 7, 64, 1000):
         for world in (1, 2, 3, 8):
