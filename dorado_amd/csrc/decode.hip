@@ -114,18 +114,34 @@ __global__ __launch_bounds__(64) void beam_search_kernel(
     constexpr int BITS = (S == 64) ? 6 : (S == 256) ? 8 : (S == 1024) ? 10 : 12;
     constexpr int RPL = (K / 64 / 8) > 0 ? (K / 64 / 8) : 1;  // half8 loads per lane per score row
     constexpr int GPL = S / 64;      // floats per lane for one guide row
-    __shared__ __attribute__((aligned(16))) half_t sc_row[K];
-    __shared__ __attribute__((aligned(16))) float bg_row[S];
-    __shared__ float c_score[BS_CAND];
-    __shared__ uint32_t c_hash[BS_CAND];
-    __shared__ uint16_t c_state[BS_CAND];
-    __shared__ int tag[4 * BS_MAXW];
-    __shared__ float n_score[BS_MAXW];
-    __shared__ uint32_t n_hash[BS_MAXW];
-    __shared__ uint32_t n_meta[BS_MAXW];       // state | prev<<16 | stay<<24
-    __shared__ uint32_t tb_tile[64 * BS_MAXW];  // trace-back tile
-    __shared__ uint16_t tb_state[64];
-    __shared__ int8_t tb_move[64];
+    // one LDS arena: the search phase (score row, guide row, 5W candidates, new front) and the
+    // trace-back phase (32-row tile of the beam trace) never overlap in time
+    constexpr int A_SC = 0;                              // half_t sc_row[K]
+    constexpr int A_BG = A_SC + K * 2;                   // float bg_row[S]
+    constexpr int A_CS = A_BG + S * 4;                   // float c_score[BS_CAND]
+    constexpr int A_CH = A_CS + BS_CAND * 4;             // uint32 c_hash[BS_CAND]
+    constexpr int A_CT = A_CH + BS_CAND * 4;             // uint16 c_state[BS_CAND]
+    constexpr int A_TG = A_CT + BS_CAND * 2;             // int tag[4W]
+    constexpr int A_NS = A_TG + 4 * BS_MAXW * 4;         // float n_score[W]
+    constexpr int A_NH = A_NS + BS_MAXW * 4;             // uint32 n_hash[W]
+    constexpr int A_NM = A_NH + BS_MAXW * 4;             // uint32 n_meta[W]
+    constexpr int A_END = A_NM + BS_MAXW * 4;
+    constexpr int TB_ROWS = 32;
+    constexpr int A_TB_END = TB_ROWS * BS_MAXW * 4 + TB_ROWS * 2 + TB_ROWS;
+    constexpr int ARENA = (A_END > A_TB_END ? A_END : A_TB_END);
+    __shared__ __attribute__((aligned(16))) unsigned char arena[(ARENA + 15) / 16 * 16];
+    half_t *sc_row = (half_t *)(arena + A_SC);
+    float *bg_row = (float *)(arena + A_BG);
+    float *c_score = (float *)(arena + A_CS);
+    uint32_t *c_hash = (uint32_t *)(arena + A_CH);
+    uint16_t *c_state = (uint16_t *)(arena + A_CT);
+    int *tag = (int *)(arena + A_TG);
+    float *n_score = (float *)(arena + A_NS);
+    uint32_t *n_hash = (uint32_t *)(arena + A_NH);
+    uint32_t *n_meta = (uint32_t *)(arena + A_NM);
+    uint32_t *tb_tile = (uint32_t *)arena;                                   // [TB_ROWS][W]
+    uint16_t *tb_state = (uint16_t *)(arena + TB_ROWS * BS_MAXW * 4);        // [TB_ROWS]
+    int8_t *tb_move = (int8_t *)(arena + TB_ROWS * BS_MAXW * 4 + TB_ROWS * 2);  // [TB_ROWS]
 
     const int n = blockIdx.x;
     const int lane = threadIdx.x;
@@ -384,14 +400,24 @@ __global__ __launch_bounds__(64) void beam_search_kernel(
     __syncthreads();
     __threadfence_block();
 
-    // ---- trace back (beam_search.cpp:448-455), 64 blocks at a time through LDS ----
+    // ---- trace back (beam_search.cpp:448-455), TB_ROWS blocks at a time through LDS ----
     uint8_t ei = 0;
-    for (int hi_blk = T; hi_blk >= 1; hi_blk -= 64) {
-        const int lo_blk = (hi_blk - 63 > 1) ? (hi_blk - 63) : 1;  // rows lo..hi inclusive
+    for (int hi_blk = T; hi_blk >= 1; hi_blk -= TB_ROWS) {
+        const int lo_blk = (hi_blk - (TB_ROWS - 1) > 1) ? (hi_blk - (TB_ROWS - 1)) : 1;  // rows lo..hi
         const int rows = hi_blk - lo_blk + 1;
-        // lane r loads row lo_blk + r (W entries)
-        for (int i = lane; i < rows * W; i += 64) {
-            tb_tile[i] = tr[(size_t)lo_blk * W + i];
+        const int words = rows * W;
+        // bulk copy (all loads issued before the first LDS store)
+        constexpr int PER = TB_ROWS * BS_MAXW / 64;
+        uint32_t tmp[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = lane + 64 * q;
+            tmp[q] = (i < words) ? tr[(size_t)lo_blk * W + i] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = lane + 64 * q;
+            if (i < words) tb_tile[i] = tmp[q];
         }
         __syncthreads();
         if (lane == 0) {
@@ -430,9 +456,7 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
     float *alpha = (float *)smem;                 // [2][S]
     float *red = alpha + 2 * S;                   // [2 * 32] reduction scratch
     float *prob = red + 64;                       // [T]
-    float *bp = prob + T;                         // [T]
-    float *tp = bp + T;                           // [T]
-    uint16_t *pst = (uint16_t *)(tp + T);         // [T]
+    uint16_t *pst = (uint16_t *)(prob + T);       // [T]
     int8_t *pmv = (int8_t *)(pst + T);            // [T]
     __shared__ int s_len;
 
@@ -448,8 +472,6 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
     for (int i = s; i < T; i += S) {
         pst[i] = path_state[(size_t)n * T + i];
         pmv[i] = moves[(size_t)n * T + i];
-        bp[i] = 0.0f;
-        tp[i] = 0.0f;
     }
     // log Z = LSE_s(bwd[0][s])  (alpha[0] = 0): shift for the posterior exponent
     float logZ;
@@ -536,28 +558,11 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
         prob[i] = powf(pr, 0.4f);
     }
     __syncthreads();
-    // ---- sequence / per-base error accumulation (beam_search.cpp:54-102), sequential ----
-    if (s == 0) {
-        int pos = 0;
-        for (int blk = 0; blk < T; ++blk) {
-            const int base = pst[blk] & 3;
-            const int mv = pmv[blk];
-            const float pr = prob[blk];
-            const float wrong = (1.0f - pr) / 3.0f;
-            const int ppos = pos + ((blk == 0) ? 0 : mv - 1);
-            bp[ppos] += pr;
-            float tot = tp[ppos];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) tot += (k == base) ? pr : wrong;
-            tp[ppos] = tot;
-            pos += (blk == 0) ? 1 : mv;
-        }
-        s_len = pos;
-    }
-    __syncthreads();
-    // bases: position of block blk = (number of moves in [0, blk]) - 1 -> parallel prefix sum
+    // ---- sequence + qstring (beam_search.cpp:54-102).  The blocks that contribute to one base are
+    //      the contiguous run [its move block, next move block): the thread that owns the move block
+    //      walks its run (same summation order as the reference's sequential accumulation) and
+    //      emits base and quality at position = (number of moves up to and including it) - 1. ----
     {
-        // inclusive prefix sum of moves over T with S threads: chunked scan
         const int per = (T + S - 1) / S;
         const int b0 = s * per;
         int local = 0;
@@ -565,8 +570,7 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
             const int blk = b0 + i;
             if (blk < T) local += (blk == 0) ? 1 : pmv[blk];
         }
-        // exclusive scan of `local` across threads (Hillis-Steele in LDS, reuse alpha as int)
-        int *scan = (int *)alpha;
+        int *scan = (int *)alpha;  // alpha is dead after the scan; S ints
         scan[s] = local;
         __syncthreads();
         for (int o = 1; o < S; o <<= 1) {
@@ -575,28 +579,41 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
             scan[s] += add;
             __syncthreads();
         }
-        int pos = scan[s] - local;  // exclusive
+        int pos = scan[s] - local;  // exclusive prefix: bases before this thread's blocks
+        if (s == S - 1) s_len = scan[s];
         const char alphabet[4] = {'A', 'C', 'G', 'T'};
         for (int i = 0; i < per; ++i) {
             const int blk = b0 + i;
-            if (blk < T) {
-                const int mv = (blk == 0) ? 1 : pmv[blk];
-                if (mv) {
-                    seq_out[(size_t)n * T + pos] = (int8_t)alphabet[pst[blk] & 3];
-                    pos += 1;
-                }
-            }
-        }
-    }
-    const int len = s_len;
-    for (int i = s; i < T; i += S) {
-        if (i < len) {
-            float e = 1.0f - (bp[i] / tp[i]);
+            if (blk >= T) break;
+            const int mv = (blk == 0) ? 1 : pmv[blk];
+            if (!mv) continue;
+            const int base = pst[blk] & 3;
+            float bsum = 0.0f, tsum = 0.0f;
+            int r = blk;
+            do {  // run of this base: its move block and the stays that follow
+                const float pr = prob[r];
+                const float wrong = (1.0f - pr) / 3.0f;
+                const int rb = pst[r] & 3;
+                bsum += pr;  // qual_data[r][rb] with rb == called base of block r
+                float tot = tsum;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tot += (k == rb) ? pr : wrong;
+                tsum = tot;
+                ++r;
+            } while (r < T && pmv[r] == 0);
+            float e = 1.0f - (bsum / tsum);
             e = -10.0f * log10f(e);
             float q = e * q_scale + q_shift;
             q = fminf(fmaxf(q, 1.0f), 50.0f);
-            qstr_out[(size_t)n * T + i] = (int8_t)(33.5f + q);
-        } else {
+            seq_out[(size_t)n * T + pos] = (int8_t)alphabet[base];
+            qstr_out[(size_t)n * T + pos] = (int8_t)(33.5f + q);
+            pos += 1;
+        }
+    }
+    __syncthreads();
+    const int len = s_len;
+    for (int i = s; i < T; i += S) {
+        if (i >= len) {
             seq_out[(size_t)n * T + i] = 0;
             qstr_out[(size_t)n * T + i] = 0;
         }
@@ -633,7 +650,7 @@ extern "C" int mibc_launch_decode(hipStream_t st, const half_t *scores, int N, i
                                trace, path_state, moves, T, W, log_cut, stay, clampv);
             break;
     }
-    const size_t smem3 = (size_t)(2 * S + 64) * 4 + (size_t)3 * T * 4 + (size_t)T * 2 + (size_t)T + 16;
+    const size_t smem3 = (size_t)(2 * S + 64) * 4 + (size_t)T * 4 + (size_t)T * 2 + (size_t)T + 16;
     hipLaunchKernelGGL(posts_qual_kernel, dim3(N), dim3(S), smem3, st, scores, bwd, path_state, moves,
                        seq, qstr, prob_tap, T, S, stay, clampv, q_shift, q_scale);
     return 0;

@@ -18,7 +18,7 @@ ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--model", default="hac")
 ap.add_argument("--tin", type=int, default=0)
 a = ap.parse_args()
-cfg = {"hac": config.hac_v43, "sup": config.sup_v43, "sup5": config.sup_v50}.get(a.model, lambda: config.tiny(128, 4))()
+cfg = {"hac": config.hac_v43, "sup": config.sup_v43, "sup5": config.sup_v50, "fast": config.fast_v43}.get(a.model, lambda: config.tiny(128, 4))()
 t_in = a.tin or cfg.chunk_size
 eng = capi.Engine(cfg, synth.make_weights(cfg, seed=42))
 T = eng.output_steps(t_in)
