@@ -5,8 +5,8 @@
 // sequence of IEEE operations rather than whatever libm/ocml happens to do.  These are plain
 // Cephes-style polynomials evaluated ONLY with fmaf/mul/add (compile this TU with
 // -ffp-contract=off); the CPU oracle restates the same operation sequence independently.
-// Accuracy ~1 ulp-class (max rel err < 4e-7), the same class as the glibc/Sleef routines the
-// reference's CPU path uses (decode/CPUDecoder.cpp:34, decode/beam_search.cpp:42-45).
+// Accuracy of a log-sum-exp built from them: ~2e-7 relative, the same class as the glibc/Sleef
+// routines the reference's CPU path uses (decode/CPUDecoder.cpp:34, decode/beam_search.cpp:42-45).
 #pragma once
 #include <stdint.h>
 
@@ -19,43 +19,32 @@
 DM_FN float dm_bits_to_f(uint32_t u) { return __builtin_bit_cast(float, u); }
 DM_FN uint32_t dm_f_to_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 
-// exp(x), intended for x <= 0; 0 below -103, clamps above 88.
+// exp(x) for x <= 0 (every use subtracts the running maximum first).  Arguments below -86 are
+// clamped: the result (< 5e-38) is absorbed by any sum that also holds the exp(0) = 1 term.
+// One-constant range reduction: the error it leaves, |n| * 2e-8 relative, only grows where the
+// value itself (2^n) has stopped mattering to the sum.
 DM_FN float dm_expf(float x) {
-    if (x < -103.0f) {
-        return 0.0f;
-    }
-    if (x > 88.0f) {
-        x = 88.0f;
-    }
+    x = x < -86.0f ? -86.0f : x;
     const float n = __builtin_rintf(x * 1.44269504088896341f);
-    float r = __builtin_fmaf(n, -0.693145751953125f, x);
-    r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
+    const float r = __builtin_fmaf(n, -0.693147182464599609375f, x);
     float p = 1.9875691500e-4f;
     p = __builtin_fmaf(p, r, 1.3981999507e-3f);
     p = __builtin_fmaf(p, r, 8.3334519073e-3f);
     p = __builtin_fmaf(p, r, 4.1665795894e-2f);
     p = __builtin_fmaf(p, r, 1.6666665459e-1f);
     p = __builtin_fmaf(p, r, 5.0000001201e-1f);
-    const float r2 = r * r;
-    p = __builtin_fmaf(p, r2, r);
-    p = p + 1.0f;
-    const int ni = (int)n;
-    const int n1 = ni / 2, n2 = ni - n1;
-    p = p * dm_bits_to_f((uint32_t)(n1 + 127) << 23);
-    p = p * dm_bits_to_f((uint32_t)(n2 + 127) << 23);
-    return p;
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    // p in [0.70, 1.42], n in [-124, 0]: scaling by 2^n is an exponent-field add
+    return dm_bits_to_f(dm_f_to_bits(p) + ((uint32_t)(int)n << 23));
 }
 
 // log(x) for finite normal x > 0.
 DM_FN float dm_logf(float x) {
-    uint32_t ix = dm_f_to_bits(x);
-    int e = (int)(ix >> 23) - 127;
-    ix = (ix & 0x007fffffu) | 0x3f800000u;
-    float m = dm_bits_to_f(ix);
-    if (m > 1.41421356237f) {
-        m = m * 0.5f;
-        e += 1;
-    }
+    // mantissa to [sqrt(1/2), sqrt(2)) by re-biasing the exponent field around sqrt(1/2)
+    const uint32_t ix = dm_f_to_bits(x) + (0x3f800000u - 0x3f3504f3u);
+    const int e = (int)(ix >> 23) - 127;
+    const float m = dm_bits_to_f((ix & 0x007fffffu) + 0x3f3504f3u);
     const float f = m - 1.0f;
     const float z = f * f;
     float p = 7.0376836292e-2f;
@@ -68,12 +57,9 @@ DM_FN float dm_logf(float x) {
     p = __builtin_fmaf(p, f, -2.4999993993e-1f);
     p = __builtin_fmaf(p, f, 3.3333331174e-1f);
     float y = (f * z) * p;
-    const float fe = (float)e;
-    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
     y = __builtin_fmaf(-0.5f, z, y);
-    float r = f + y;
-    r = __builtin_fmaf(fe, 0.693359375f, r);
-    return r;
+    const float r = f + y;
+    return __builtin_fmaf((float)e, 0.693147182464599609375f, r);
 }
 
 // log-sum-exp of {stay, 4 steps}: max, sum of exp in argument order, log

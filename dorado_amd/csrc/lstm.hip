@@ -476,6 +476,156 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_x8_kernel(
     }
 }
 
+// Ablation copy of x8 for timing experiments (MIBC_LSTM_DBG=<bits>; results are wrong when a bit is
+// set): bit0 = no gate math, bit1 = no weight reloads, bit2 = no activation fragment reads;
+// 8 = unmodified.  DESIGN.md "what bounds the LSTM kernel" quotes these runs.
+template <int C, int PF, int DBG>
+__global__ __launch_bounds__(512, 2) void lstm_layer_x8dbg_kernel(
+        const half_t *__restrict__ Xin,   // [T][N][C]
+        half_t *__restrict__ Xout,        // [T][N][C]
+        const half_t *__restrict__ Wf16,  // [C/16][2C/32][4][64][8]
+        const float *__restrict__ biasn,  // [4C]: [(hidden/32)][4][32]  (b_ih + b_hh)
+        int T, int N, int reverse) {
+    constexpr int NB = 64;
+    constexpr int NT = 512;
+    constexpr int HT = C / 16 / 8;   // 16-unit hidden tiles per wave
+    constexpr int KS = 2 * C / 32;   // k-steps of 32 over [x ; h]
+    constexpr int KSX = C / 32;
+    constexpr int LD = C + 16;       // +32 B: conflict-free ds_read_b128 for the 16x32 fragment pattern
+    constexpr int XPF = C / 64;      // 16-byte chunks per thread for one x_t block
+    constexpr int KTOT = HT * KS;
+    constexpr int UN = (PF & 1) ? 2 * PF : PF;  // unroll: ring slot u % PF, fragment parity u & 1
+    static_assert(KS % UN == 0, "k-steps must divide the unroll");
+    __shared__ __attribute__((aligned(16))) half_t hbuf[2][NB * LD];
+    __shared__ __attribute__((aligned(16))) half_t xbuf[NB * LD];
+    __shared__ __attribute__((aligned(16))) float bias_s[4 * C];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int n0 = blockIdx.x * NB;
+
+    for (int i = tid; i < NB * LD / 8; i += NT) ((half8_t *)hbuf[0])[i] = (half8_t)(0);
+    for (int i = tid; i < 4 * C; i += NT) bias_s[i] = biasn[i];
+
+    float4v cst[HT][4];
+#pragma unroll
+    for (int a = 0; a < HT; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cst[a][b] = (float4v)(0.0f);
+
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(Wf16 + (size_t)wave * HT * KS * 4 * 64 * 8), 0, HT * KS * 4 * 64 * 16, 0x00020000);
+    const int wvoff = lane * 16;
+    half8_t wr[PF][4];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wr[u][g] = wload(wrs, wvoff, (u * 4 + g) * 1024);
+    int kpre = PF;
+
+    {
+        const int t_first = reverse ? (T - 1) : 0;
+        const half_t *xg = Xin + ((size_t)t_first * N + n0) * C;
+#pragma unroll
+        for (int p = 0; p < XPF; ++p) {
+            const int c = tid + NT * p;
+            const int row = c / (C / 8), col8 = c % (C / 8);
+            *(half8_t *)(xbuf + row * LD + col8 * 8) = *(const half8_t *)(xg + (size_t)c * 8);
+        }
+    }
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int t = reverse ? (T - 1 - step) : step;
+        const int tn = (step + 1 < T) ? (reverse ? (t - 1) : (t + 1)) : t;
+        const half_t *hprev = hbuf[step & 1];
+        half_t *hnext = hbuf[(step + 1) & 1];
+
+        half8_t xpf[XPF];
+        {
+            const half_t *xg = Xin + ((size_t)tn * N + n0) * C;
+#pragma unroll
+            for (int p = 0; p < XPF; ++p) xpf[p] = *(const half8_t *)(xg + (size_t)(tid + NT * p) * 8);
+        }
+
+#pragma unroll
+        for (int jj = 0; jj < HT; ++jj) {
+            const int j = wave * HT + jj;  // 16-unit hidden tile
+            float4v acc[4][4];             // [gate][row tile of 16]
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // hidden = 16 j + 4 lq + r ; bias_s order [(hidden / 32)][g][hidden % 32]
+                const float4v bv = *(const float4v *)(bias_s + ((j >> 1) * 4 + g) * 32 + (j & 1) * 16 + 4 * lq);
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) acc[g][rt] = bv;
+            }
+            const half_t *xb = xbuf + l15 * LD + 8 * lq;
+            const half_t *hb = hprev + l15 * LD + 8 * lq;
+            half8_t bq[2][4];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) bq[0][rt] = *(const half8_t *)(xb + rt * 16 * LD);
+#pragma nounroll
+            for (int ks0 = 0; ks0 < KS; ks0 += UN) {
+#pragma unroll
+                for (int uu = 0; uu < UN; ++uu) {
+                    const int u = uu % PF;
+                    const int kn = (ks0 + uu + 1 < KS) ? (ks0 + uu + 1) : (KS - 1);
+                    const half_t *bn = (kn < KSX) ? (xb + kn * 32) : (hb + (kn - KSX) * 32);
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt)
+                        if (!(DBG & 4)) bq[(uu + 1) & 1][rt] = *(const half8_t *)(bn + rt * 16 * LD);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int rt = 0; rt < 4; ++rt)
+                            acc[g][rt] = mfma16x16x32(wr[u][g], bq[uu & 1][rt], acc[g][rt]);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (!(DBG & 2)) wr[u][g] = wload(wrs, wvoff, (kpre * 4 + g) * 1024);
+                    kpre = (kpre + 1 == KTOT) ? 0 : kpre + 1;
+                }
+            }
+            // gates: D row = hidden 4 lq + r, D col = batch row l15 of row tile rt
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                half4_t hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (DBG & 1) {
+                        hv[r] = (half_t)(1e-3f * (acc[0][rt][r] + acc[1][rt][r] + acc[2][rt][r] + acc[3][rt][r]));
+                    } else {
+                        const float ig = fast_sigmoid(acc[0][rt][r]);
+                        const float fg = fast_sigmoid(acc[1][rt][r]);
+                        const float gg = fast_tanh(acc[2][rt][r]);
+                        const float og = fast_sigmoid(acc[3][rt][r]);
+                        const float c = fmaf(fg, cst[jj][rt][r], ig * gg);
+                        cst[jj][rt][r] = c;
+                        hv[r] = (half_t)(og * fast_tanh(c));
+                    }
+                }
+                *(half4_t *)(hnext + (rt * 16 + l15) * LD + j * 16 + 4 * lq) = hv;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < XPF; ++p) {
+            const int c = tid + NT * p;
+            const int row = c / (C / 8), col8 = c % (C / 8);
+            *(half8_t *)(xbuf + row * LD + col8 * 8) = xpf[p];
+        }
+        half_t *orow = Xout + ((size_t)t * N + n0) * C;
+#pragma unroll
+        for (int p = 0; p < XPF; ++p) {
+            const int c = tid + NT * p;
+            const int row = c / (C / 8), col8 = c % (C / 8);
+            *(half8_t *)(orow + (size_t)c * 8) = *(const half8_t *)(hnext + row * LD + col8 * 8);
+        }
+        __syncthreads();
+    }
+}
+
 // batch granularity (rows per workgroup) for a given layer width
 extern "C" int mibc_lstm_rows_per_wg(int C) {
     if (C == 96 || C == 128 || C == 256 || C == 384 || C == 512) return 64;
@@ -489,6 +639,13 @@ extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, h
     const int nb = mibc_lstm_rows_per_wg(C);
     if (nb == 0 || N % nb != 0) {
         return 1;
+    }
+    static const int dbg8 = getenv("MIBC_LSTM_DBG") ? atoi(getenv("MIBC_LSTM_DBG")) : 0;
+    if (dbg8 && C == 384 && Wf16 != nullptr) {
+        dim3 gd(N / nb);
+#define X8D(D) case D: hipLaunchKernelGGL((lstm_layer_x8dbg_kernel<384, 4, D>), gd, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse); return 0;
+        switch (dbg8) { X8D(1) X8D(2) X8D(4) X8D(7) X8D(8) default: break; }
+#undef X8D
     }
     static const int use_x8 = getenv("MIBC_LSTM_X8") ? atoi(getenv("MIBC_LSTM_X8")) : 1;
     if (use_x8 && Wf16 != nullptr && (C == 128 || C == 256 || C == 384)) {

@@ -37,157 +37,199 @@ struct WsArgs {
     int N, Ns, n0, T;    // full batch, sub-batch, first chunk of the sub-batch, steps
     // conv3:
     int Tpitch, stride;  // a2p rows per chunk, conv stride
+    int dbg;             // timing ablations (MIBC_WS_DBG); 0 in production
 };
 
-#define WS_ROWS 128
 
 // MODE 0: head (A = X[T][N][C], K = C).  MODE 1: conv3 (A = a2p, K = 32*KT >= W*16).
-template <int KT, int MODE>
-__global__ __launch_bounds__(512, 2) void wsgemm_kernel(WsArgs p) {
+// CT = 16-column tiles per wave per pass (8 waves x CT x 16 columns per pass).
+//
+// Persistent: the grid is one workgroup per CU (8 waves x 256 registers); each loops over tiles
+// tile = blockIdx.x, += gridDim.x.  While tile i is being multiplied out of LDS, tile i+1 is already
+// in flight from HBM into registers (pre[]), so the HBM latency of the activation read hides behind
+// the MFMAs instead of being paid once per workgroup; the weight fragments of the next pass's first
+// k-step are requested before the epilogue for the same reason.
+template <int KT, int MODE, int CT, int RT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void wsgemm_kernel(WsArgs p) {
+    constexpr int NT = NW * 64;
+    constexpr int WS_ROWS = RT * 16;
     constexpr int K = KT * 32;
     constexpr int LD = K + 16;                      // MODE 0 row stride (halfs): conflict-free 16x32 reads
     constexpr int SPAN_BLK = 96;                    // MODE 1: halfs per 192-byte block
+    constexpr int WCOLS = CT * 16;
+    constexpr int CH = (MODE == 0) ? ((WS_ROWS * (K / 8) + NT - 1) / NT) : (2048 / NT);   // 16-byte chunks per thread per tile
+    static_assert((KT & 1) == 0, "the weight double buffer assumes an even number of k-steps");
     extern __shared__ __attribute__((aligned(16))) half_t lds_all[];
-    half_t *stage = lds_all;                 // 8 waves x 16 x 72 halfs = 18 KiB
-    half_t *lds = lds_all + 8 * 16 * 72;
+    half_t *stage = lds_all;                 // NW waves x 16 x 72 halfs
+    half_t *lds = lds_all + NW * 16 * 72;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
 
-    int rows_valid = WS_ROWS;
-    long out_base;     // MODE 0: n' of row 0 ; MODE 1: t of row 0
-    int t_fix = 0, n_fix = 0;
-    if (MODE == 0) {
-        const int tiles_per_t = (p.Ns + WS_ROWS - 1) / WS_ROWS;
-        t_fix = blockIdx.x / tiles_per_t;
-        const int nloc = (blockIdx.x % tiles_per_t) * WS_ROWS;
-        rows_valid = min(WS_ROWS, p.Ns - nloc);
-        out_base = nloc;
-        const half_t *src = p.A + ((size_t)t_fix * p.N + p.n0 + nloc) * K;
-        // all global loads first, then the LDS stores (one memory latency, not one per iteration)
-        constexpr int CH = WS_ROWS * (K / 8) / 512;
-        half8_t stg_r[CH];
+    const int tiles_per_grp = (MODE == 0) ? ((p.Ns + WS_ROWS - 1) / WS_ROWS) : ((p.T + WS_ROWS - 1) / WS_ROWS);
+    const int ntiles = (MODE == 0) ? (p.T * tiles_per_grp) : (p.N * tiles_per_grp);
+    // MODE 1: span of a2p rows [stride*t0, stride*t0 + 127*stride + K/16 + 1): 16 halfs per a2p row
+    const int span_halfs = (WS_ROWS - 1) * p.stride * 16 + K + 16;
+    const int nch = (span_halfs + 7) / 8;
+
+    half8_t pre[CH];
+    auto tile_fetch = [&](int tile) {
+        const int grp = tile / tiles_per_grp;
+        const int r0 = (tile % tiles_per_grp) * WS_ROWS;
+        if (MODE == 0) {
+            const int rows_valid = min(WS_ROWS, p.Ns - r0);
+            const half_t *src = p.A + ((size_t)grp * p.N + p.n0 + r0) * K;   // 128 consecutive rows
+#pragma unroll
+            for (int it = 0; it < CH; ++it) {
+                const int c = tid + NT * it;
+                pre[it] = (half8_t)(0);
+                if (c < WS_ROWS * (K / 8) && c / (K / 8) < rows_valid) pre[it] = *(const half8_t *)(src + (size_t)c * 8);
+            }
+        } else {
+            const half_t *src = p.A + ((size_t)grp * p.Tpitch + (size_t)p.stride * r0) * 16;
+            const long avail = ((long)p.Tpitch - (long)p.stride * r0) * 16;  // stay inside this chunk + slack
+#pragma unroll
+            for (int it = 0; it < CH; ++it) {
+                const int c = tid + NT * it;
+                pre[it] = (half8_t)(0);
+                if (c < nch && (long)c * 8 + 8 <= avail) pre[it] = *(const half8_t *)(src + (size_t)c * 8);
+            }
+        }
+    };
+    auto tile_commit = [&]() {
 #pragma unroll
         for (int it = 0; it < CH; ++it) {
-            const int c = tid + 512 * it;
-            const int row = c / (K / 8), col8 = c % (K / 8);
-            stg_r[it] = (half8_t)(0);
-            if (row < rows_valid) stg_r[it] = *(const half8_t *)(src + (size_t)row * K + col8 * 8);
+            const int c = tid + NT * it;
+            if (MODE == 0) {
+                if (c < WS_ROWS * (K / 8)) *(half8_t *)(lds + (c / (K / 8)) * LD + (c % (K / 8)) * 8) = pre[it];
+            } else {
+                const int h = c * 8;
+                if (c < nch) *(half8_t *)(lds + (h / SPAN_BLK) * (SPAN_BLK + 16) + (h % SPAN_BLK)) = pre[it];
+            }
         }
-#pragma unroll
-        for (int it = 0; it < CH; ++it) {
-            const int c = tid + 512 * it;
-            *(half8_t *)(lds + (c / (K / 8)) * LD + (c % (K / 8)) * 8) = stg_r[it];
-        }
-    } else {
-        const int tiles_per_chunk = (p.T + WS_ROWS - 1) / WS_ROWS;
-        n_fix = blockIdx.x / tiles_per_chunk;
-        const int t0 = (blockIdx.x % tiles_per_chunk) * WS_ROWS;
-        rows_valid = min(WS_ROWS, p.T - t0);
-        out_base = t0;
-        // span of a2p rows [stride*t0, stride*t0 + 127*stride + K/16 + 1): 16 halfs per a2p row
-        const half_t *src = p.A + ((size_t)n_fix * p.Tpitch + (size_t)p.stride * t0) * 16;
-        const int span_halfs = (WS_ROWS - 1) * p.stride * 16 + K + 16;
-        const long avail = ((long)p.Tpitch - (long)p.stride * t0) * 16;  // stay inside this chunk + slack
-        constexpr int CH1 = 4;  // span <= 4 * 512 * 8 halfs
-        half8_t stg_r[CH1];
-        const int nch = (span_halfs + 7) / 8;
-#pragma unroll
-        for (int it = 0; it < CH1; ++it) {
-            const int c = tid + 512 * it;
-            stg_r[it] = (half8_t)(0);
-            if (c < nch && (long)c * 8 + 8 <= avail) stg_r[it] = *(const half8_t *)(src + (size_t)c * 8);
-        }
-#pragma unroll
-        for (int it = 0; it < CH1; ++it) {
-            const int c = tid + 512 * it;
-            const int h = c * 8;
-            if (c < nch) *(half8_t *)(lds + (h / SPAN_BLK) * (SPAN_BLK + 16) + (h % SPAN_BLK)) = stg_r[it];
-        }
-    }
-    __syncthreads();
+    };
 
     const int wvoff = lane * 16;
-    const int passes = p.cols / 512 + ((p.cols % 512) ? 1 : 0);
-    for (int pass = 0; pass < passes; ++pass) {
-        const int col0 = pass * 512 + wave * 64;   // this wave's 64 columns
-        if (col0 >= p.cols) break;
-        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(p.Wf + (size_t)(col0 / 16) * KT * 512), 0, 4 * KT * 1024, 0x00020000);
-        float4w acc[4][8];
+    const int passes = (p.cols + NW * WCOLS - 1) / (NW * WCOLS);
+    auto wrsrc = [&](int pass) {
+        const int col0 = pass * NW * WCOLS + wave * WCOLS;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(p.Wf + (size_t)(col0 / 16) * KT * 512), 0,
+                                                 CT * KT * 1024, 0x00020000);
+    };
+    half8_t wq[2][CT];
+    if (wave * WCOLS < p.cols) {
+        const __amdgpu_buffer_rsrc_t w0 = wrsrc(0);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            float4w bv = (float4w)(0.0f);
-            if (p.bias != nullptr) bv = *(const float4w *)(p.bias + col0 + ct * 16 + 4 * lq);
+        for (int ct = 0; ct < CT; ++ct) wq[0][ct] = wsload(w0, wvoff, (ct * KT + 0) * 1024);
+    }
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) tile_fetch(tile);
+    tile_commit();
+    __syncthreads();
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int grp = tile / tiles_per_grp;               // MODE 0: t ; MODE 1: chunk n
+        const int out_base = (tile % tiles_per_grp) * WS_ROWS;   // MODE 0: n' of row 0 ; MODE 1: t of row 0
+        const int rows_valid = min(WS_ROWS, ((MODE == 0) ? p.Ns : p.T) - out_base);
+        const int tnext = tile + gridDim.x;
+        if (tnext < ntiles) tile_fetch(tnext);
+
+        const int dbg = p.dbg;
+        const int act = (dbg & 1) ? -1 : p.act;
+        for (int pass = 0; pass < passes; ++pass) {
+            const int col0 = pass * NW * WCOLS + wave * WCOLS;   // this wave's columns
+            if (col0 >= p.cols) break;
+            const __amdgpu_buffer_rsrc_t wrs = wrsrc(pass);
+            float4w acc[CT][RT];
 #pragma unroll
-            for (int rt = 0; rt < 8; ++rt) acc[ct][rt] = bv;
-        }
-        half8_t wq[2][4];
+            for (int ct = 0; ct < CT; ++ct) {
+                float4w bv = (float4w)(0.0f);
+                if (p.bias != nullptr) bv = *(const float4w *)(p.bias + col0 + ct * 16 + 4 * lq);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) wq[0][ct] = wsload(wrs, wvoff, (ct * KT + 0) * 1024);
-#pragma unroll
-        for (int ks = 0; ks < KT; ++ks) {
-            if (ks + 1 < KT) {
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) wq[(ks + 1) & 1][ct] = wsload(wrs, wvoff, (ct * KT + ks + 1) * 1024);
+                for (int rt = 0; rt < RT; ++rt) acc[ct][rt] = bv;
             }
+#pragma nounroll
+            for (int ks0 = 0; ks0 < ((dbg & 4) ? 0 : KT); ks0 += 2) {
 #pragma unroll
-            for (int rt = 0; rt < 8; ++rt) {
-                half8_t b;
-                if (MODE == 0) {
-                    b = *(const half8_t *)(lds + (rt * 16 + l15) * LD + ks * 32 + 8 * lq);
-                } else {
-                    // row t = rt*16 + l15 starts at 96*t halfs of the span = block t (+ pad 8 halfs/block)
-                    const int kb = ks * 32;                          // halfs into the row
-                    const int blk = (rt * 16 + l15) * (p.stride * 16 / SPAN_BLK) + kb / SPAN_BLK;
-                    b = *(const half8_t *)(lds + blk * (SPAN_BLK + 16) + (kb % SPAN_BLK) + 8 * lq);
-                }
+                for (int uu = 0; uu < 2; ++uu) {
+                    const int ks = ks0 + uu;
+                    const int kn = (ks + 1 < KT) ? ks + 1 : KT - 1;   // last one: harmless re-load
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct][rt] = mfma16(wq[ks & 1][ct], b, acc[ct][rt]);
-            }
-        }
-        // epilogue: lane holds out[row = rt*16 + l15][col0 + ct*16 + 4*lq .. +4].  Each wave
-        // transposes 16 rows x 64 columns through its private 2 KiB LDS patch so that it leaves as
-        // whole 128-byte row segments (8 rows per store instruction) instead of 32-byte pieces.
-        half_t *stg = stage + wave * (16 * 72);   // [16 rows][64 + 8 pad]
+                    for (int ct = 0; ct < CT; ++ct)
+                        wq[(uu + 1) & 1][ct] = wsload(wrs, wvoff, (ct * KT + kn) * 1024);
 #pragma unroll
-        for (int rt = 0; rt < 8; ++rt) {
+                    for (int rt = 0; rt < RT; ++rt) {
+                        half8_t b;
+                        if (MODE == 0) {
+                            b = *(const half8_t *)(lds + (rt * 16 + l15) * LD + ks * 32 + 8 * lq);
+                        } else {
+                            // row t = rt*16 + l15 starts at 96*t halfs of the span = block t (+ pad 8 halfs/block)
+                            const int kb = ks * 32;                          // halfs into the row
+                            const int blk = (rt * 16 + l15) * (p.stride * 16 / SPAN_BLK) + kb / SPAN_BLK;
+                            b = *(const half8_t *)(lds + blk * (SPAN_BLK + 16) + (kb % SPAN_BLK) + 8 * lq);
+                        }
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                half4_t h;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[ct][rt][r];
-                    if (p.act == 3) {
-                        v = 5.0f * fast_tanh(v);
-                    } else if (p.act >= 0) {
-                        v = act_apply(v, p.act);
+                        for (int ct = 0; ct < CT; ++ct) acc[ct][rt] = mfma16(wq[uu & 1][ct], b, acc[ct][rt]);
                     }
-                    h[r] = (half_t)v;
                 }
-                *(half4_t *)(stg + l15 * 72 + ct * 16 + 4 * lq) = h;
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
-            __builtin_amdgcn_wave_barrier();
+            {   // first weight fragments of the pass that runs next (this tile's or the next tile's)
+                const int pn = (pass + 1 < passes && (pass + 1) * NW * WCOLS + wave * WCOLS < p.cols) ? pass + 1 : 0;
+                const __amdgpu_buffer_rsrc_t wn = wrsrc(pn);
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int r16 = half * 8 + (lane >> 3), seg = lane & 7;   // 8 rows x 8 x 16 B
-                const int row = rt * 16 + r16;
-                const half8_t v = *(const half8_t *)(stg + r16 * 72 + seg * 8);
-                if (row < rows_valid) {
-                    half_t *orow;
-                    if (MODE == 0) {
-                        orow = p.out + ((size_t)(out_base + row) * p.T + t_fix) * p.cols;
-                    } else {
-                        orow = p.out + ((size_t)(out_base + row) * p.N + n_fix) * p.cols;
-                    }
-                    *(half8_t *)(orow + col0 + seg * 8) = v;
-                }
+                for (int ct = 0; ct < CT; ++ct) wq[0][ct] = wsload(wn, wvoff, (ct * KT + 0) * 1024);
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
+            // epilogue: lane holds out[row = rt*16 + l15][col0 + ct*16 + 4*lq .. +4].  Each wave
+            // transposes 16 rows x WCOLS columns through its private LDS patch so that it leaves as
+            // whole row segments (16 B per lane) instead of 8-byte pieces.  LDS operations of one
+            // wave execute in order, so the only wait needed is write -> read.
+            half_t *stg = stage + wave * (16 * 72);   // [16 rows][64 + 8 pad]
+            constexpr int SEGS = WCOLS / 8;            // 16-byte segments per row
+            constexpr int RPI = 64 / SEGS;             // rows per store instruction
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    half4_t h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[ct][rt][r];
+                        if (act == 3) {
+                            v = 5.0f * fast_tanh(v);
+                        } else if (act >= 0) {
+                            v = act_apply(v, act);
+                        }
+                        h[r] = (half_t)v;
+                    }
+                    *(half4_t *)(stg + l15 * 72 + ct * 16 + 4 * lq) = h;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r16_0 = 0; r16_0 < 16; r16_0 += RPI) {
+                    const int r16 = r16_0 + lane / SEGS, seg = lane % SEGS;
+                    const int row = rt * 16 + r16;
+                    if (lane < RPI * SEGS && r16 < 16) {
+                        const half8_t v = *(const half8_t *)(stg + r16 * 72 + seg * 8);
+                        if (row < rows_valid && !(dbg & 2)) {
+                            half_t *orow;
+                            if (MODE == 0) {
+                                orow = p.out + ((size_t)(out_base + row) * p.T + grp) * p.cols;
+                            } else {
+                                orow = p.out + ((size_t)(out_base + row) * p.N + grp) * p.cols;
+                            }
+                            *(half8_t *)(orow + col0 + seg * 8) = v;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
+        __syncthreads();   // every wave is done with this tile's activations
+        if (tnext < ntiles) tile_commit();
+        __syncthreads();
     }
 }
 
@@ -196,31 +238,65 @@ __global__ __launch_bounds__(512, 2) void wsgemm_kernel(WsArgs p) {
 extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mode) {
     if (a->cols % 64 != 0 || K % 32 != 0) return 1;
     const int KT = K / 32;
-    size_t smem;
-    int grid;
+    // NW = waves per workgroup: 8 (one workgroup per CU) or 4 (two independent workgroups per CU,
+    // so that one's MFMA k-loop runs beside the other's VALU epilogue)
+    static const int ws_dbg = getenv("MIBC_WS_DBG") ? atoi(getenv("MIBC_WS_DBG")) : 0;
+    WsArgs adbg = *a;
+    if (ws_dbg) {
+        adbg.dbg = ws_dbg;
+        a = &adbg;
+    }
+    static const int nw_env = getenv("MIBC_WS_NW") ? atoi(getenv("MIBC_WS_NW")) : 8;
+    const int NW = (nw_env == 4) ? 4 : 8;
+    // columns per wave per pass: whichever of 64 / 48 / 32 keeps all waves busy
+    const int per = NW * 16;
+    const int CT = (a->cols % (4 * per) == 0) ? 4 : (a->cols % (3 * per) == 0) ? 3 : (a->cols % (2 * per) == 0) ? 2 : 4;
+    // rows per tile: 128, or fewer where the accumulators + the prefetched next tile do not fit the
+    // 256-register budget / two workgroups do not fit the LDS
+    int RT = 8;
     if (mode == 0) {
-        smem = (size_t)WS_ROWS * (K + 16) * 2 + 8 * 16 * 72 * 2;
-        grid = a->T * ((a->Ns + WS_ROWS - 1) / WS_ROWS);
+        if (NW == 8) RT = (CT == 4) ? (KT >= 16 ? 5 : KT >= 8 ? 6 : 8) : 8;
+        else RT = (KT >= 16) ? 4 : (KT >= 12) ? 5 : 8;
+    }
+    const int rows = RT * 16;
+    size_t smem;
+    int ntiles;
+    if (mode == 0) {
+        smem = (size_t)rows * (K + 16) * 2 + NW * 16 * 72 * 2;
+        ntiles = a->T * ((a->Ns + rows - 1) / rows);
     } else {
         if ((a->stride * 16) % 96 != 0) return 1;  // pad scheme assumes 192-byte row pitch multiples
-        const int span_halfs = (WS_ROWS - 1) * a->stride * 16 + K + 16;
-        smem = (size_t)((span_halfs + 95) / 96 + 1) * 112 * 2 + 8 * 16 * 72 * 2;
-        grid = a->N * ((a->T + WS_ROWS - 1) / WS_ROWS);
+        const int span_halfs = (rows - 1) * a->stride * 16 + K + 16;
+        if ((span_halfs + 7) / 8 > 2048) return 1;
+        smem = (size_t)((span_halfs + 95) / 96 + 1) * 112 * 2 + NW * 16 * 72 * 2;
+        ntiles = a->N * ((a->T + rows - 1) / rows);
     }
-    if (smem > 160 * 1024) return 1;
-#define WS_CASE(KT_, M_)                                                                               \
-    if (KT == KT_ && mode == M_) {                                                                     \
+    if (smem > (size_t)(NW == 8 ? 160 : 80) * 1024) return 1;
+    static int ncu = 0;
+    if (ncu == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int slots = ncu * (NW == 8 ? 1 : 2);
+    const int grid = ntiles < slots ? ntiles : slots;
+#define WS_CASE(KT_, M_, CT_, RT_, NW_)                                                                \
+    if (KT == KT_ && mode == M_ && CT == CT_ && RT == RT_ && NW == NW_) {                              \
         static bool once = false;                                                                      \
         if (!once) {                                                                                   \
-            (void)hipFuncSetAttribute((const void *)wsgemm_kernel<KT_, M_>,                            \
+            (void)hipFuncSetAttribute((const void *)wsgemm_kernel<KT_, M_, CT_, RT_, NW_>,             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
             once = true;                                                                               \
         }                                                                                              \
-        hipLaunchKernelGGL((wsgemm_kernel<KT_, M_>), dim3(grid), dim3(512), smem, s, *a);              \
+        hipLaunchKernelGGL((wsgemm_kernel<KT_, M_, CT_, RT_, NW_>), dim3(grid), dim3(NW_ * 64), smem,  \
+                           s, *a);                                                                     \
         return 0;                                                                                      \
     }
-    WS_CASE(4, 0) WS_CASE(8, 0) WS_CASE(12, 0) WS_CASE(16, 0)
-    WS_CASE(10, 1)
+    WS_CASE(4, 0, 4, 8, 8) WS_CASE(8, 0, 4, 6, 8) WS_CASE(12, 0, 4, 6, 8) WS_CASE(16, 0, 4, 5, 8)
+    WS_CASE(4, 0, 2, 8, 8) WS_CASE(8, 0, 2, 8, 8)
+    WS_CASE(10, 1, 4, 8, 8) WS_CASE(10, 1, 3, 8, 8) WS_CASE(10, 1, 2, 8, 8)
+    WS_CASE(12, 0, 4, 5, 4) WS_CASE(10, 1, 3, 8, 4) WS_CASE(10, 1, 4, 8, 4)
 #undef WS_CASE
     return 1;
 }

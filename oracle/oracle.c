@@ -42,44 +42,30 @@ static inline uint32_t f_to_bits(float f) {
     return u;
 }
 
-/* exp(x) for x <= 0 (and small positive); returns 0 below -103. */
+/* exp(x) for x <= 0; arguments below -86 are clamped (the result, < 5e-38, vanishes in any sum
+ * that also holds the exp(0) = 1 term of a log-sum-exp). */
 static float det_expf(float x) {
-    if (x < -103.0f) {
-        return 0.0f;
-    }
-    if (x > 88.0f) {
-        x = 88.0f;
-    }
+    x = x < -86.0f ? -86.0f : x;
     const float n = rintf(x * 1.44269504088896341f);
-    float r = fmaf(n, -0.693145751953125f, x);       /* ln2 hi */
-    r = fmaf(n, -1.42860682030941723212e-6f, r);     /* ln2 lo */
+    const float r = fmaf(n, -0.693147182464599609375f, x); /* one-constant ln2 */
     float p = 1.9875691500e-4f;
     p = fmaf(p, r, 1.3981999507e-3f);
     p = fmaf(p, r, 8.3334519073e-3f);
     p = fmaf(p, r, 4.1665795894e-2f);
     p = fmaf(p, r, 1.6666665459e-1f);
     p = fmaf(p, r, 5.0000001201e-1f);
-    const float r2 = r * r;
-    p = fmaf(p, r2, r);
-    p = p + 1.0f;
-    /* scale by 2^n in two steps so that n down to -149 stays exact until the final rounding */
-    const int ni = (int)n;
-    const int n1 = ni / 2, n2 = ni - n1;
-    p = p * bits_to_f((uint32_t)(n1 + 127) << 23);
-    p = p * bits_to_f((uint32_t)(n2 + 127) << 23);
-    return p;
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    /* p in [0.70, 1.42], n in [-124, 0]: 2^n by adding n to the exponent field */
+    return bits_to_f(f_to_bits(p) + ((uint32_t)(int)n << 23));
 }
 
 /* log(x) for finite x > 0 (normal). */
 static float det_logf(float x) {
-    uint32_t ix = f_to_bits(x);
-    int e = (int)(ix >> 23) - 127;
-    ix = (ix & 0x007fffffu) | 0x3f800000u; /* m in [1,2) */
-    float m = bits_to_f(ix);
-    if (m > 1.41421356237f) {
-        m = m * 0.5f;
-        e += 1;
-    }
+    /* mantissa into [sqrt(1/2), sqrt(2)): re-bias the exponent field around sqrt(1/2) */
+    const uint32_t ix = f_to_bits(x) + (0x3f800000u - 0x3f3504f3u);
+    const int e = (int)(ix >> 23) - 127;
+    const float m = bits_to_f((ix & 0x007fffffu) + 0x3f3504f3u);
     const float f = m - 1.0f;
     const float z = f * f;
     float p = 7.0376836292e-2f;
@@ -92,12 +78,9 @@ static float det_logf(float x) {
     p = fmaf(p, f, -2.4999993993e-1f);
     p = fmaf(p, f, 3.3333331174e-1f);
     float y = (f * z) * p;
-    const float fe = (float)e;
-    y = fmaf(fe, -2.12194440e-4f, y);
     y = fmaf(-0.5f, z, y);
-    float r = f + y;
-    r = fmaf(fe, 0.693359375f, r);
-    return r;
+    const float r = f + y;
+    return fmaf((float)e, 0.693147182464599609375f, r);
 }
 
 static inline float m_exp(float x, int det) { return det ? det_expf(x) : expf(x); }
