@@ -48,6 +48,7 @@ __global__ void bwd_scan_kernel(const half_t *__restrict__ scores,  // [N][T][4S
     half4_t row = *(const half4_t *)(sn + (size_t)(T - 1) * K + 4 * s);
     const int hi = s / Q;
     const int n0 = (s << 2) & (S - 1);
+    const half_t ch = (half_t)((clampv > 0.0f) ? fminf(clampv, 65504.0f) : 65504.0f);
     int p = 0;
     for (int t = T - 1; t >= 0; --t) {
         half_t *scw = sc + p * K;
@@ -61,11 +62,11 @@ __global__ void bwd_scan_kernel(const half_t *__restrict__ scores,  // [N][T][4S
             row = *(const half4_t *)(sn + (size_t)(t - 1) * K + 4 * s);
         }
         const float4_t b4 = *(const float4_t *)(beta + p * S + n0);
-        const half4_t m4 = *(const half4_t *)(scw + hi * S + n0);
-        const float v = dm_lse5(mine + stay, b4[0] + clampf((float)m4[0], clampv),
-                                b4[1] + clampf((float)m4[1], clampv),
-                                b4[2] + clampf((float)m4[2], clampv),
-                                b4[3] + clampf((float)m4[3], clampv));
+        // clamp in f16 (packed; +-5 is exact in f16, so this equals clamping the converted floats)
+        const half4_t m4 = __builtin_elementwise_min(
+                __builtin_elementwise_max(*(const half4_t *)(scw + hi * S + n0), (half4_t)(-ch)), (half4_t)(ch));
+        const float v = dm_lse5(mine + stay, b4[0] + (float)m4[0], b4[1] + (float)m4[1],
+                                b4[2] + (float)m4[2], b4[3] + (float)m4[3]);
         mine = v;
         beta[(p ^ 1) * S + s] = v;
         bn[(size_t)t * S + s] = v;
@@ -86,10 +87,32 @@ __device__ __forceinline__ uint32_t crc32c_bits(uint32_t crc, uint32_t bits, int
     }
     return crc;
 }
+// Wave-wide reductions on the DPP network (no LDS round trips): four steps inside every row of 16
+// lanes, then row_bcast:15 / row_bcast:31 fold the four rows into lane 63, which is broadcast
+// through an SGPR.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float oldv, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv),
+                                                                 __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f<0xB1, 0xf>(v, v));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_f<0x4E, 0xf>(v, v));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_f<0x141, 0xf>(v, v));   // row_half_mirror
+    v = fmaxf(v, dpp_f<0x140, 0xf>(v, v));   // row_mirror: every lane holds its row's maximum
+    v = fmaxf(v, dpp_f<0x142, 0xa>(v, v));   // row_bcast:15 into rows 1 and 3
+    v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));   // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_sum(float v) {  // summation order is fixed but not the butterfly's
+    v += dpp_f<0xB1, 0xf>(0.0f, v);
+    v += dpp_f<0x4E, 0xf>(0.0f, v);
+    v += dpp_f<0x141, 0xf>(0.0f, v);
+    v += dpp_f<0x140, 0xf>(0.0f, v);
+    v += dpp_f<0x142, 0xa>(0.0f, v);
+    v += dpp_f<0x143, 0xc>(0.0f, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ uint32_t f2key(float f) {  // monotone float -> uint
     const uint32_t u = __builtin_bit_cast(uint32_t, f);
@@ -532,12 +555,7 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
                             ((s & (Q - 1)) == (st >> 2)) ||  // left-shifted:  (st >> 2) + b * Q
                             ((s >> 2) == (st & (Q - 1)));    // right-shifted: ((st << 2) % S) + b
         const float e = __expf((v + bw) - logZ);
-        float e_all = e, e_sel = in_set ? e : 0.0f;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            e_all += __shfl_xor(e_all, o, 64);
-            e_sel += __shfl_xor(e_sel, o, 64);
-        }
+        const float e_all = wave_sum(e), e_sel = wave_sum(in_set ? e : 0.0f);
         if (lane == 0) {
             red[(t & 1) * 32 + wave] = e_all;
             red[(t & 1) * 32 + 16 + wave] = e_sel;

@@ -24,7 +24,7 @@ DM_FN uint32_t dm_f_to_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 // One-constant range reduction: the error it leaves, |n| * 2e-8 relative, only grows where the
 // value itself (2^n) has stopped mattering to the sum.
 DM_FN float dm_expf(float x) {
-    x = x < -86.0f ? -86.0f : x;
+    x = __builtin_fmaxf(x, -86.0f);
     const float n = __builtin_rintf(x * 1.44269504088896341f);
     const float r = __builtin_fmaf(n, -0.693147182464599609375f, x);
     float p = 1.9875691500e-4f;
@@ -65,11 +65,7 @@ DM_FN float dm_logf(float x) {
 // log-sum-exp of {stay, 4 steps}: max, sum of exp in argument order, log
 // (at::logsumexp semantics, decode/CPUDecoder.cpp:28-34).
 DM_FN float dm_lse5(float v0, float v1, float v2, float v3, float v4) {
-    float m = v0;
-    m = v1 > m ? v1 : m;
-    m = v2 > m ? v2 : m;
-    m = v3 > m ? v3 : m;
-    m = v4 > m ? v4 : m;
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(v0, v1), __builtin_fmaxf(v2, v3)), v4);
     float s = dm_expf(v0 - m);
     s += dm_expf(v1 - m);
     s += dm_expf(v2 - m);

@@ -285,10 +285,17 @@ extern "C" int mibc_batch_granularity(const mibc_engine *e) {
     return e->is_tx ? 1 : mibc_lstm_rows_per_wg(e->C);
 }
 
+static int decode_sub_default(const mibc_engine *e) {
+    if (e->is_tx) return 2048;          // 25 MB per chunk (T = 2048, K = 4096)
+    return e->K > 1024 ? 4096 : 16384;  // sup@v4.3: 20.5 MB per chunk ; hac: 5.3 MB ; fast: 1.3 MB
+}
+
 static int decode_sub(const mibc_engine *e, int N) {
     const char *s = getenv("MIBC_DECODE_SUB");
-    int nd = s ? atoi(s) : (e->K > 1024 ? 2048 : 4096);  // keeps scores+guides per sub-batch <= ~45 GB
-    if (e->is_tx && !s) nd = 1024;                        // 16 MB of scores per chunk (T = 2048, K = 4096)
+    // Largest sub-batch whose scores + back-guides + trace stay under ~100 GB of the 288 GB: every
+    // decode kernel is one wave / workgroup per chunk, so the more chunks per launch the better the
+    // latency hiding (hac: 16384 chunks in one launch 70 ms vs 81 ms in four launches of 4096).
+    int nd = s ? atoi(s) : decode_sub_default(e);
     if (nd < 64) nd = 64;
     nd = (nd / 64) * 64;
     return N < nd ? N : nd;
@@ -302,7 +309,7 @@ extern "C" int mibc_query_memory(const mibc_engine *e, int T_in, size_t *bytes_p
     if (e->is_tx) {
         const size_t per_dec = T * e->K * 2 + (T + 1) * e->S * 4 + (T + 1) * 32 * 4 + T * 2 + T * 4;
         if (bytes_per_chunk) *bytes_per_chunk = tx_bytes_per_chunk(e, T_in);
-        if (bytes_fixed) *bytes_fixed = per_dec * 1024;
+        if (bytes_fixed) *bytes_fixed = per_dec * (size_t)decode_sub_default(e);
         return MIBC_OK;
     }
     const size_t Tpitch = (size_t)T_in + 2 * e->pad3 + 2;
@@ -314,7 +321,7 @@ extern "C" int mibc_query_memory(const mibc_engine *e, int T_in, size_t *bytes_p
     const size_t per_dec = T * e->K * 2 + (T + 1) * e->S * 4 + (T + 1) * 32 * 4 + T * 2 + T * 4 +
                            (e->d.out_features > 0 ? T * e->d.out_features * 2 : 0);
     if (bytes_per_chunk) *bytes_per_chunk = per;
-    if (bytes_fixed) *bytes_fixed = per_dec * 4096;  // decode scratch is per sub-batch
+    if (bytes_fixed) *bytes_fixed = per_dec * (size_t)decode_sub_default(e);  // decode scratch is per sub-batch
     return MIBC_OK;
 }
 

@@ -45,7 +45,7 @@ static inline uint32_t f_to_bits(float f) {
 /* exp(x) for x <= 0; arguments below -86 are clamped (the result, < 5e-38, vanishes in any sum
  * that also holds the exp(0) = 1 term of a log-sum-exp). */
 static float det_expf(float x) {
-    x = x < -86.0f ? -86.0f : x;
+    x = fmaxf(x, -86.0f);
     const float n = rintf(x * 1.44269504088896341f);
     const float r = fmaf(n, -0.693147182464599609375f, x); /* one-constant ln2 */
     float p = 1.9875691500e-4f;
