@@ -26,6 +26,31 @@ __device__ __forceinline__ half8_t wsload(__amdgpu_buffer_rsrc_t rs, int voff, i
     return __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
 
+// Activation of four outputs.  All forms are  a + b / (1 + 2^(k x))  (one v_exp_f32, one
+// v_rcp_f32 per element, the rest on the packed-f32 pipe):
+//   3: 5 tanh x = 5 - 10 / (1 + 2^(2 log2e x))      2: tanh x = 1 - 2 / (1 + 2^(2 log2e x))
+//   0: swish x = x / (1 + 2^(-log2e x))              1: min(swish x, 3.5)
+template <int act>
+__device__ __forceinline__ float4w ws_activation(float4w v) {
+    if (act < 0) return v;
+    const float k = (act >= 2) ? 2.88539008f : -1.44269504f;
+    const float4w kv = v * (float4w)(k);
+    float4w d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r] = __builtin_amdgcn_exp2f(kv[r]);
+    d = d + (float4w)(1.0f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r] = __builtin_amdgcn_rcpf(d[r]);
+    if (act == 3) return d * (float4w)(-10.0f) + (float4w)(5.0f);
+    if (act == 2) return d * (float4w)(-2.0f) + (float4w)(1.0f);
+    float4w sw = v * d;
+    if (act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sw[r] = fminf(sw[r], 3.5f);
+    }
+    return sw;
+}
+
 struct WsArgs {
     const half_t *A;     // activations
     const half_t *Wf;    // [cols/16][K/32][64][8] fragment order
@@ -49,7 +74,7 @@ struct WsArgs {
 // in flight from HBM into registers (pre[]), so the HBM latency of the activation read hides behind
 // the MFMAs instead of being paid once per workgroup; the weight fragments of the next pass's first
 // k-step are requested before the epilogue for the same reason.
-template <int KT, int MODE, int CT, int RT, int NW>
+template <int KT, int MODE, int CT, int RT, int NW, int ACT>
 __global__ __launch_bounds__(NW * 64, 2) void wsgemm_kernel(WsArgs p) {
     constexpr int NT = NW * 64;
     constexpr int WS_ROWS = RT * 16;
@@ -137,7 +162,6 @@ __global__ __launch_bounds__(NW * 64, 2) void wsgemm_kernel(WsArgs p) {
         if (tnext < ntiles) tile_fetch(tnext);
 
         const int dbg = p.dbg;
-        const int act = (dbg & 1) ? -1 : p.act;
         for (int pass = 0; pass < passes; ++pass) {
             const int col0 = pass * NW * WCOLS + wave * WCOLS;   // this wave's columns
             if (col0 >= p.cols) break;
@@ -192,17 +216,12 @@ __global__ __launch_bounds__(NW * 64, 2) void wsgemm_kernel(WsArgs p) {
             for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
+                    const float4w h4 = (dbg & 1) ? acc[ct][rt] : ws_activation<ACT>(acc[ct][rt]);
                     half4_t h;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[ct][rt][r];
-                        if (act == 3) {
-                            v = 5.0f * fast_tanh(v);
-                        } else if (act >= 0) {
-                            v = act_apply(v, act);
-                        }
-                        h[r] = (half_t)v;
-                    }
+                    h[0] = (half_t)h4[0];
+                    h[1] = (half_t)h4[1];
+                    h[2] = (half_t)h4[2];
+                    h[3] = (half_t)h4[3];
                     *(half4_t *)(stg + l15 * 72 + ct * 16 + 4 * lq) = h;
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
@@ -281,22 +300,35 @@ extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mod
     }
     const int slots = ncu * (NW == 8 ? 1 : 2);
     const int grid = ntiles < slots ? ntiles : slots;
-#define WS_CASE(KT_, M_, CT_, RT_, NW_)                                                                \
-    if (KT == KT_ && mode == M_ && CT == CT_ && RT == RT_ && NW == NW_) {                              \
+    // activation is a template parameter (a run-time switch costs ~4 extra VALU per output): the
+    // head uses 5*tanh (3) or none (-1), conv3 swish (0), clamped swish (1) or tanh (2)
+#define WS_ONE(KT_, M_, CT_, RT_, NW_, ACT_)                                                           \
+    if (a->act == ACT_) {                                                                              \
         static bool once = false;                                                                      \
         if (!once) {                                                                                   \
-            (void)hipFuncSetAttribute((const void *)wsgemm_kernel<KT_, M_, CT_, RT_, NW_>,             \
+            (void)hipFuncSetAttribute((const void *)wsgemm_kernel<KT_, M_, CT_, RT_, NW_, ACT_>,       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
             once = true;                                                                               \
         }                                                                                              \
-        hipLaunchKernelGGL((wsgemm_kernel<KT_, M_, CT_, RT_, NW_>), dim3(grid), dim3(NW_ * 64), smem,  \
-                           s, *a);                                                                     \
+        hipLaunchKernelGGL((wsgemm_kernel<KT_, M_, CT_, RT_, NW_, ACT_>), dim3(grid), dim3(NW_ * 64),  \
+                           smem, s, *a);                                                               \
         return 0;                                                                                      \
+    }
+#define WS_CASE(KT_, M_, CT_, RT_, NW_)                                                                \
+    if (KT == KT_ && mode == M_ && CT == CT_ && RT == RT_ && NW == NW_) {                              \
+        if (M_ == 0) {                                                                                 \
+            WS_ONE(KT_, M_, CT_, RT_, NW_, 3) WS_ONE(KT_, M_, CT_, RT_, NW_, -1)                       \
+        } else {                                                                                       \
+            WS_ONE(KT_, M_, CT_, RT_, NW_, 0) WS_ONE(KT_, M_, CT_, RT_, NW_, 1)                        \
+            WS_ONE(KT_, M_, CT_, RT_, NW_, 2)                                                          \
+        }                                                                                              \
+        return 1;                                                                                      \
     }
     WS_CASE(4, 0, 4, 8, 8) WS_CASE(8, 0, 4, 6, 8) WS_CASE(12, 0, 4, 6, 8) WS_CASE(16, 0, 4, 5, 8)
     WS_CASE(4, 0, 2, 8, 8) WS_CASE(8, 0, 2, 8, 8)
     WS_CASE(10, 1, 4, 8, 8) WS_CASE(10, 1, 3, 8, 8) WS_CASE(10, 1, 2, 8, 8)
-    WS_CASE(12, 0, 4, 5, 4) WS_CASE(10, 1, 3, 8, 4) WS_CASE(10, 1, 4, 8, 4)
+    WS_CASE(10, 1, 3, 8, 4)
 #undef WS_CASE
+#undef WS_ONE
     return 1;
 }

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; each `--pmc X --kernel-trace
+--output-format csv` of `tools/stage_times.py --steps 1`) into profiles/<tag>_pmc_traffic_<model>_n<N>.json.
+
+usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> <model> <N> <T_in>
+FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of a wide coalesced read
+(MI355X_MICROARCH.md, HBM section), so hbm_bytes = (2*FETCH + WRITE) * 1024.  Per-launch averages."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(d, counter):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    tot = collections.defaultdict(float)
+    disp = collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        tot[r["Kernel_Name"]] += float(r["Counter_Value"])
+        disp[r["Kernel_Name"]].add(r["Dispatch_Id"])
+    return {k: tot[k] / len(disp[k]) for k in tot}, {k: len(v) for k, v in disp.items()}
+
+
+def main():
+    fd, wd, out, model, n, t_in = sys.argv[1:7]
+    fe, nl = per_kernel(fd, "FETCH_SIZE")
+    wr, _ = per_kernel(wd, "WRITE_SIZE")
+    kern = {}
+    for k in fe:
+        if "rocclr" in k:
+            continue
+        kern[k] = {"launches": nl[k], "FETCH_SIZE_KB": fe[k], "WRITE_SIZE_KB": wr.get(k, 0.0),
+                   "hbm_bytes_corrected": (2.0 * fe[k] + wr.get(k, 0.0)) * 1024.0}
+    json.dump({"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of "
+                        "tools/stage_times.py --steps 1 on MI355X. Counter unit = KB. Per MI355X_MICROARCH.md "
+                        "(HBM) FETCH_SIZE reads exactly 1/2 of a wide coalesced stream on gfx950, so hbm_bytes = "
+                        "(2*FETCH_SIZE + WRITE_SIZE)*1024; WRITE_SIZE uncalibrated. Averages per launch.",
+               "workload": {"model": model, "N": int(n), "T_in": int(t_in)}, "kernels": kern},
+              open(out, "w"), indent=1)
+    for k, v in kern.items():
+        print(f"{k[:50]:50s} x{v['launches']} {v['hbm_bytes_corrected'] / 1e9:8.2f} GB")
+
+
+if __name__ == "__main__":
+    main()
