@@ -44,7 +44,11 @@ EXPORTS = [
     "mibc_host_free", "mibc_device_alloc", "mibc_device_free", "mibc_memcpy_h2d",
     "mibc_memcpy_d2h", "mibc_forward", "mibc_decode", "mibc_call_device", "mibc_call",
     "mibc_sync", "mibc_time_forward", "mibc_get_stage_ms", "mibc_set_profile", "mibc_debug_tap",
+    "mibc_forward_i16", "mibc_call_device_i16", "mibc_call_i16", "mibc_scaler_stats", "mibc_scale_reads",
 ]
+
+SCALE_QUANTILE = 0
+SCALE_MED_MAD = 1
 
 
 def build() -> None:
@@ -99,6 +103,14 @@ def lib():
         L.mibc_get_stage_ms.argtypes = [C.c_void_p, C.POINTER(StageMsC)]
         L.mibc_set_profile.argtypes = [C.c_void_p, C.c_int]
         L.mibc_debug_tap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.mibc_forward_i16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.mibc_call_device_i16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                           C.POINTER(DecodeOptsC), C.c_void_p]
+        L.mibc_call_i16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.POINTER(DecodeOptsC), C.c_void_p]
+        L.mibc_scaler_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                        C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        L.mibc_scale_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -263,6 +275,94 @@ class Engine:
         self._check(lib().mibc_call(self._h, x.ctypes.data, n, t_in, C.byref(self.opts),
                                     out.ctypes.data), "mibc_call")
         return unpack_planes(out)
+
+    # -- f1: ScalerNode on the device (raw int16 in)
+    def call_i16(self, x_i16: np.ndarray, shift_scale: np.ndarray):
+        """Host batch of RAW int16 chunks + one (shift, scale) per chunk -> decoded chunks
+        (mibc_call_i16: the ScalerNode map is applied inside conv1's input read)."""
+        x = np.ascontiguousarray(x_i16, np.int16)
+        ss = np.ascontiguousarray(shift_scale, np.float32).reshape(-1, 2)
+        n, t_in = x.shape
+        assert ss.shape[0] == n
+        t = self.output_steps(t_in)
+        self.reserve(n, t_in)
+        out = np.zeros((3, n, t), np.int8)
+        self._check(lib().mibc_call_i16(self._h, x.ctypes.data, ss.ctypes.data, n, t_in,
+                                        C.byref(self.opts), out.ctypes.data), "mibc_call_i16")
+        return unpack_planes(out)
+
+    def forward_i16(self, x_i16: np.ndarray, shift_scale: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x_i16, np.int16)
+        ss = np.ascontiguousarray(shift_scale, np.float32).reshape(-1, 2)
+        n, t_in = x.shape
+        t = self.output_steps(t_in)
+        k = self.cfg.outsize
+        self.reserve(n, t_in)
+        d_in, d_ss = self.device_alloc(x.nbytes), self.device_alloc(ss.nbytes)
+        d_sc = self.device_alloc(n * t * k * 2)
+        try:
+            self.h2d(d_in, x)
+            self.h2d(d_ss, ss)
+            self._check(lib().mibc_forward_i16(self._h, d_in, d_ss, n, t_in, d_sc), "mibc_forward_i16")
+            self.sync()
+            out = np.zeros((n, t, k), np.float16)
+            self.d2h(out, d_sc)
+        finally:
+            for p in (d_in, d_ss, d_sc):
+                self.device_free(p)
+        return out
+
+    def scaler_stats(self, reads, strategy: int, params4=None):
+        """reads: list of int16 arrays -> (shift_scale [n,2] f32, raw [n,2] f32) computed on the device
+        (mibc_scaler_stats)."""
+        sig = np.ascontiguousarray(np.concatenate([np.asarray(r, np.int16) for r in reads]) if reads
+                                   else np.zeros(0, np.int16))
+        off = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+        n = len(reads)
+        d_sig = self.device_alloc(max(sig.nbytes, 16))
+        d_off = self.device_alloc(off.nbytes)
+        d_ss = self.device_alloc(max(n, 1) * 8)
+        d_raw = self.device_alloc(max(n, 1) * 8)
+        try:
+            if sig.nbytes:
+                self.h2d(d_sig, sig)
+            self.h2d(d_off, off)
+            p = None
+            if params4 is not None:
+                p = (C.c_float * 4)(*[float(v) for v in params4])
+            self._check(lib().mibc_scaler_stats(self._h, d_sig, d_off, n, strategy, p, d_ss, d_raw),
+                        "mibc_scaler_stats")
+            self.sync()
+            ss = np.zeros((n, 2), np.float32)
+            raw = np.zeros((n, 2), np.float32)
+            if n:
+                self.d2h(ss, d_ss)
+                self.d2h(raw, d_raw)
+        finally:
+            for q in (d_sig, d_off, d_ss, d_raw):
+                self.device_free(q)
+        return ss, raw
+
+    def scale_reads(self, reads, shift_scale: np.ndarray):
+        """list of int16 reads + [n,2] (shift, scale) -> list of np.float16 arrays (mibc_scale_reads)."""
+        sig = np.ascontiguousarray(np.concatenate([np.asarray(r, np.int16) for r in reads]))
+        off = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+        ss = np.ascontiguousarray(shift_scale, np.float32).reshape(-1, 2)
+        n = len(reads)
+        d_sig, d_off = self.device_alloc(max(sig.nbytes, 16)), self.device_alloc(off.nbytes)
+        d_ss, d_out = self.device_alloc(ss.nbytes), self.device_alloc(max(sig.nbytes, 16))
+        try:
+            self.h2d(d_sig, sig)
+            self.h2d(d_off, off)
+            self.h2d(d_ss, ss)
+            self._check(lib().mibc_scale_reads(self._h, d_sig, d_off, n, d_ss, d_out), "mibc_scale_reads")
+            self.sync()
+            out = np.zeros(sig.shape, np.float16)
+            self.d2h(out, d_out)
+        finally:
+            for q in (d_sig, d_off, d_ss, d_out):
+                self.device_free(q)
+        return [out[off[i]:off[i + 1]] for i in range(n)]
 
 
 def unpack_planes(out3: np.ndarray):

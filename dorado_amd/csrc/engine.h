@@ -14,21 +14,26 @@
 
 struct GemmArgs {
     const half_t *A;
-    const half_t *B;
-    const float *bias;
+    const half_t *B;    // [Ncols][K]
+    const float *bias;  // [Ncols] or nullptr
     half_t *out;
-    int M, Ncols, K;
+    int M, Ncols, K;    // K multiple of 32, Ncols multiple of 128
     int a_div;
     long a_outer, a_inner;
     int o_div;
     long o_outer, o_inner;
-    int act;
-    int ncols_valid;
+    int act;            // -1 identity, 0/1/2 as MIBC_ACT_*, 3 = 5*tanh
+    int ncols_valid;    // 0 = all; else columns >= ncols_valid are computed (zero weights) but not stored
+    // epilogue fusions of the transformer path (tx.hip):
+    //  mode 1: rotary embedding on q and k (columns < rope_cols), head_dim 64, half-split pairs
+    //          (c, c+32); table rope[t][32] = {cos, sin} interleaved as float2, t = m % rope_T
+    //  mode 2: SwiGLU: each 128-column tile holds 64 "y" then 64 "gate" features; writes
+    //          silu(gate) * y to 64 output columns (out row stride = Ncols / 2)
     int epi_mode;
     const float *rope;
     int rope_T, rope_cols;
-    half_t *vT;
-    int dbg;
+    half_t *vT;         // epi_mode 1: if set, columns >= 2*rope_cols/2.. (the V third) go to vT[n][h][64][rope_T]
+    int dbg;            // debug ablation bits (microbenchmark only): 1 no stores, 2 no MFMA, 4 no DMA
 };
 extern "C" int mibc_launch_gemm_tn(hipStream_t s, const GemmArgs *a);
 struct WsArgs {
@@ -38,13 +43,19 @@ struct WsArgs {
     half_t *out;
     int cols;
     int act;
-    int N, Ns, n0, T;
-    int Tpitch, stride;
+    int N, Ns, n0, T;    // head: full batch, sub-batch, first chunk of the sub-batch, steps
+    int Tpitch, stride;  // conv3: a2p rows per chunk, conv stride
+    int dbg;             // timing ablations (MIBC_WS_DBG); 0 in production
 };
 extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mode);
 extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w1, const float *b1,
-                                  const float *w2, const float *b2, half_t *a2p, half_t *a1_tap,
+                                  const float *w2, const float *b2, half_t *a2p, half_t *a1_tap, const float *ss,
                                   int N, int T_in, int Tpitch, int pad, int act1, int act2);
+extern "C" int mibc_launch_read_stats(hipStream_t s, const int16_t *sig, const long long *off, int n_reads,
+                                      int strategy, float qa, float qb, float shift_mult, float scale_mult,
+                                      float *out_ss, float *out_raw, uint32_t *scratch);
+extern "C" int mibc_launch_scale_reads(hipStream_t s, const int16_t *sig, const long long *off, int n_reads,
+                                       const float *ss, half_t *out, int blocks_per_read);
 extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, half_t *Xout,
                                       const half_t *Wf, const half_t *Wf16, const float *biasn, int T, int N,
                                       int reverse);
@@ -75,6 +86,10 @@ struct mibc_engine {
     half_t *head_w1 = nullptr, *head_w2 = nullptr;
     float *head_b1 = nullptr;
     int head_act1 = -1, head_act2 = -1;
+    // f1 (ScalerNode): per-chunk (shift, scale) of the int16 input of the call in flight, or nullptr
+    const float *in_ss = nullptr;
+    float *ss_stage = nullptr;          // device copy of host-provided pairs (mibc_call_i16)
+    uint32_t *stats_scratch = nullptr;  // [256][2][65536] wide-range histograms, allocated on first use
     // geometry
     int C = 0, S = 0, K = 0, stride = 1, pad3 = 0;
     // workspace

@@ -71,6 +71,9 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
         }
         const char *tp = getenv("MIBC_TAPS");
         e->taps = tp ? atoi(tp) : 0;
+        // weight uploads are null-stream copies from pageable memory: hipMemcpy may return once the data
+        // sits in the staging buffer, and the engine's stream is non-blocking, so finish them here
+        HIP_OK(e, hipDeviceSynchronize());
         *out = e;
         return MIBC_OK;
     }
@@ -235,6 +238,9 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
     if (const char *wsv = getenv("MIBC_WSGEMM")) e->use_ws = atoi(wsv);
     const char *tp = getenv("MIBC_TAPS");
     e->taps = tp ? atoi(tp) : 0;
+    // weight uploads are null-stream copies from pageable memory: hipMemcpy may return once the data sits
+    // in the staging buffer, and the engine's stream is non-blocking, so finish them before first use
+    HIP_OK(e, hipDeviceSynchronize());
     *out = e;
     return MIBC_OK;
 }
@@ -242,7 +248,7 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
 static void free_ws(mibc_engine *e) {
     if (e->is_tx) tx_free_ws(e);
     void *ptrs[] = {e->in_stage, e->a2p, e->xa, e->xb, e->scores, e->mid, e->a1_tap, e->bwd,
-                    e->prob_tap, e->trace, e->path_state, e->out3};
+                    e->prob_tap, e->trace, e->path_state, e->out3, e->ss_stage};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     e->in_stage = e->a2p = e->xa = e->xb = e->scores = e->mid = e->a1_tap = nullptr;
@@ -250,6 +256,7 @@ static void free_ws(mibc_engine *e) {
     e->trace = nullptr;
     e->path_state = nullptr;
     e->out3 = nullptr;
+    e->ss_stage = nullptr;
     for (auto ev : e->sub_ev) (void)hipEventDestroy(ev);
     e->sub_ev.clear();
     e->N_res = 0;
@@ -262,7 +269,8 @@ extern "C" void mibc_destroy(mibc_engine *e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     free_ws(e);
     if (e->is_tx) tx_destroy(e);
-    void *ptrs[] = {e->w1, e->b1, e->w2, e->b2, e->b3, e->w3, e->head_w1, e->head_w2, e->head_b1, e->w3f, e->head_w1f};
+    void *ptrs[] = {e->w1, e->b1, e->w2, e->b2, e->b3, e->w3, e->head_w1, e->head_w2, e->head_b1, e->w3f, e->head_w1f,
+                    e->stats_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto p : e->lstm_w) (void)hipFree(p);
@@ -346,6 +354,7 @@ extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
         return 0;
     };
     if (alloc((void **)&e->in_stage, N * T_in * 2)) return MIBC_ERR_MEM;
+    if (alloc((void **)&e->ss_stage, N * 2 * sizeof(float))) return MIBC_ERR_MEM;
     if (e->is_tx) {
         size_t txb = 0;
         const int rc = tx_reserve(e, N_max, T_in, &txb);
@@ -353,7 +362,8 @@ extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
         total += txb;
     } else {
         if (alloc((void **)&e->a2p, (N * e->Tpitch + 64) * 16 * 2)) return MIBC_ERR_MEM;
-        HIP_OK(e, hipMemset(e->a2p, 0, (N * e->Tpitch + 64) * 16 * 2));
+        // on the engine's stream: a null-stream memset is not ordered with this non-blocking stream
+        HIP_OK(e, hipMemsetAsync(e->a2p, 0, (N * e->Tpitch + 64) * 16 * 2, e->stream));
         if (alloc((void **)&e->xa, T * N * e->C * 2)) return MIBC_ERR_MEM;
         if (alloc((void **)&e->xb, T * N * e->C * 2)) return MIBC_ERR_MEM;
     }
@@ -375,6 +385,7 @@ extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
     e->T_in_res = T_in;
     e->T_res = (int)T;
     e->ws_bytes = total;
+    HIP_OK(e, hipStreamSynchronize(e->stream));  // the zero fills above
     return MIBC_OK;
 }
 
@@ -424,7 +435,7 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     const int T = mibc_output_steps(e, T_in);
     const bool prof = e->profile > 0;
     if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_START], e->stream));
-    if (mibc_launch_conv12(e->stream, in_dev, e->w1, e->b1, e->w2, e->b2, e->a2p, e->a1_tap, N, T_in,
+    if (mibc_launch_conv12(e->stream, in_dev, e->w1, e->b1, e->w2, e->b2, e->a2p, e->a1_tap, e->in_ss, N, T_in,
                            e->Tpitch, e->pad3, d.conv_act[0], d.conv_act[1]) != 0)
         return fail(e, MIBC_NOT_SUPPORTED, "conv activation combination not supported");
     bool conv3_done = false;
@@ -644,6 +655,85 @@ extern "C" int mibc_call(mibc_engine *e, const uint16_t *in_host, int N, int T_i
     if (rc != MIBC_OK) return rc;
     HIP_OK(e, hipMemcpyAsync(out_host, e->out3, (size_t)3 * N * T, hipMemcpyDeviceToHost, e->stream));
     HIP_OK(e, hipStreamSynchronize(e->stream));
+    return MIBC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// f1: ScalerNode on the device.  The *_i16 entry points take raw int16 chunks
+// plus one (shift, scale) pair per chunk and apply f16((x - shift) / scale)
+// (torch_utils/tensor_utils.cpp:89-142) inside the first convolution's input read.
+// ---------------------------------------------------------------------------------------------
+extern "C" int mibc_forward_i16(mibc_engine *e, const int16_t *in_dev, const float *shift_scale_dev, int N,
+                                int T_in, uint16_t *scores_dev) {
+    if (!e || !shift_scale_dev) return MIBC_ERR_ARG;
+    e->in_ss = shift_scale_dev;
+    const int rc = mibc_forward(e, (const uint16_t *)in_dev, N, T_in, scores_dev);
+    e->in_ss = nullptr;
+    return rc;
+}
+
+extern "C" int mibc_call_device_i16(mibc_engine *e, const int16_t *in_dev, const float *shift_scale_dev, int N,
+                                    int T_in, const mibc_decode_opts *o, int8_t *out_dev) {
+    if (!e || !shift_scale_dev) return MIBC_ERR_ARG;
+    e->in_ss = shift_scale_dev;
+    const int rc = mibc_call_device(e, (const uint16_t *)in_dev, N, T_in, o, out_dev);
+    e->in_ss = nullptr;
+    return rc;
+}
+
+extern "C" int mibc_call_i16(mibc_engine *e, const int16_t *in_host, const float *shift_scale_host, int N,
+                             int T_in, const mibc_decode_opts *o, int8_t *out_host) {
+    if (!shift_scale_host) return MIBC_ERR_ARG;
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    const int T = mibc_output_steps(e, T_in);
+    HIP_OK(e, hipMemcpyAsync(e->in_stage, in_host, (size_t)N * T_in * 2, hipMemcpyHostToDevice, e->stream));
+    HIP_OK(e, hipMemcpyAsync(e->ss_stage, shift_scale_host, (size_t)N * 2 * sizeof(float),
+                             hipMemcpyHostToDevice, e->stream));
+    rc = mibc_call_device_i16(e, (const int16_t *)e->in_stage, e->ss_stage, N, T_in, o, e->out3);
+    if (rc != MIBC_OK) return rc;
+    HIP_OK(e, hipMemcpyAsync(out_host, e->out3, (size_t)3 * N * T, hipMemcpyDeviceToHost, e->stream));
+    HIP_OK(e, hipStreamSynchronize(e->stream));
+    return MIBC_OK;
+}
+
+// Per-read shift / scale of the QUANTILE (strategy 0; params = quantile_a, quantile_b, shift_multiplier,
+// scale_multiplier) and MED_MAD (strategy 1) strategies, ScalerNode.cpp:32-52.  Reads are concatenated in
+// sig_dev, read r = [offsets_dev[r], offsets_dev[r+1]).  raw_dev (optional) receives (q_a, q_b) or
+// (median, median |x - median|).
+extern "C" int mibc_scaler_stats(mibc_engine *e, const int16_t *sig_dev, const int64_t *offsets_dev, int n_reads,
+                                 int strategy, const float *params4, float *shift_scale_dev, float *raw_dev) {
+    if (!e || !sig_dev || !offsets_dev || !shift_scale_dev || n_reads < 0) return MIBC_ERR_ARG;
+    if (strategy != 0 && strategy != 1) return fail(e, MIBC_ERR_ARG, "strategy: 0 quantile, 1 med_mad");
+    if (strategy == 0 && !params4) return MIBC_ERR_ARG;
+    HIP_OK(e, hipSetDevice(e->device));
+    constexpr int GROUP = 256;  // bounds the wide-range scratch at 128 MiB
+    if (!e->stats_scratch) HIP_OK(e, hipMalloc((void **)&e->stats_scratch, (size_t)GROUP * 2 * 65536 * 4));
+    const float qa = params4 ? params4[0] : 0.f, qb = params4 ? params4[1] : 0.f;
+    const float shm = params4 ? params4[2] : 0.f, scm = params4 ? params4[3] : 0.f;
+    for (int r0 = 0; r0 < n_reads; r0 += GROUP) {
+        const int nr = (n_reads - r0 < GROUP) ? (n_reads - r0) : GROUP;
+        mibc_launch_read_stats(e->stream, sig_dev, (const long long *)offsets_dev + r0, nr, strategy, qa, qb, shm,
+                               scm, shift_scale_dev + 2 * (size_t)r0, raw_dev ? raw_dev + 2 * (size_t)r0 : nullptr,
+                               e->stats_scratch);
+    }
+    HIP_OK(e, hipGetLastError());
+    return MIBC_OK;
+}
+
+// out[i] = f16((float(x[i]) - shift_r) / scale_r) for every sample of every read
+// (utils::shift_scale_tensor_i16_to_f16_inplace, tensor_utils.cpp:89-142).
+extern "C" int mibc_scale_reads(mibc_engine *e, const int16_t *sig_dev, const int64_t *offsets_dev, int n_reads,
+                                const float *shift_scale_dev, uint16_t *out_f16_dev) {
+    if (!e || !sig_dev || !offsets_dev || !shift_scale_dev || !out_f16_dev || n_reads < 0) return MIBC_ERR_ARG;
+    if (n_reads == 0) return MIBC_OK;
+    HIP_OK(e, hipSetDevice(e->device));
+    for (int r0 = 0; r0 < n_reads; r0 += 32768) {  // grid.y limit
+        const int nr = (n_reads - r0 < 32768) ? (n_reads - r0) : 32768;
+        mibc_launch_scale_reads(e->stream, sig_dev, (const long long *)offsets_dev + r0, nr,
+                                shift_scale_dev + 2 * (size_t)r0, (half_t *)out_f16_dev, n_reads >= 256 ? 8 : 64);
+    }
+    HIP_OK(e, hipGetLastError());
     return MIBC_OK;
 }
 

@@ -7,7 +7,8 @@
 #include "engine.h"
 
 extern "C" int mibc_launch_conv1_tx(hipStream_t s, const half_t *x, const float *w, const float *b,
-                                    half_t *out, int N, int T_in, int Tpitch, int pad_out, int C1, int act);
+                                    half_t *out, const float *ss, int N, int T_in, int Tpitch, int pad_out,
+                                    int C1, int act);
 extern "C" int mibc_launch_window_attention(hipStream_t s, const half_t *qkv, half_t *out, int N, int T,
                                             int C, int H, int win_upper, int win_lower);
 extern "C" int mibc_launch_window_attention_v2(hipStream_t s, const half_t *qk, const half_t *vT, half_t *out,
@@ -190,7 +191,7 @@ int tx_reserve(mibc_engine *e, int N_max, int T_in, size_t *total_out) {
     size_t total = 0;
     auto alloc = [&](half_t **p, size_t halfs, bool zero) -> int {
         HIP_OK(e, hipMalloc((void **)p, halfs * 2));
-        if (zero) HIP_OK(e, hipMemset(*p, 0, halfs * 2));
+        if (zero) HIP_OK(e, hipMemsetAsync(*p, 0, halfs * 2, e->stream));  // ordered with the engine's stream
         total += halfs * 2;
         return 0;
     };
@@ -258,7 +259,7 @@ int tx_run_network(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     const bool prof = e->profile > 0;
     if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_START], e->stream));
     // conv1 -> cbuf[0] (with conv2's pad rows)
-    if (mibc_launch_conv1_tx(e->stream, in_dev, tx.c1w, tx.c1b, tx.cbuf[0], N, T_in, tx.ctp[0],
+    if (mibc_launch_conv1_tx(e->stream, in_dev, tx.c1w, tx.c1b, tx.cbuf[0], e->in_ss, N, T_in, tx.ctp[0],
                              tx.convs[0].pad, d.conv_size[0], d.conv_act[0]) != 0)
         return fail(e, MIBC_NOT_SUPPORTED, "tx conv1 shape");
     for (size_t i = 0; i < tx.convs.size(); ++i) {

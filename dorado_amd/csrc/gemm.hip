@@ -12,31 +12,10 @@
 // LDS as full 256-byte rows (16-byte stores per lane) — the head's scores are the largest HBM
 // stream of the LSTM models (2 KB/step for hac).
 #include "common.h"
+#include "engine.h"
 #include <stdlib.h>
 
-struct GemmArgs {
-    const half_t *A;
-    const half_t *B;    // [Ncols][K]
-    const float *bias;  // [Ncols] or nullptr
-    half_t *out;
-    int M, Ncols, K;    // K multiple of 32, Ncols multiple of 128
-    int a_div;
-    long a_outer, a_inner;
-    int o_div;
-    long o_outer, o_inner;
-    int act;            // -1 identity, 0/1/2 as MIBC_ACT_*, 3 = 5*tanh
-    int ncols_valid;    // 0 = all; else columns >= ncols_valid are computed (zero weights) but not stored
-    // epilogue fusions of the transformer path (tx.hip):
-    //  mode 1: rotary embedding on q and k (columns < rope_cols), head_dim 64, half-split pairs
-    //          (c, c+32); table rope[t][32] = {cos, sin} interleaved as float2, t = m % rope_T
-    //  mode 2: SwiGLU: each 128-column tile holds 64 "y" then 64 "gate" features; writes
-    //          silu(gate) * y to 64 output columns (out row stride = Ncols / 2)
-    int epi_mode;
-    const float *rope;
-    int rope_T, rope_cols;
-    half_t *vT;         // epi_mode 1: if set, columns >= 2*rope_cols/2.. (the V third) go to vT[n][h][64][rope_T]
-    int dbg;            // debug ablation bits (microbenchmark only): 1 no stores, 2 no MFMA, 4 no DMA
-};
+// struct GemmArgs: engine.h (ONE definition shared with the callers)
 
 #define G_BM 128
 #define G_BN 128

@@ -23,13 +23,23 @@ __global__ __launch_bounds__(256) void conv1_tx_kernel(const half_t *__restrict_
                                                        const float *__restrict__ w,    // [5][C1]
                                                        const float *__restrict__ b,    // [C1]
                                                        half_t *__restrict__ out,       // [N][Tpitch][C1]
+                                                       const float *__restrict__ ss,   // nullptr or [N][2]: x is int16
                                                        int T_in, int Tpitch, int pad_out, int act) {
     __shared__ float xs[256 + 8];
     const int n = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
     const half_t *xn = x + (size_t)n * T_in;
-    for (int i = tid; i < 256 + 4; i += 256) {
-        const int t = t0 - 2 + i;
-        xs[i] = (t >= 0 && t < T_in) ? (float)xn[t] : 0.0f;
+    if (ss != nullptr) {  // raw int16 input: ScalerNode's f16((x - shift) / scale) applied on the fly
+        const int16_t *xi = (const int16_t *)x + (size_t)n * T_in;
+        const float shift = ss[2 * n], scale = ss[2 * n + 1];
+        for (int i = tid; i < 256 + 4; i += 256) {
+            const int t = t0 - 2 + i;
+            xs[i] = (t >= 0 && t < T_in) ? (float)(half_t)(((float)xi[t] - shift) / scale) : 0.0f;
+        }
+    } else {
+        for (int i = tid; i < 256 + 4; i += 256) {
+            const int t = t0 - 2 + i;
+            xs[i] = (t >= 0 && t < T_in) ? (float)xn[t] : 0.0f;
+        }
     }
     __syncthreads();
     const int t = t0 + tid;
@@ -54,10 +64,11 @@ __global__ __launch_bounds__(256) void conv1_tx_kernel(const half_t *__restrict_
 }
 
 extern "C" int mibc_launch_conv1_tx(hipStream_t s, const half_t *x, const float *w, const float *b,
-                                    half_t *out, int N, int T_in, int Tpitch, int pad_out, int C1, int act) {
+                                    half_t *out, const float *ss, int N, int T_in, int Tpitch, int pad_out,
+                                    int C1, int act) {
     dim3 grid((T_in + 255) / 256, N);
     if (C1 == 64) {
-        hipLaunchKernelGGL((conv1_tx_kernel<64>), grid, dim3(256), 0, s, x, w, b, out, T_in, Tpitch, pad_out, act);
+        hipLaunchKernelGGL((conv1_tx_kernel<64>), grid, dim3(256), 0, s, x, w, b, out, ss, T_in, Tpitch, pad_out, act);
         return 0;
     }
     return 1;

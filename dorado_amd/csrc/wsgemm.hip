@@ -17,6 +17,7 @@
 // D layout: col = lane & 15 (row of the tile), row = 4*(lane >> 4) + r (output column) -> every
 // lane stores 4 consecutive f16 outputs (8 bytes) of one row.
 #include "common.h"
+#include "engine.h"
 
 typedef float float4w __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4w mfma16(half8_t a, half8_t b, float4w c) {
@@ -51,19 +52,7 @@ __device__ __forceinline__ float4w ws_activation(float4w v) {
     return sw;
 }
 
-struct WsArgs {
-    const half_t *A;     // activations
-    const half_t *Wf;    // [cols/16][K/32][64][8] fragment order
-    const float *bias;   // [cols] or nullptr
-    half_t *out;
-    int cols;            // multiple of 64
-    int act;             // -1 none, 0/1/2 MIBC_ACT_*, 3 = 5*tanh
-    // head: rows are (t, n'): tile index -> t = tile / tiles_per_t, n' = (tile % tiles_per_t)*128
-    int N, Ns, n0, T;    // full batch, sub-batch, first chunk of the sub-batch, steps
-    // conv3:
-    int Tpitch, stride;  // a2p rows per chunk, conv stride
-    int dbg;             // timing ablations (MIBC_WS_DBG); 0 in production
-};
+// struct WsArgs: engine.h (ONE definition shared with the caller)
 
 
 // MODE 0: head (A = X[T][N][C], K = C).  MODE 1: conv3 (A = a2p, K = 32*KT >= W*16).
@@ -273,6 +262,7 @@ extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mod
     // rows per tile: 128, or fewer where the accumulators + the prefetched next tile do not fit the
     // 256-register budget / two workgroups do not fit the LDS
     int RT = 8;
+    if (mode == 1 && CT == 4 && NW == 8) RT = 6;   // 128 rows x 64 columns per wave would spill
     if (mode == 0) {
         if (NW == 8) RT = (CT == 4) ? (KT >= 16 ? 5 : KT >= 8 ? 6 : 8) : 8;
         else RT = (KT >= 16) ? 4 : (KT >= 12) ? 5 : 8;
@@ -326,7 +316,7 @@ extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mod
     }
     WS_CASE(4, 0, 4, 8, 8) WS_CASE(8, 0, 4, 6, 8) WS_CASE(12, 0, 4, 6, 8) WS_CASE(16, 0, 4, 5, 8)
     WS_CASE(4, 0, 2, 8, 8) WS_CASE(8, 0, 2, 8, 8)
-    WS_CASE(10, 1, 4, 8, 8) WS_CASE(10, 1, 3, 8, 8) WS_CASE(10, 1, 2, 8, 8)
+    WS_CASE(10, 1, 4, 6, 8) WS_CASE(10, 1, 3, 8, 8) WS_CASE(10, 1, 2, 8, 8)
     WS_CASE(10, 1, 3, 8, 4)
 #undef WS_CASE
 #undef WS_ONE

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <numeric>
 #include <set>
@@ -154,9 +155,20 @@ void HipCaller::restart() {  // CudaCaller.cpp:283-287
 }
 
 std::vector<DecodedChunk> HipCaller::call_chunks(const uint16_t *in, int8_t *out, int num_chunks) {
+    return submit(in, nullptr, out, num_chunks);
+}
+
+std::vector<DecodedChunk> HipCaller::call_chunks_i16(const int16_t *in, const float *ss, int8_t *out,
+                                                     int num_chunks) {
+    if (!ss) throw std::invalid_argument("call_chunks_i16: shift/scale pairs missing");
+    return submit(reinterpret_cast<const uint16_t *>(in), ss, out, num_chunks);
+}
+
+std::vector<DecodedChunk> HipCaller::submit(const uint16_t *in, const float *ss, int8_t *out, int num_chunks) {
     if (num_chunks <= 0) return {};
     auto task = std::make_shared<NNTask>();
     task->in = in;
+    task->ss = ss;
     task->out = out;
     task->num_chunks = num_chunks;
     {
@@ -185,6 +197,44 @@ std::vector<DecodedChunk> HipCaller::call_chunks(const uint16_t *in, int8_t *out
     return res;
 }
 
+// Quantile / med_mad parameters of whole reads on the device (mibc_scaler_stats).  Synchronous; uses the
+// engine's stream, so it is serialised with the GPU thread by the engine mutex of this caller.
+std::vector<std::pair<float, float>> HipCaller::scaler_stats(
+        const std::vector<std::pair<const int16_t *, size_t>> &reads, const SignalNormalisationParams &p) {
+    if (p.strategy == ScalingStrategy::PA)
+        throw std::invalid_argument("scaler_stats: the PA strategy needs no pass over the samples");
+    std::vector<int64_t> off(reads.size() + 1, 0);
+    for (size_t i = 0; i < reads.size(); ++i) off[i + 1] = off[i] + int64_t(reads[i].second);
+    const size_t total = size_t(off.back());
+    std::vector<std::pair<float, float>> out(reads.size());
+    if (reads.empty()) return out;
+    std::lock_guard<std::mutex> lk(m_engine_mutex);
+    void *d_sig = mibc_device_alloc(m_engine, std::max<size_t>(total * 2, 16));
+    void *d_off = mibc_device_alloc(m_engine, off.size() * 8);
+    void *d_ss = mibc_device_alloc(m_engine, reads.size() * 8);
+    if (!d_sig || !d_off || !d_ss) throw std::runtime_error("scaler_stats: device allocation failed");
+    int rc = MIBC_OK;
+    for (size_t i = 0; i < reads.size() && rc == MIBC_OK; ++i)
+        if (reads[i].second)
+            rc = mibc_memcpy_h2d(m_engine, static_cast<char *>(d_sig) + off[i] * 2, reads[i].first, reads[i].second * 2);
+    if (rc == MIBC_OK) rc = mibc_memcpy_h2d(m_engine, d_off, off.data(), off.size() * 8);
+    const float params[4] = {p.quantile.quantile_a, p.quantile.quantile_b, p.quantile.shift_multiplier,
+                             p.quantile.scale_multiplier};
+    if (rc == MIBC_OK)
+        rc = mibc_scaler_stats(m_engine, static_cast<const int16_t *>(d_sig), static_cast<const int64_t *>(d_off),
+                               int(reads.size()),
+                               p.strategy == ScalingStrategy::QUANTILE ? MIBC_SCALE_QUANTILE : MIBC_SCALE_MED_MAD,
+                               params, static_cast<float *>(d_ss), nullptr);
+    std::vector<float> ss(reads.size() * 2);
+    if (rc == MIBC_OK) rc = mibc_memcpy_d2h(m_engine, ss.data(), d_ss, ss.size() * 4);
+    mibc_device_free(m_engine, d_sig);
+    mibc_device_free(m_engine, d_off);
+    mibc_device_free(m_engine, d_ss);
+    if (rc != MIBC_OK) throw std::runtime_error(std::string("mibc_scaler_stats: ") + mibc_last_error(m_engine));
+    for (size_t i = 0; i < reads.size(); ++i) out[i] = {ss[2 * i], ss[2 * i + 1]};
+    return out;
+}
+
 void HipCaller::gpu_thread_fn() {
     while (true) {
         std::shared_ptr<NNTask> task;
@@ -198,8 +248,17 @@ void HipCaller::gpu_thread_fn() {
         const auto t0 = std::chrono::steady_clock::now();
         // the engine decodes all batch rows (stale rows included), the node uses the first n
         // (CudaCaller.cpp:269-270, BasecallerNode.cpp:185-189)
-        int rc = mibc_call(m_engine, task->in, m_batch_size, m_chunk_size, &m_opts, task->out);
-        if (rc != MIBC_OK) rc = mibc_call(m_engine, task->in, m_batch_size, m_chunk_size, &m_opts, task->out);  // retry once (:698-704)
+        int rc;
+        {
+            std::lock_guard<std::mutex> elk(m_engine_mutex);
+            auto run = [&]() {
+                return task->ss ? mibc_call_i16(m_engine, reinterpret_cast<const int16_t *>(task->in), task->ss,
+                                                m_batch_size, m_chunk_size, &m_opts, task->out)
+                                : mibc_call(m_engine, task->in, m_batch_size, m_chunk_size, &m_opts, task->out);
+            };
+            rc = run();
+            if (rc != MIBC_OK) rc = run();  // retry once (:698-704)
+        }
         m_model_decode_us += std::chrono::duration_cast<std::chrono::microseconds>(
                                      std::chrono::steady_clock::now() - t0).count();
         ++m_batches;
@@ -217,6 +276,105 @@ NamedStats HipCaller::sample_stats() const {  // CudaCaller.cpp:316-321
             {"model_decode_ms", double(m_model_decode_us.load()) / 1000.0}};
 }
 
+// ------------------------------------------------------------------ ScalerNode, host half
+std::optional<float> expected_open_pore_level(const std::string &code) {
+    // read_pipeline/nodes/ScalerNode.cpp:112-139; lookup is case-insensitive (models/kits.cpp:17-30)
+    std::string s = code;
+    std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return char(std::toupper(c)); });
+    static const std::map<std::string, float> table = {
+            {"FLO-FLG114", 200.0f},   {"FLO-FLG114HD", 200.0f}, {"FLO-MIN004RA", 195.50f},
+            {"FLO-PRO004RA", 194.97f}, {"FLO-MIN114", 197.61f},  {"FLO-MIN114HD", 197.61f},
+            {"FLO-PRO114", 199.21f},  {"FLO-PRO114HD", 199.21f}, {"FLO-PRO114M", 199.21f},
+    };
+    const auto it = table.find(s);
+    if (it == table.end()) return std::nullopt;
+    return it->second;
+}
+
+ReadScaling finish_read_scaling(float shift, float scale, const ReadCalibration &cal) {
+    ReadScaling r;
+    r.shift = shift;
+    r.scale = scale;
+    r.scale_pa = cal.scaling * scale;                 // ScalerNode.cpp:226
+    r.shift_pa = cal.scaling * (shift + cal.offset);  // :227
+    return r;
+}
+
+ReadScaling pa_read_scaling(const SignalNormalisationParams &p, const ReadCalibration &cal) {
+    if (p.strategy != ScalingStrategy::PA)
+        throw std::invalid_argument("pa_read_scaling: strategy is data-driven, use HipCaller::scaler_stats");
+    float scale, shift;
+    if (p.standardisation.standardise) {  // ScalerNode.cpp:191-199
+        scale = p.standardisation.stdev / cal.scaling;
+        shift = (p.standardisation.mean / cal.scaling) - cal.offset;
+    } else {
+        scale = 1.f / cal.scaling;
+        shift = -1.f * cal.offset;
+    }
+    ReadScaling r = finish_read_scaling(shift, scale, cal);
+    if (!std::isnan(cal.open_pore_level)) {  // :205-213
+        const auto expected = expected_open_pore_level(cal.flow_cell_product_code);
+        if (expected.has_value() && *expected != 0) r.open_pore_adjustment = (cal.open_pore_level - *expected) / cal.scaling;
+    }
+    return r;
+}
+
+static float f16_bits_to_f32(uint16_t h) {
+    const uint32_t sign = uint32_t(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu, bits;
+    if (e == 0) {
+        if (m == 0) {
+            bits = sign;
+        } else {
+            int sh = 0;
+            while (!(m & 0x400u)) {
+                m <<= 1;
+                ++sh;
+            }
+            bits = sign | uint32_t(127 - 15 - sh + 1) << 23 | (m & 0x3ffu) << 13;
+        }
+    } else if (e == 31) {
+        bits = sign | 0x7f800000u | m << 13;
+    } else {
+        bits = sign | (e + 127 - 15) << 23 | m << 13;
+    }
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+int trim_signal(const uint16_t *sig, int n, float threshold, int window_size, int min_elements) {
+    // torch_utils/trim.cpp:23-60
+    const int min_trim = 10;
+    const int num_samples = n - min_trim;
+    const int num_windows = num_samples / window_size;
+    bool seen_peak = false;
+    for (int pos = 0; pos < num_windows; ++pos) {
+        const int start = pos * window_size + min_trim;
+        const int end = start + window_size;
+        int cnt = 0;
+        for (int i = start; i < end; ++i) cnt += f16_bits_to_f32(sig[i]) > threshold;
+        if (cnt > min_elements || seen_peak) {
+            seen_peak = true;
+            if (f16_bits_to_f32(sig[end - 1]) > threshold) continue;
+            return end >= num_samples ? min_trim : end;
+        }
+    }
+    return min_trim;
+}
+
+int dna_trim_start(const SignalNormalisationParams &p, const uint16_t *scaled, size_t n_samples) {
+    // ScalerNode.cpp:231-254 (DNA branch, no RNA adapter trim in front)
+    int trim_start;
+    if (p.standardisation.standardise) {
+        trim_start = 10;
+    } else {
+        const int max_samples = std::min(8000, int(n_samples / 2));
+        trim_start = trim_signal(scaled, max_samples);
+    }
+    return size_t(trim_start) < n_samples ? trim_start : 0;
+}
+
 // ------------------------------------------------------------------ HipModelRunner
 static std::atomic<int> g_runner_id{0};
 
@@ -224,23 +382,44 @@ HipModelRunner::HipModelRunner(std::shared_ptr<HipCaller> caller) : m_caller(std
     const size_t N = size_t(m_caller->batch_size());
     m_in = static_cast<uint16_t *>(mibc_host_alloc(N * size_t(m_caller->chunk_size()) * 2));
     m_out = static_cast<int8_t *>(mibc_host_alloc(3 * N * size_t(m_caller->output_steps())));
-    if (!m_in || !m_out) throw std::runtime_error("mibc_host_alloc failed");
+    m_ss = static_cast<float *>(mibc_host_alloc(N * 2 * sizeof(float)));
+    if (!m_in || !m_out || !m_ss) throw std::runtime_error("mibc_host_alloc failed");
+    for (size_t i = 0; i < N; ++i) {
+        m_ss[2 * i] = 0.0f;
+        m_ss[2 * i + 1] = 1.0f;
+    }
     std::memset(m_in, 0, N * size_t(m_caller->chunk_size()) * 2);
 }
 
 HipModelRunner::~HipModelRunner() {
     mibc_host_free(m_in);
     mibc_host_free(m_out);
+    mibc_host_free(m_ss);
 }
 
 void HipModelRunner::accept_chunk(int idx, const uint16_t *f16, size_t n) {
     if (idx < 0 || idx >= m_caller->batch_size() || n != size_t(m_caller->chunk_size()))
         throw std::runtime_error("accept_chunk: bad index or chunk length");
+    if (m_mode == 2) throw std::runtime_error("accept_chunk: this batch already holds raw int16 chunks");
+    m_mode = 1;
     std::memcpy(m_in + size_t(idx) * n, f16, n * 2);
+}
+
+void HipModelRunner::accept_chunk_i16(int idx, const int16_t *raw, size_t n, float shift, float scale) {
+    if (idx < 0 || idx >= m_caller->batch_size() || n != size_t(m_caller->chunk_size()))
+        throw std::runtime_error("accept_chunk_i16: bad index or chunk length");
+    if (m_mode == 1) throw std::runtime_error("accept_chunk_i16: this batch already holds scaled f16 chunks");
+    m_mode = 2;
+    std::memcpy(m_in + size_t(idx) * n, raw, n * 2);
+    m_ss[2 * idx] = shift;
+    m_ss[2 * idx + 1] = scale;
 }
 
 std::vector<DecodedChunk> HipModelRunner::call_chunks(int num_chunks) {
     ++m_batches;
+    const int mode = m_mode;
+    m_mode = 0;
+    if (mode == 2) return m_caller->call_chunks_i16(reinterpret_cast<const int16_t *>(m_in), m_ss, m_out, num_chunks);
     return m_caller->call_chunks(m_in, m_out, num_chunks);
 }
 
@@ -278,6 +457,19 @@ SimplexBasecaller::SimplexBasecaller(std::vector<RunnerPtr> runners, int overlap
         : m_runners(std::move(runners)), m_overlap(overlap), m_stride(model_stride) {}
 
 std::vector<CalledRead> SimplexBasecaller::basecall(const std::vector<std::vector<uint16_t>> &reads) {
+    std::vector<ReadView> v;
+    for (const auto &r : reads) v.push_back({r.data(), r.size(), false, 0.0f, 1.0f});
+    return basecall_views(v);
+}
+
+std::vector<CalledRead> SimplexBasecaller::basecall_raw(const std::vector<RawRead> &reads) {
+    std::vector<ReadView> v;
+    for (const auto &r : reads)
+        v.push_back({reinterpret_cast<const uint16_t *>(r.signal), r.n_samples, true, r.shift, r.scale});
+    return basecall_views(v);
+}
+
+std::vector<CalledRead> SimplexBasecaller::basecall_views(const std::vector<ReadView> &reads) {
     struct Work {
         size_t read, idx, offset;
     };
@@ -286,7 +478,7 @@ std::vector<CalledRead> SimplexBasecaller::basecall(const std::vector<std::vecto
     std::vector<std::vector<Chunk>> chunks(reads.size());
     std::deque<Work> queue;
     for (size_t r = 0; r < reads.size(); ++r) {
-        out[r].chunk_offsets = generate_chunks(reads[r].size(), chunk_size, size_t(m_stride), size_t(m_overlap));
+        out[r].chunk_offsets = generate_chunks(reads[r].n, chunk_size, size_t(m_stride), size_t(m_overlap));
         chunks[r].resize(out[r].chunk_offsets.size());
         for (size_t i = 0; i < out[r].chunk_offsets.size(); ++i) {
             chunks[r][i].input_offset = out[r].chunk_offsets[i];
@@ -309,14 +501,19 @@ std::vector<CalledRead> SimplexBasecaller::basecall(const std::vector<std::vecto
             }
             if (mine.empty()) return;
             for (size_t k = 0; k < mine.size(); ++k) {
-                const auto &sig = reads[mine[k].read];
-                const size_t avail = std::min(chunk_size, sig.size() - mine[k].offset);
-                const uint16_t *src = sig.data() + mine[k].offset;
-                if (avail == chunk_size) {
-                    runner->accept_chunk(int(k), src, chunk_size);
-                } else {  // repeat-pad non-full chunks (BasecallerNode.cpp:432-440)
+                const ReadView &sig = reads[mine[k].read];
+                const size_t avail = std::min(chunk_size, sig.n - mine[k].offset);
+                const uint16_t *src = sig.data + mine[k].offset;
+                if (avail != chunk_size) {  // repeat-pad non-full chunks (BasecallerNode.cpp:432-440)
                     for (size_t p = 0; p < chunk_size; ++p) padded[p] = src[p % avail];
-                    runner->accept_chunk(int(k), padded.data(), chunk_size);
+                    src = padded.data();
+                }
+                if (sig.raw) {
+                    auto *hip = dynamic_cast<HipModelRunner *>(runner);
+                    if (!hip) throw std::runtime_error("raw int16 reads need a HipModelRunner");
+                    hip->accept_chunk_i16(int(k), reinterpret_cast<const int16_t *>(src), chunk_size, sig.shift, sig.scale);
+                } else {
+                    runner->accept_chunk(int(k), src, chunk_size);
                 }
             }
             auto decoded = runner->call_chunks(int(mine.size()));
@@ -337,11 +534,11 @@ std::vector<CalledRead> SimplexBasecaller::basecall(const std::vector<std::vecto
     for (size_t r = 0; r < reads.size(); ++r) {
         std::vector<const Chunk *> cc;
         for (auto &c : chunks[r]) cc.push_back(&c);
-        StitchedRead s = stitch_chunks(cc, reads[r].size(), m_stride);
+        StitchedRead s = stitch_chunks(cc, reads[r].n, m_stride);
         out[r].seq = std::move(s.seq);
         out[r].qstring = std::move(s.qstring);
         out[r].moves = std::move(s.moves);
-        m_samples_processed += int64_t(reads[r].size());
+        m_samples_processed += int64_t(reads[r].n);
     }
     return out;
 }
@@ -362,6 +559,83 @@ static thread_local std::string g_herr;
 extern "C" {
 
 const char *mibch_last_error(void) { return g_herr.c_str(); }
+
+// ---- ScalerNode host half, for the Python tests ----
+// strategy PA: out = {shift, scale, open_pore_adjustment, scale_pa, shift_pa}
+int mibch_pa_read_scaling(int standardise, float mean, float stdev, float scaling, float offset,
+                          float open_pore_level, const char *flow_cell_product_code, float *out5) {
+    try {
+        SignalNormalisationParams p;
+        p.strategy = ScalingStrategy::PA;
+        p.standardisation = {standardise != 0, mean, stdev};
+        ReadCalibration cal{scaling, offset, open_pore_level, flow_cell_product_code ? flow_cell_product_code : ""};
+        const ReadScaling r = pa_read_scaling(p, cal);
+        out5[0] = r.shift; out5[1] = r.scale; out5[2] = r.open_pore_adjustment; out5[3] = r.scale_pa; out5[4] = r.shift_pa;
+        return 0;
+    } catch (const std::exception &e) {
+        g_herr = e.what();
+        return -1;
+    }
+}
+int mibch_trim_signal(const uint16_t *f16, int n, float threshold, int window_size, int min_elements) {
+    return trim_signal(f16, n, threshold, window_size, min_elements);
+}
+int mibch_dna_trim_start(int standardise, const uint16_t *f16, uint64_t n) {
+    SignalNormalisationParams p;
+    p.standardisation.standardise = standardise != 0;
+    return dna_trim_start(p, f16, size_t(n));
+}
+
+// Whole raw reads (int16) with per-read (shift, scale, trim_start): ScalerNode's host half decides the
+// parameters, the samples are scaled on the device.  Same outputs as mibch_basecall_reads.
+int mibch_basecall_raw_reads(const mibc_model_desc *desc, const float *const *weights, int n_weights,
+                             const char *device_string, int num_runners, int chunk_size, int overlap,
+                             int batch_size, const mibc_decode_opts *opts, const int16_t *signals,
+                             const int64_t *read_len, const float *shift_scale, const int64_t *trim_start,
+                             int n_reads, char *seq_out, char *qstr_out, int64_t *seq_len_out,
+                             uint8_t *moves_out, int64_t *moves_len_out, int64_t *offsets_out,
+                             int64_t *n_offsets_out, double *stats4) {
+    try {
+        int stride = 1;
+        for (int i = 0; i < desc->n_convs; ++i) stride *= desc->conv_stride[i];
+        auto per_dev = create_basecall_runners(*desc, weights, n_weights, device_string, num_runners,
+                                               chunk_size, batch_size, *opts);
+        std::vector<RunnerPtr> flat;
+        for (auto &d : per_dev)
+            for (auto &r : d) flat.push_back(std::move(r));
+        SimplexBasecaller node(std::move(flat), overlap, stride);
+        std::vector<SimplexBasecaller::RawRead> reads;
+        size_t pos = 0;
+        for (int r = 0; r < n_reads; ++r) {
+            const size_t ts = size_t(trim_start[r]);
+            reads.push_back({signals + pos + ts, size_t(read_len[r]) - ts, shift_scale[2 * r], shift_scale[2 * r + 1]});
+            pos += size_t(read_len[r]);
+        }
+        auto called = node.basecall_raw(reads);
+        size_t so = 0, mo = 0, oo = 0;
+        for (int r = 0; r < n_reads; ++r) {
+            const auto &c = called[size_t(r)];
+            std::memcpy(seq_out + so, c.seq.data(), c.seq.size());
+            std::memcpy(qstr_out + so, c.qstring.data(), c.qstring.size());
+            so += c.seq.size();
+            seq_len_out[r] = int64_t(c.seq.size());
+            std::memcpy(moves_out + mo, c.moves.data(), c.moves.size());
+            mo += c.moves.size();
+            moves_len_out[r] = int64_t(c.moves.size());
+            for (size_t o : c.chunk_offsets) offsets_out[oo++] = int64_t(o);
+            n_offsets_out[r] = int64_t(c.chunk_offsets.size());
+        }
+        auto st = node.sample_stats();
+        stats4[0] = st["samples_processed"];
+        stats4[1] = st["samples_incl_padding"];
+        stats4[2] = st["batches_called"];
+        stats4[3] = st["partial_batches_called"];
+        return 0;
+    } catch (const std::exception &e) {
+        g_herr = e.what();
+        return -1;
+    }
+}
 
 long mibch_generate_chunks(uint64_t num_samples, uint64_t chunk_size, uint64_t stride, uint64_t overlap,
                            uint64_t *out, long max_out) {

@@ -10,6 +10,10 @@
 //                     one GPU thread, stats, terminate/restart)
 //   create_basecall_runners  dorado/api/runner_creation.cpp:46-133 ([device][runner] order)
 //   generate_chunks / stitch_chunks  dorado/read_pipeline/base/{chunk,stitch}.cpp
+//   ScalerNode (host half)  dorado/read_pipeline/nodes/ScalerNode.cpp:144-269: scaling parameters of a
+//                     read (PA strategy: closed formula; quantile / med_mad: mibc_scaler_stats on the
+//                     device), open-pore table, signal trim.  The sample-wise map itself runs on the
+//                     device, fused into conv1 (accept_chunk_i16 -> mibc_call_i16).
 //   SimplexBasecaller  the chunk -> batch -> call -> stitch loop of
 //                     dorado/read_pipeline/nodes/BasecallerNode.cpp:96-171,289-457,205-287
 //                     (one worker thread per runner, repeat-padding of short tails)
@@ -23,6 +27,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <optional>
 #include <string>
 #include <thread>
 #include <utility>
@@ -78,6 +83,53 @@ struct StitchedRead {
 StitchedRead stitch_chunks(const std::vector<const Chunk *> &called_chunks, size_t raw_samples,
                            int model_stride);  // stitch.cpp:12-96
 
+// ---- ScalerNode, host half ------------------------------------------------------
+// config/include/config/BasecallModelConfig.h:13-44
+enum class ScalingStrategy { MED_MAD, QUANTILE, PA };
+struct StandardisationScalingParams {
+    bool standardise = false;
+    float mean = 0.0f;
+    float stdev = 1.0f;
+};
+struct QuantileScalingParams {
+    float quantile_a = 0.2f;
+    float quantile_b = 0.9f;
+    float shift_multiplier = 0.51f;
+    float scale_multiplier = 0.53f;
+};
+struct SignalNormalisationParams {
+    ScalingStrategy strategy = ScalingStrategy::QUANTILE;
+    QuantileScalingParams quantile;
+    StandardisationScalingParams standardisation;
+};
+// The calibration fields of SimplexRead that ScalerNode reads (messages.h: scaling, offset,
+// open_pore_level, read_common.flow_cell_product_code).
+struct ReadCalibration {
+    float scaling = 1.0f;
+    float offset = 0.0f;
+    float open_pore_level = __builtin_nanf("");
+    std::string flow_cell_product_code;
+};
+// What ScalerNode leaves on the read: x_scaled = f16((x - (shift + open_pore_adjustment)) / scale),
+// read_common.scale / shift in pA, num_trimmed_samples.
+struct ReadScaling {
+    float shift = 0.0f, scale = 1.0f, open_pore_adjustment = 0.0f;
+    float scale_pa = 1.0f, shift_pa = 0.0f;   // ScalerNode.cpp:226-227
+    float device_shift() const { return shift + open_pore_adjustment; }  // the pair mibc_*_i16 takes
+};
+std::optional<float> expected_open_pore_level(const std::string &flow_cell_product_code);  // :112-139
+// Strategy PA (ScalerNode.cpp:186-215).  Throws std::invalid_argument for the data-driven strategies,
+// whose (shift, scale) come from mibc_scaler_stats on the device.
+ReadScaling pa_read_scaling(const SignalNormalisationParams &p, const ReadCalibration &cal);
+// ScalerNode.cpp:226-227 applied to a (shift, scale) pair obtained on the device.
+ReadScaling finish_read_scaling(float shift, float scale, const ReadCalibration &cal);
+// torch_utils/trim.cpp:23-60 on a scaled f16 signal prefix; defaults = trim.h:17-19.
+int trim_signal(const uint16_t *signal_f16, int n, float threshold = 2.4f, int window_size = 40,
+                int min_elements = 3);
+// The DNA branch of ScalerNode.cpp:231-254: 10 for standardised models, else trim() over the first
+// min(8000, n/2) scaled samples; 0 when the trim would swallow the read.
+int dna_trim_start(const SignalNormalisationParams &p, const uint16_t *scaled_f16, size_t n_samples);
+
 class HipCaller {
 public:
     HipCaller(const mibc_model_desc &desc, const float *const *weights, int n_weights, int device,
@@ -86,6 +138,12 @@ public:
     // Blocks until decoded (CudaCaller::call_chunks, CudaCaller.cpp:224-271).
     // in: pinned f16 [batch][chunk]; out: pinned int8 [3][batch][T].
     std::vector<DecodedChunk> call_chunks(const uint16_t *in_pinned, int8_t *out_pinned, int num_chunks);
+    // Raw int16 batch + pinned [batch][2] (shift, scale): scaling fused into conv1 (mibc_call_i16).
+    std::vector<DecodedChunk> call_chunks_i16(const int16_t *in_pinned, const float *shift_scale_pinned,
+                                              int8_t *out_pinned, int num_chunks);
+    // Per-read (shift, scale) of the QUANTILE / MED_MAD strategies on the device (mibc_scaler_stats).
+    std::vector<std::pair<float, float>> scaler_stats(const std::vector<std::pair<const int16_t *, size_t>> &reads,
+                                                      const SignalNormalisationParams &p);
     void terminate();
     void restart();
     const mibc_model_desc &config() const { return m_desc; }
@@ -100,6 +158,7 @@ public:
 private:
     struct NNTask {
         const uint16_t *in;
+        const float *ss = nullptr;   // non-null: `in` holds raw int16 samples
         int8_t *out;
         int num_chunks;
         int rc = 0;
@@ -109,6 +168,8 @@ private:
     };
     void start_thread();
     void gpu_thread_fn();
+    std::vector<DecodedChunk> submit(const uint16_t *in, const float *ss, int8_t *out, int num_chunks);
+    std::mutex m_engine_mutex;  // the engine (one stream) is used by the GPU thread and by scaler_stats
     mibc_model_desc m_desc;
     mibc_decode_opts m_opts;
     mibc_engine *m_engine = nullptr;
@@ -127,6 +188,9 @@ public:
     explicit HipModelRunner(std::shared_ptr<HipCaller> caller);
     ~HipModelRunner() override;
     void accept_chunk(int chunk_idx, const uint16_t *chunk_f16, size_t n_samples) override;
+    // Raw ADC samples of one chunk + its read's (shift, scale): the batch is then scaled on the device.
+    // A batch is either all-f16 or all-int16 (the mode resets after every call_chunks).
+    void accept_chunk_i16(int chunk_idx, const int16_t *chunk_raw, size_t n_samples, float shift, float scale);
     std::vector<DecodedChunk> call_chunks(int num_chunks) override;
     const mibc_model_desc &config() const override { return m_caller->config(); }
     size_t chunk_size() const override { return size_t(m_caller->chunk_size()); }
@@ -140,7 +204,9 @@ public:
 private:
     std::shared_ptr<HipCaller> m_caller;
     uint16_t *m_in = nullptr;  // pinned [batch][chunk]
+    float *m_ss = nullptr;     // pinned [batch][2]
     int8_t *m_out = nullptr;   // pinned [3][batch][T]
+    int m_mode = 0;            // 0 undecided, 1 f16 chunks, 2 raw int16 chunks
     int m_id;
     std::atomic<int64_t> m_batches{0};
 };
@@ -164,9 +230,25 @@ class SimplexBasecaller {
 public:
     SimplexBasecaller(std::vector<RunnerPtr> runners, int overlap, int model_stride);
     std::vector<CalledRead> basecall(const std::vector<std::vector<uint16_t>> &reads_f16);
+    // Raw reads: int16 ADC samples (already cut at the read's trim_start) + the read's device
+    // (shift, scale) pair = ReadScaling::device_shift(), ReadScaling::scale; scaling happens inside the
+    // engine's first convolution (HipModelRunner::accept_chunk_i16).
+    struct RawRead {
+        const int16_t *signal;
+        size_t n_samples;
+        float shift, scale;
+    };
+    std::vector<CalledRead> basecall_raw(const std::vector<RawRead> &reads);
     NamedStats sample_stats() const;
 
 private:
+    struct ReadView {
+        const uint16_t *data;   // f16 bits or raw int16 bits
+        size_t n;
+        bool raw;
+        float shift, scale;
+    };
+    std::vector<CalledRead> basecall_views(const std::vector<ReadView> &reads);
     std::vector<RunnerPtr> m_runners;
     int m_overlap, m_stride;
     std::atomic<int64_t> m_samples_processed{0}, m_samples_incl_padding{0}, m_batches{0},

@@ -115,3 +115,70 @@ def basecall_reads(cfg: ModelConfig, weights, reads_f16, device="hip:0", num_run
         so += int(sl[r]); mo += int(ml[r]); oo += int(noff[r])
     return out, {"samples_processed": stats[0], "samples_incl_padding": stats[1],
                  "batches_called": stats[2], "partial_batches_called": stats[3]}
+
+
+# ---------------------------------------------------------------- ScalerNode host half
+def pa_read_scaling(standardise, mean, stdev, scaling, offset, open_pore_level=float("nan"),
+                    flow_cell_product_code=""):
+    """ScalerNode.cpp:186-227 (strategy PA) -> dict(shift, scale, open_pore_adjustment, scale_pa, shift_pa)."""
+    out = (C.c_float * 5)()
+    rc = lib().mibch_pa_read_scaling(C.c_int(int(standardise)), C.c_float(mean), C.c_float(stdev),
+                                     C.c_float(scaling), C.c_float(offset), C.c_float(open_pore_level),
+                                     flow_cell_product_code.encode(), out)
+    if rc != 0:
+        raise ValueError(lib().mibch_last_error().decode())
+    return dict(zip(("shift", "scale", "open_pore_adjustment", "scale_pa", "shift_pa"), [float(v) for v in out]))
+
+
+def trim_signal(scaled_f16, threshold=2.4, window_size=40, min_elements=3):
+    s = np.ascontiguousarray(scaled_f16, np.float16)
+    return int(lib().mibch_trim_signal(s.ctypes.data_as(C.c_void_p), C.c_int(s.size), C.c_float(threshold),
+                                       C.c_int(window_size), C.c_int(min_elements)))
+
+
+def dna_trim_start(standardise, scaled_f16):
+    s = np.ascontiguousarray(scaled_f16, np.float16)
+    return int(lib().mibch_dna_trim_start(C.c_int(int(standardise)), s.ctypes.data_as(C.c_void_p),
+                                          C.c_uint64(s.size)))
+
+
+def basecall_raw_reads(cfg: ModelConfig, weights, reads_i16, shift_scale, trim_start=None, device="hip:0",
+                       num_runners=2, batch_size=64, beam_width=32):
+    """reads_i16: list of RAW int16 reads; shift_scale [n,2]; trim_start [n] samples cut from the front
+    (ScalerNode's num_trimmed_samples).  Scaling runs on the device, fused into conv1."""
+    L = lib()
+    d = cfg.to_desc()
+    ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+    arr = (C.POINTER(C.c_float) * len(ws))(*[w.ctypes.data_as(C.POINTER(C.c_float)) for w in ws])
+    opts = capi.DecodeOptsC(beam_width, 100.0, 2.0, cfg.qbias, cfg.qscale)
+    sig = np.ascontiguousarray(np.concatenate(reads_i16).astype(np.int16))
+    lens = np.array([len(r) for r in reads_i16], np.int64)
+    n = len(reads_i16)
+    ss = np.ascontiguousarray(shift_scale, np.float32).reshape(n, 2)
+    ts = np.zeros(n, np.int64) if trim_start is None else np.ascontiguousarray(trim_start, np.int64)
+    tot_steps = int(sum(l // cfg.stride + 2 for l in lens))
+    seq = C.create_string_buffer(tot_steps + 8)
+    qs = C.create_string_buffer(tot_steps + 8)
+    mv = np.zeros(tot_steps + 8, np.uint8)
+    sl = np.zeros(n, np.int64)
+    ml = np.zeros(n, np.int64)
+    max_off = int(sum(l // (cfg.chunk_size - cfg.overlap) + 3 for l in lens))
+    offs = np.zeros(max_off, np.int64)
+    noff = np.zeros(n, np.int64)
+    stats = (C.c_double * 4)()
+    rc = L.mibch_basecall_raw_reads(C.byref(d), arr, len(ws), device.encode(), num_runners, cfg.chunk_size,
+                                    cfg.overlap, batch_size, C.byref(opts), sig.ctypes.data_as(C.c_void_p),
+                                    lens.ctypes.data_as(_i64p), ss.ctypes.data_as(C.c_void_p),
+                                    ts.ctypes.data_as(_i64p), n, seq, qs, sl.ctypes.data_as(_i64p),
+                                    mv.ctypes.data_as(_u8p), ml.ctypes.data_as(_i64p),
+                                    offs.ctypes.data_as(_i64p), noff.ctypes.data_as(_i64p), stats)
+    if rc != 0:
+        raise capi.MibcError(L.mibch_last_error().decode())
+    out = []
+    so = mo = oo = 0
+    for r in range(n):
+        out.append((seq.raw[so:so + sl[r]].decode(), qs.raw[so:so + sl[r]].decode(),
+                    mv[mo:mo + ml[r]].copy(), offs[oo:oo + noff[r]].tolist()))
+        so += int(sl[r]); mo += int(ml[r]); oo += int(noff[r])
+    return out, {"samples_processed": stats[0], "samples_incl_padding": stats[1],
+                 "batches_called": stats[2], "partial_batches_called": stats[3]}

@@ -117,6 +117,35 @@ int mibc_call(mibc_engine *e, const uint16_t *in_host, int N, int T_in,
                                     (CudaCaller::call_chunks, CudaCaller.cpp:224-271) */
 int mibc_sync(mibc_engine *e);
 
+/* ---- signal scaling in front of the path (the device side of ScalerNode,
+ *      dorado/read_pipeline/nodes/ScalerNode.cpp:144-269) ----
+ * The reference scales each read on the host (int16 ADC -> f16((x - shift) / scale),
+ * torch_utils/tensor_utils.cpp:89-142) before chunking; these entry points take the raw int16 chunk
+ * rows instead, with ONE (shift, scale) pair per chunk (its read's), and apply the identical map
+ * (f32 subtract, IEEE divide, round-to-nearest-even to f16) inside the first convolution's input read.
+ * shift_scale: float [N][2]. */
+#define MIBC_SCALE_QUANTILE 0 /* ScalerNode.cpp:42-52 (normalisation), utils::quantile_counting */
+#define MIBC_SCALE_MED_MAD 1  /* ScalerNode.cpp:32-40 (med_mad) */
+int mibc_forward_i16(mibc_engine *e, const int16_t *in_dev, const float *shift_scale_dev, int N, int T_in,
+                     uint16_t *scores_dev);
+int mibc_call_device_i16(mibc_engine *e, const int16_t *in_dev, const float *shift_scale_dev, int N, int T_in,
+                         const mibc_decode_opts *opts, int8_t *out_dev);
+int mibc_call_i16(mibc_engine *e, const int16_t *in_host, const float *shift_scale_host, int N, int T_in,
+                  const mibc_decode_opts *opts, int8_t *out_host);
+/* Per-read (shift, scale) of the two data-driven strategies.  Reads are concatenated in sig_dev;
+ * read r = [offsets_dev[r], offsets_dev[r+1]) (n_reads + 1 offsets).  params4 (quantile only) =
+ * {quantile_a, quantile_b, shift_multiplier, scale_multiplier} (config::QuantileScalingParams).
+ * raw_dev (optional, [n_reads][2]) receives (q_a, q_b) resp. (median, median |x - median|).
+ * Integer work, bit-exact with the reference.  (The PA strategy, ScalerNode.cpp:186-215, is a closed
+ * formula of the read's calibration and needs no pass over the samples: host side.) */
+int mibc_scaler_stats(mibc_engine *e, const int16_t *sig_dev, const int64_t *offsets_dev, int n_reads,
+                      int strategy, const float *params4, float *shift_scale_dev, float *raw_dev);
+/* Whole reads: out[i] = f16((float(x[i]) - shift_r) / scale_r); replaces
+ * utils::shift_scale_tensor_i16_to_f16_inplace for callers that want the scaled read back
+ * (e.g. for the signal trim, torch_utils/trim.cpp). */
+int mibc_scale_reads(mibc_engine *e, const int16_t *sig_dev, const int64_t *offsets_dev, int n_reads,
+                     const float *shift_scale_dev, uint16_t *out_f16_dev);
+
 /* ---- measurement (replaces CudaCaller.cpp:552-569 timing + gpu_profiling.h ranges) ---- */
 int mibc_time_forward(mibc_engine *e, int N, int T_in, float *ms); /* min of 2 runs, like :552-569 */
 int mibc_get_stage_ms(mibc_engine *e, mibc_stage_ms *out);         /* hipEvent times, last call */

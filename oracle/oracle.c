@@ -851,6 +851,179 @@ ORC_API void orc_decode_batch(const float *scores, int N, int T, int K, int beam
 }
 
 /* ------------------------------------------------------------------------------------------
+ * f1: signal scaling in front of the path — ScalerNode.
+ * ---------------------------------------------------------------------------------------- */
+
+/* f32 -> f16 bit pattern, round to nearest even (what at::Half / _mm256_cvtps_ph do). */
+static uint16_t f32_to_f16_bits(float f) {
+    const uint32_t x = f_to_bits(f);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) { /* inf / nan */
+        return (uint16_t)(sign | 0x7c00u | ((ax > 0x7f800000u) ? 0x0200u : 0u));
+    }
+    if (ax >= 0x477ff000u) { /* >= 65520 rounds to inf */
+        return (uint16_t)(sign | 0x7c00u);
+    }
+    if (ax < 0x33000001u) { /* <= 2^-25: rounds to zero (ties-to-even at exactly 2^-25) */
+        return (uint16_t)sign;
+    }
+    int e = (int)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x007fffffu) | 0x00800000u; /* 24-bit significand */
+    int shift;                                    /* bits to drop */
+    uint32_t he;
+    if (e < -14) { /* subnormal half */
+        shift = 13 + (-14 - e);
+        he = 0;
+    } else {
+        shift = 13;
+        he = (uint32_t)(e + 15);
+    }
+    const uint32_t kept = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u);
+    const uint32_t half = 1u << (shift - 1);
+    uint32_t r = kept;
+    if (rem > half || (rem == half && (kept & 1u))) r += 1u;
+    uint32_t h;
+    if (he == 0) {
+        h = r; /* may carry into the exponent field: correct (becomes the smallest normal) */
+    } else {
+        h = ((he - 1u) << 10) + r; /* r includes the hidden bit (0x400) */
+    }
+    return (uint16_t)(sign | h);
+}
+
+ORC_API uint16_t orc_f32_to_f16_bits(float f) { return f32_to_f16_bits(f); }
+
+/* torch_utils/tensor_utils.cpp:89-142: x -> f16((float(x) - shift) / scale), f32 arithmetic. */
+ORC_API void orc_shift_scale_i16_to_f16(const int16_t *x, long n, float shift, float scale,
+                                        uint16_t *out) {
+    for (long i = 0; i < n; ++i) {
+        const float v = ((float)x[i] - shift) / scale;
+        out[i] = f32_to_f16_bits(v);
+    }
+}
+
+/* torch_utils/tensor_utils.cpp:217-245: "lower" quantiles of an int16 signal by counting.
+ * out[i] = smallest value v with #(x <= v) > int(q[i] * (n - 1)). */
+ORC_API void orc_quantile_counting(const int16_t *x, long n, const float *q, int nq, float *out) {
+    int lo = x[0], hi = x[0];
+    for (long i = 1; i < n; ++i) {
+        lo = x[i] < lo ? x[i] : lo;
+        hi = x[i] > hi ? x[i] : hi;
+    }
+    const int nb = hi - lo + 1;
+    int *cnt = (int *)calloc((size_t)nb, sizeof(int));
+    for (long i = 0; i < n; ++i) cnt[x[i] - lo]++;
+    for (int i = 1; i < nb; ++i) cnt[i] += cnt[i - 1];
+    for (int k = 0; k < nq; ++k) {
+        const int thr = (int)(q[k] * (float)(n - 1)); /* float * size_t -> float, truncated */
+        for (int i = 0; i < nb; ++i) {
+            if (cnt[i] > thr) {
+                out[k] = (float)(i + lo);
+                break;
+            }
+        }
+    }
+    free(cnt);
+}
+
+/* read_pipeline/nodes/ScalerNode.cpp:32-40 (med_mad on the int16 tensor): torch's median is the
+ * LOWER median (sorted[(n-1)/2]); |x - med| is evaluated in int16 (wraps), its median again lower;
+ * mad = that * 1.4826f + 1e-9f in f32. */
+static int16_t lower_median_i16(const int16_t *x, long n) {
+    int *cnt = (int *)calloc(65536, sizeof(int));
+    for (long i = 0; i < n; ++i) cnt[(int)x[i] + 32768]++;
+    const long k = (n - 1) / 2;
+    long acc = 0;
+    int v = 0;
+    for (int i = 0; i < 65536; ++i) {
+        acc += cnt[i];
+        if (acc > k) {
+            v = i - 32768;
+            break;
+        }
+    }
+    free(cnt);
+    return (int16_t)v;
+}
+
+ORC_API void orc_med_mad(const int16_t *x, long n, float *med_out, float *mad_out) {
+    const int16_t med = lower_median_i16(x, n);
+    int16_t *d = (int16_t *)malloc((size_t)n * sizeof(int16_t));
+    for (long i = 0; i < n; ++i) {
+        const int16_t diff = (int16_t)((int)x[i] - (int)med); /* int16 arithmetic wraps */
+        d[i] = (int16_t)(diff < 0 ? -diff : diff);
+    }
+    const int16_t mad_i = lower_median_i16(d, n);
+    free(d);
+    *med_out = (float)med;
+    *mad_out = (float)mad_i * 1.4826f + 1e-9f;
+}
+
+/* ScalerNode.cpp:42-52 (normalisation): shift/scale from two quantiles. */
+ORC_API void orc_quantile_shift_scale(const int16_t *x, long n, float quantile_a, float quantile_b,
+                                      float shift_multiplier, float scale_multiplier, float *shift,
+                                      float *scale) {
+    const float q[2] = {quantile_a, quantile_b};
+    float r[2];
+    orc_quantile_counting(x, n, q, 2, r);
+    const float sh = shift_multiplier * (r[0] + r[1]);
+    const float sc = scale_multiplier * (r[1] - r[0]);
+    *shift = sh > 10.0f ? sh : 10.0f;
+    *scale = sc > 1.0f ? sc : 1.0f;
+}
+
+/* ScalerNode.cpp:186-215 (strategy PA): the read's calibration (scaling, offset) and the model's
+ * standardisation (mean, stdev) give the affine map x -> (x - shift) / scale; the open-pore
+ * adjustment (added to shift) is (open_pore_level - expected) / scaling when both are known.
+ * expected_open_pore_level <= 0 or a NaN open_pore_level mean "not available". */
+ORC_API void orc_pa_shift_scale(float scaling, float offset, int standardise, float mean, float stdev,
+                                float open_pore_level, float expected_open_pore_level, float *shift,
+                                float *scale, float *open_pore_adjustment) {
+    float sc, sh;
+    if (standardise) {
+        sc = stdev / scaling;
+        sh = (mean / scaling) - offset;
+    } else {
+        sc = 1.f / scaling;
+        sh = -1.f * offset;
+    }
+    float adj = 0.0f;
+    if (!isnan(open_pore_level) && expected_open_pore_level > 0.0f) {
+        adj = (open_pore_level - expected_open_pore_level) / scaling;
+    }
+    *shift = sh;
+    *scale = sc;
+    *open_pore_adjustment = adj;
+}
+
+/* torch_utils/trim.cpp:23-60: first window end after the initial peak. */
+ORC_API int orc_trim(const float *signal, int n, float threshold, int window_size, int min_elements) {
+    const int min_trim = 10;
+    const int num_samples = n - min_trim;
+    const int num_windows = num_samples / window_size;
+    int seen_peak = 0;
+    for (int pos = 0; pos < num_windows; ++pos) {
+        const int start = pos * window_size + min_trim;
+        const int end = start + window_size;
+        int cnt = 0;
+        for (int i = start; i < end; ++i) cnt += signal[i] > threshold;
+        if (cnt > min_elements || seen_peak) {
+            seen_peak = 1;
+            if (signal[end - 1] > threshold) {
+                continue;
+            }
+            if (end >= num_samples) {
+                return min_trim;
+            }
+            return end;
+        }
+    }
+    return min_trim;
+}
+
+/* ------------------------------------------------------------------------------------------
  * a5-a6: transformer model (sup@v5): conv stack -> TxEncoder x depth -> LinearUpsample ->
  * LinearScaledCRF.  Follows basecall/model/TxModel.cpp:20-41 and nn/TxModules.cpp.
  * ---------------------------------------------------------------------------------------- */

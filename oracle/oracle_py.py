@@ -217,3 +217,67 @@ def decode(scores_NTK, beam_width=32, beam_cut=100.0, blank=2.0, q_shift=0.0, q_
         L = int(lens[n])
         out.append((seq[n, :L].tobytes().decode(), qs[n, :L].tobytes().decode(), moves[n].copy()))
     return out
+
+
+# ---------------------------------------------------------------- f1: signal scaling (ScalerNode)
+_i16p = C.POINTER(C.c_int16)
+_u16p = C.POINTER(C.c_uint16)
+
+
+def shift_scale_i16_to_f16(x_i16, shift, scale, use_ref=False):
+    """f16((float(x) - shift) / scale) as np.float16 (tensor_utils.cpp:89-142)."""
+    x = np.ascontiguousarray(x_i16, np.int16)
+    out = np.empty(x.shape, np.uint16)
+    fn = ref().ref_shift_scale_i16_to_f16 if use_ref else lib().orc_shift_scale_i16_to_f16
+    fn(x.ctypes.data_as(_i16p), C.c_long(x.size), C.c_float(shift), C.c_float(scale),
+       out.ctypes.data_as(_u16p))
+    return out.view(np.float16)
+
+
+def quantile_counting(x_i16, q, use_ref=False):
+    x = np.ascontiguousarray(x_i16, np.int16)
+    qq = np.ascontiguousarray(q, np.float32)
+    out = np.empty(qq.size, np.float32)
+    fn = ref().ref_quantile_counting if use_ref else lib().orc_quantile_counting
+    fn(x.ctypes.data_as(_i16p), C.c_long(x.size), _fp(qq), C.c_int(qq.size), _fp(out))
+    return out
+
+
+def med_mad(x_i16, use_ref=False):
+    x = np.ascontiguousarray(x_i16, np.int16)
+    med, mad = C.c_float(), C.c_float()
+    fn = ref().ref_med_mad_expr if use_ref else lib().orc_med_mad
+    fn(x.ctypes.data_as(_i16p), C.c_long(x.size), C.byref(med), C.byref(mad))
+    return med.value, mad.value
+
+
+def quantile_shift_scale(x_i16, quantile_a, quantile_b, shift_multiplier, scale_multiplier):
+    x = np.ascontiguousarray(x_i16, np.int16)
+    sh, sc = C.c_float(), C.c_float()
+    lib().orc_quantile_shift_scale(x.ctypes.data_as(_i16p), C.c_long(x.size), C.c_float(quantile_a),
+                                   C.c_float(quantile_b), C.c_float(shift_multiplier),
+                                   C.c_float(scale_multiplier), C.byref(sh), C.byref(sc))
+    return sh.value, sc.value
+
+
+def pa_shift_scale(scaling, offset, standardise, mean, stdev, open_pore_level=float("nan"),
+                   expected_open_pore_level=0.0):
+    sh, sc, adj = C.c_float(), C.c_float(), C.c_float()
+    lib().orc_pa_shift_scale(C.c_float(scaling), C.c_float(offset), C.c_int(int(standardise)),
+                             C.c_float(mean), C.c_float(stdev), C.c_float(open_pore_level),
+                             C.c_float(expected_open_pore_level), C.byref(sh), C.byref(sc),
+                             C.byref(adj))
+    return sh.value, sc.value, adj.value
+
+
+def trim(signal_f32, threshold=2.4, window_size=40, min_elements=3):
+    s = np.ascontiguousarray(signal_f32, np.float32)
+    return int(lib().orc_trim(_fp(s), C.c_int(s.size), C.c_float(threshold), C.c_int(window_size),
+                              C.c_int(min_elements)))
+
+
+def trimtest_signal(n=2000):
+    """The input of tests/TrimTest.cpp "Test trim signal" regenerated by the compiled driver."""
+    out = np.empty(n, np.float32)
+    ref().ref_trimtest_signal(_fp(out), C.c_int(n))
+    return out

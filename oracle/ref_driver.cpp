@@ -15,11 +15,13 @@
 #include "basecall/model/TxModel.h"
 #include "config/BasecallModelConfig.h"
 #include "read_pipeline/base/chunk.h"
+#include "torch_utils/tensor_utils.h"
 
 #include <torch/torch.h>
 
 #include <cstdint>
 #include <cstring>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -273,6 +275,60 @@ int ref_generate_chunks(uint64_t num_samples, uint64_t chunk_size, uint64_t stri
         g_err = e.what();
         return -1;
     }
+}
+
+// ---- signal scaling: the reference's own utils, torch_utils/tensor_utils.cpp ----
+
+// utils::quantile_counting (tensor_utils.cpp:217-245)
+int ref_quantile_counting(const int16_t *x, long n, const float *q, int nq, float *out) {
+    try {
+        auto t = at::from_blob(const_cast<int16_t *>(x), {n}, at::kShort).clone();
+        auto qt = at::from_blob(const_cast<float *>(q), {nq}, at::kFloat).clone();
+        auto r = utils::quantile_counting(t, qt);
+        for (int i = 0; i < nq; ++i) out[i] = r[i].item<float>();
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// utils::shift_scale_tensor_i16_to_f16_inplace (tensor_utils.cpp:89-142); out = f16 bit patterns
+int ref_shift_scale_i16_to_f16(const int16_t *x, long n, float shift, float scale, uint16_t *out) {
+    try {
+        auto t = at::from_blob(const_cast<int16_t *>(x), {n}, at::kShort).clone();
+        utils::shift_scale_tensor_i16_to_f16_inplace(t, shift, scale);
+        std::memcpy(out, t.data_ptr(), size_t(n) * 2);
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// The expression of the file-local med_mad() in read_pipeline/nodes/ScalerNode.cpp:32-40, evaluated by
+// libtorch on the same dtypes (int16 tensor).  (ScalerNode.cpp itself needs the whole pipeline to link.)
+int ref_med_mad_expr(const int16_t *x, long n, float *med_out, float *mad_out) {
+    try {
+        auto t = at::from_blob(const_cast<int16_t *>(x), {n}, at::kShort).clone();
+        constexpr float factor = 1.4826f;
+        auto med = t.median();
+        auto mad = at::median(at::abs(t - med)) * factor + 1e-9f;
+        *med_out = med.item<float>();
+        *mad_out = mad.item<float>();
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// The input signal of tests/TrimTest.cpp:31-42 ("Test trim signal"): mt19937{42}, N(0,1), +5 on [1,55).
+void ref_trimtest_signal(float *out, int n) {
+    std::mt19937 gen{42};
+    std::normal_distribution<float> rng{0, 1};
+    for (int i = 0; i < n; ++i) out[i] = rng(gen);
+    for (int i = 1; i < 55 && i < n; ++i) out[i] += 5;
 }
 
 }  // extern "C"

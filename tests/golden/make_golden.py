@@ -89,9 +89,49 @@ def chunk_cases():
     print("chunks", len(rows))
 
 
+def scaler_cases():
+    """outputs of the reference's own utils (compiled in oracle/_ref) on seeded reads,
+    the expressions its tests pin them to (tests/TensorUtilsTest.cpp:44-63: torch.quantile 'lower';
+    :121-139: ((x.float() - shift) / scale).half()), and the TrimTest.cpp:31-93 signal + answers."""
+    import torch
+
+    rng = np.random.default_rng(31)
+    reads, q_ref, q_torch, mm_ref, ss, ss_ref = [], [], [], [], [], []
+    for i in range(12):
+        n = int(rng.integers(1, 40000)) if i else 1
+        base = rng.integers(200, 900)
+        x = (base + 90.0 * rng.standard_normal(n) + 40.0 * np.sin(np.arange(n) / 37.0)).astype(np.int16)
+        if i == 3:
+            x[::97] = 32767   # extreme values: wide counting range, int16 wrap in |x - med|
+            x[5::101] = -32768
+        qs = np.array([0.2, 0.9], np.float32)
+        reads.append(x)
+        q_ref.append(O.quantile_counting(x, qs, use_ref=True))
+        q_torch.append(torch.quantile(torch.from_numpy(x).float(), torch.from_numpy(qs), 0, False,
+                                      interpolation="lower").numpy())
+        mm_ref.append(O.med_mad(x, use_ref=True))
+        shift = float(rng.uniform(-100, 1000))
+        scale = float(rng.uniform(0.1, 200))
+        ss.append((shift, scale))
+        ss_ref.append(O.shift_scale_i16_to_f16(x, shift, scale, use_ref=True).view(np.uint16))
+        want = ((torch.from_numpy(x).float() - shift) / scale).half().numpy().view(np.uint16)
+        assert (ss_ref[-1] == want).all()
+    sig = O.trimtest_signal(2000)
+    np.savez_compressed(
+        os.path.join(OUT, "scaler.npz"),
+        lens=np.array([len(r) for r in reads], np.int64), signal=np.concatenate(reads),
+        quantiles_ref=np.array(q_ref, np.float32), quantiles_torch_lower=np.array(q_torch, np.float32),
+        med_mad_ref=np.array(mm_ref, np.float32), shift_scale=np.array(ss, np.float32),
+        scaled_f16_bits_ref=np.concatenate(ss_ref),
+        trim_signal=sig, trim_expected=np.array([90, 60, 10, 10], np.int32),
+    )
+    print("scaler", len(reads), "reads")
+
+
 if __name__ == "__main__":
     assert O.have_ref(), "build oracle/_ref first: make -C oracle -f Makefile.ref"
     chunk_cases()
+    scaler_cases()
     network_case("net_tiny64_s3", config.tiny(64, 3), N=3, T_in=1200, seed=11)
     network_case("net_tiny128_s4", config.tiny(128, 4), N=2, T_in=900, seed=12)
     network_case("net_tx_tiny", config.tiny_tx(), N=2, T_in=1536, seed=13)

@@ -307,3 +307,114 @@ def test_host_layer_whole_reads_vs_oracle_pipeline():
     print("whole-read identity vs f32 oracle pipeline:", np.round(ids, 3))
     assert np.mean(ids) >= 0.95
     eng.close()
+
+
+# ---------------------------------------------------------------- f1: ScalerNode on the device
+def _scaler_fixture():
+    g = np.load(os.path.join(GOLDEN, "scaler.npz"))
+    offs = np.concatenate([[0], np.cumsum(g["lens"])])
+    return g, [g["signal"][offs[i]:offs[i + 1]] for i in range(len(g["lens"]))], offs
+
+
+def test_scaler_stats_bit_exact():
+    """mibc_scaler_stats vs the reference fixture (utils::quantile_counting, med_mad) and the oracle:
+    integer work, exact — including the 1-sample read and the read with +-32767/-32768 outliers
+    (wide-range histogram path, int16 wrap of |x - med|)."""
+    g, reads, _ = _scaler_fixture()
+    cfg = config.tiny(128, 3)
+    eng = capi.Engine(cfg, synth.make_weights(cfg, seed=1))
+    ss, raw = eng.scaler_stats(reads, capi.SCALE_QUANTILE, (0.2, 0.9, 0.51, 0.53))
+    assert (raw == g["quantiles_ref"]).all()
+    for i, x in enumerate(reads):
+        sh, sc = O.quantile_shift_scale(x, 0.2, 0.9, 0.51, 0.53)
+        assert ss[i, 0] == np.float32(sh) and ss[i, 1] == np.float32(sc)
+    ss2, raw2 = eng.scaler_stats(reads, capi.SCALE_MED_MAD)
+    assert (raw2[:, 0] == g["med_mad_ref"][:, 0]).all()
+    assert (ss2[:, 1] == g["med_mad_ref"][:, 1]).all()      # mad * 1.4826f + 1e-9f, bit-exact
+    assert (ss2[:, 0] == g["med_mad_ref"][:, 0]).all()
+    # size-independent property on a large synthetic read set: quantiles are order statistics
+    rng = np.random.default_rng(5)
+    big = [(400 + 80 * rng.standard_normal(int(n))).astype(np.int16) for n in rng.integers(1000, 400000, 40)]
+    _, rawb = eng.scaler_stats(big, capi.SCALE_QUANTILE, (0.2, 0.9, 0.51, 0.53))
+    for x, (qa, qb) in zip(big, rawb):
+        srt = np.sort(x)
+        assert qa == srt[int(np.float32(0.2) * np.float32(len(x) - 1))]
+        assert qb == srt[int(np.float32(0.9) * np.float32(len(x) - 1))]
+    eng.close()
+
+
+def test_scale_reads_bit_exact():
+    """mibc_scale_reads == utils::shift_scale_tensor_i16_to_f16_inplace bit for bit (the reference's
+    own test demands rtol = atol = 0, tests/TensorUtilsTest.cpp:121-139)."""
+    g, reads, offs = _scaler_fixture()
+    cfg = config.tiny(128, 3)
+    eng = capi.Engine(cfg, synth.make_weights(cfg, seed=1))
+    got = eng.scale_reads(reads, g["shift_scale"])
+    for i in range(len(reads)):
+        assert (got[i].view(np.uint16) == g["scaled_f16_bits_ref"][offs[i]:offs[i + 1]]).all()
+    # ragged large case vs the oracle restatement
+    rng = np.random.default_rng(9)
+    big = [rng.integers(-600, 3000, int(n)).astype(np.int16) for n in rng.integers(1, 300000, 25)]
+    ssb = np.stack([rng.uniform(-50, 900, 25), rng.uniform(0.2, 150, 25)], 1).astype(np.float32)
+    gb = eng.scale_reads(big, ssb)
+    for x, (sh, sc), y in zip(big, ssb, gb):
+        assert (y.view(np.uint16) == O.shift_scale_i16_to_f16(x, float(sh), float(sc)).view(np.uint16)).all()
+    eng.close()
+
+
+@pytest.mark.parametrize("model", ["lstm", "tx"])
+def test_fused_int16_input_equals_prescaled_f16(model):
+    """mibc_*_i16 (raw int16 chunks + per-chunk shift/scale, scaling fused into conv1's read) must give
+    exactly the scores / calls of feeding the reference-scaled f16 chunks — the fused map is the same
+    IEEE sequence, so the network sees bit-identical inputs."""
+    if model == "lstm":
+        cfg = config.tiny(128, 4)
+        N, T_in = 64, 1200
+    else:
+        cfg = config.tiny_tx()
+        N, T_in = 4, 1536
+    ws = synth.make_weights(cfg, seed=3)
+    rng = np.random.default_rng(12)
+    raw = (480 + 95 * synth.make_signal(N, T_in, seed=4).astype(np.float32)).astype(np.int16)
+    ss = np.stack([rng.uniform(380, 560, N), rng.uniform(60, 130, N)], 1).astype(np.float32)
+    x16 = np.stack([O.shift_scale_i16_to_f16(raw[i], float(ss[i, 0]), float(ss[i, 1])) for i in range(N)])
+    eng = capi.Engine(cfg, ws)
+    s_ref = eng.forward(x16)
+    s_i16 = eng.forward_i16(raw, ss)
+    assert (s_ref.view(np.uint16) == s_i16.view(np.uint16)).all()
+    calls_ref = eng.call(x16)
+    calls_i16 = eng.call_i16(raw, ss)
+    for (a, qa, ma), (b, qb, mb) in zip(calls_ref, calls_i16):
+        assert a == b and qa == qb and (ma == mb).all()
+    eng.close()
+
+
+def test_host_layer_raw_reads_equal_prescaled_reads():
+    """Whole raw int16 reads through the C++ host layer (HipModelRunner::accept_chunk_i16 ->
+    mibc_call_i16) == the reference order of operations: scale the read on the CPU (oracle of
+    utils::shift_scale_tensor_i16_to_f16_inplace), cut trim_start samples (ScalerNode.cpp:231-254),
+    chunk, call.  PA-standardised parameters from the host mirror of ScalerNode.cpp:186-227."""
+    cfg = _cfg(128, 4, 5)
+    cfg.chunk_size, cfg.overlap = 1200, 120
+    cfg.normalise_basecaller_params()
+    ws = synth.make_weights(cfg, seed=41)
+    lens = [300, 1210, 2500, 3343, 5010, 809, 4106, 1200 + 10]
+    rng = np.random.default_rng(77)
+    raws, ss, ts = [], [], []
+    for i, L in enumerate(lens):
+        scaling, offset = float(rng.uniform(0.14, 0.2)), float(rng.integers(-260, -200))
+        pa = 93.7 + 23.4 * synth.make_signal(1, L, seed=200 + i)[0].astype(np.float32)
+        raws.append(np.round(pa / scaling - offset).astype(np.int16))
+        sc = hostapi.pa_read_scaling(True, 93.69, 23.5, scaling, offset, 203.0 + i, "FLO-PRO114M")
+        ss.append((sc["shift"] + sc["open_pore_adjustment"], sc["scale"]))
+        ts.append(10)                                   # standardised models: constant trim
+    ss = np.array(ss, np.float32)
+    got, stats = hostapi.basecall_raw_reads(cfg, ws, raws, ss, ts, device="hip:0", num_runners=2, batch_size=64)
+    pre = [O.shift_scale_i16_to_f16(r, float(s[0]), float(s[1]))[t:] for r, s, t in zip(raws, ss, ts)]
+    assert all(hostapi.dna_trim_start(True, O.shift_scale_i16_to_f16(r, float(s[0]), float(s[1]))) == 10
+               for r, s in zip(raws, ss))
+    want, _ = hostapi.basecall_reads(cfg, ws, pre, device="hip:0", num_runners=2, batch_size=64)
+    assert stats["samples_processed"] == sum(lens) - 10 * len(lens)
+    for g, w in zip(got, want):
+        assert g[0] == w[0] and g[1] == w[1] and (g[2] == w[2]).all() and g[3] == w[3]
+    assert sum(len(g[0]) for g in got) > 500

@@ -163,3 +163,39 @@ def test_two_process_gloo_replicas(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "OK 2 101.0 2.0" in out.stdout
+
+
+# ---------------------------------------------------------------- ScalerNode host half
+def test_scaler_host_pa_formula_matches_oracle():
+    """ScalerNode.cpp:186-227: host mirror == oracle restatement, incl. the open-pore adjustment table."""
+    from oracle import oracle_py as O
+
+    for std, mean, stdev, scaling, offset, opl, fc, expected in [
+        (1, 93.69, 23.5, 0.1755, -243.0, float("nan"), "", None),
+        (1, 93.69, 23.5, 0.1755, -243.0, 205.0, "FLO-PRO114M", 199.21),
+        (0, 0.0, 1.0, 0.2, 12.0, 190.0, "flo-min114", 197.61),      # case-insensitive lookup
+        (1, 90.0, 20.0, 0.15, -250.0, 201.0, "FLO-UNKNOWN", None),
+    ]:
+        got = hostapi.pa_read_scaling(std, mean, stdev, scaling, offset, opl, fc)
+        sh, sc, adj = O.pa_shift_scale(scaling, offset, std, mean, stdev, opl, expected or 0.0)
+        assert got["shift"] == np.float32(sh) and got["scale"] == np.float32(sc)
+        assert got["open_pore_adjustment"] == np.float32(adj)
+        assert got["scale_pa"] == np.float32(np.float32(scaling) * np.float32(sc))
+        assert got["shift_pa"] == np.float32(np.float32(scaling) * (np.float32(sh) + np.float32(offset)))
+
+
+def test_scaler_host_trim_known_answers():
+    """tests/TrimTest.cpp:31-93 through the host mirror (operating on the f16 signal the pipeline holds)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scaler.npz"))
+    sig = g["trim_signal"].astype(np.float16)
+    from oracle import oracle_py as O
+
+    for args in [(2.4, 40, 3), (2.4, 10, 3), (24.0, 40, 3)]:
+        assert hostapi.trim_signal(sig, *args) == O.trim(sig.astype(np.float32), *args)
+    assert hostapi.trim_signal(sig) == 90
+    assert hostapi.trim_signal(sig, 2.4, 10, 3) == 60
+    assert hostapi.trim_signal(sig, 24.0, 40, 3) == 10
+    assert hostapi.trim_signal(np.full(2000, 100.0, np.float16), 24.0, 40, 3) == 10
+    assert hostapi.dna_trim_start(True, sig) == 10                      # standardised models: constant
+    assert hostapi.dna_trim_start(False, sig) == 90
+    assert hostapi.dna_trim_start(True, sig[:8]) == 0                   # trim would swallow the read

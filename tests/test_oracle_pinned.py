@@ -154,6 +154,75 @@ def test_det_math_accuracy():
         assert abs(L.orc_det_logf(float(x)) - np.log(np.float64(x))) <= 3e-7 * max(1.0, abs(np.log(np.float64(x))))
 
 
+# ---------------------------------------------------------------- f1: ScalerNode
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _scaler_reads():
+    g = np.load(os.path.join(GOLD, "scaler.npz"))
+    offs = np.concatenate([[0], np.cumsum(g["lens"])])
+    return g, [g["signal"][offs[i]:offs[i + 1]] for i in range(len(g["lens"]))], offs
+
+
+def test_scaler_quantiles_pinned():
+    """tensor_utils.cpp:217-245 == torch.quantile(..., 'lower') on int16 data — the identity the
+    reference's own test asserts (tests/TensorUtilsTest.cpp:44-63) — and == the compiled reference."""
+    g, reads, _ = _scaler_reads()
+    for i, x in enumerate(reads):
+        got = O.quantile_counting(x, [0.2, 0.9])
+        assert (got == g["quantiles_ref"][i]).all()
+        assert (got == g["quantiles_torch_lower"][i]).all()
+
+
+def test_scaler_med_mad_pinned():
+    g, reads, _ = _scaler_reads()
+    for i, x in enumerate(reads):
+        med, mad = O.med_mad(x)
+        assert med == g["med_mad_ref"][i][0]
+        assert np.float32(mad) == g["med_mad_ref"][i][1]
+
+
+def test_scaler_shift_scale_pinned():
+    """Bit-exact f16 (tests/TensorUtilsTest.cpp:121-139 demands rtol = atol = 0)."""
+    g, reads, offs = _scaler_reads()
+    for i, x in enumerate(reads):
+        shift, scale = g["shift_scale"][i]
+        got = O.shift_scale_i16_to_f16(x, float(shift), float(scale)).view(np.uint16)
+        assert (got == g["scaled_f16_bits_ref"][offs[i]:offs[i + 1]]).all()
+
+
+def test_scaler_trim_known_answers():
+    """tests/TrimTest.cpp:31-93: default 90, window 10 -> 60, nothing above 24 -> 10, all above -> 10,
+    peak beyond the inspected prefix -> 10."""
+    g = np.load(os.path.join(GOLD, "scaler.npz"))
+    sig = g["trim_signal"].copy()
+    assert O.trim(sig) == 90
+    assert O.trim(sig, 2.4, 10, 3) == 60
+    assert O.trim(sig, 24.0, 40, 3) == 10
+    assert O.trim(np.full(2000, 100.0, np.float32), 24.0, 40, 3) == 10
+    sig[500:555] += 50
+    assert O.trim(sig[:400], 24.0, 40, 3) == 10
+
+
+def test_scaler_pa_formula():
+    """ScalerNode.cpp:186-215: (x - shift)/scale == ((x + offset) * scaling - mean) / stdev."""
+    sh, sc, adj = O.pa_shift_scale(0.1755, -243.0, True, 93.69, 23.5)
+    x = np.arange(-400, 2000, 7, dtype=np.float64)
+    want = ((x - 243.0) * 0.1755 - 93.69) / 23.5
+    got = (x - sh) / sc
+    assert np.abs(got - want).max() < 2e-4
+    assert adj == 0.0
+    sh2, sc2, adj2 = O.pa_shift_scale(0.1755, -243.0, False, 0.0, 1.0, 205.0, 199.21)
+    assert sc2 == np.float32(1.0) / np.float32(0.1755) and sh2 == 243.0
+    assert abs(adj2 - (205.0 - 199.21) / 0.1755) < 1e-4
+    if O.have_ref():
+        g, reads, _ = _scaler_reads()
+        for x in reads[:4]:
+            assert (O.quantile_counting(x, [0.25, 0.5, 0.75]) ==
+                    O.quantile_counting(x, [0.25, 0.5, 0.75], use_ref=True)).all()
+            assert O.med_mad(x) == O.med_mad(x, use_ref=True)
+
+
 # ---------------------------------------------------------------- live vs compiled reference
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
 def test_live_against_compiled_reference():
