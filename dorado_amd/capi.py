@@ -45,6 +45,7 @@ EXPORTS = [
     "mibc_memcpy_d2h", "mibc_forward", "mibc_decode", "mibc_call_device", "mibc_call",
     "mibc_sync", "mibc_time_forward", "mibc_get_stage_ms", "mibc_set_profile", "mibc_debug_tap",
     "mibc_forward_i16", "mibc_call_device_i16", "mibc_call_i16", "mibc_scaler_stats", "mibc_scale_reads",
+    "mibc_svb16_decode",
 ]
 
 SCALE_QUANTILE = 0
@@ -111,6 +112,8 @@ def lib():
         L.mibc_scaler_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                         C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
         L.mibc_scale_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.mibc_svb16_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_void_p]
         _lib = L
     return _lib
 
@@ -363,6 +366,38 @@ class Engine:
             for q in (d_sig, d_off, d_ss, d_out):
                 self.device_free(q)
         return [out[off[i]:off[i + 1]] for i in range(n)]
+
+    # -- f2: POD5 VBZ (svb16 stage) on the device
+    def svb16_decode(self, streams, n_samples):
+        """streams: list of inflated (post-zstd) signal rows (bytes / uint8 arrays); n_samples: values per row.
+        Returns (list of int16 arrays, status int32[n_rows]) decoded by mibc_svb16_decode."""
+        rows = [np.frombuffer(s, np.uint8) if isinstance(s, (bytes, bytearray, memoryview)) else
+                np.ascontiguousarray(s, np.uint8) for s in streams]
+        n = len(rows)
+        soff = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+        noff = np.concatenate([[0], np.cumsum(n_samples)]).astype(np.int64)
+        blob = np.concatenate(rows) if n else np.zeros(0, np.uint8)
+        d_b = self.device_alloc(max(blob.nbytes, 16))
+        d_so, d_no = self.device_alloc(soff.nbytes), self.device_alloc(noff.nbytes)
+        d_out = self.device_alloc(max(int(noff[-1]) * 2, 16))
+        d_st = self.device_alloc(max(n, 1) * 4)
+        try:
+            if blob.nbytes:
+                self.h2d(d_b, blob)
+            self.h2d(d_so, soff)
+            self.h2d(d_no, noff)
+            self._check(lib().mibc_svb16_decode(self._h, d_b, d_so, d_no, n, d_out, d_st), "mibc_svb16_decode")
+            self.sync()
+            out = np.zeros(int(noff[-1]), np.int16)
+            st = np.zeros(n, np.int32)
+            if out.size:
+                self.d2h(out, d_out)
+            if n:
+                self.d2h(st, d_st)
+        finally:
+            for q in (d_b, d_so, d_no, d_out, d_st):
+                self.device_free(q)
+        return [out[noff[i]:noff[i + 1]] for i in range(n)], st
 
 
 def unpack_planes(out3: np.ndarray):

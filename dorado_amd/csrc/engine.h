@@ -54,6 +54,8 @@ extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w
 extern "C" int mibc_launch_read_stats(hipStream_t s, const int16_t *sig, const long long *off, int n_reads,
                                       int strategy, float qa, float qb, float shift_mult, float scale_mult,
                                       float *out_ss, float *out_raw, uint32_t *scratch);
+extern "C" int mibc_launch_svb16_decode(hipStream_t s, const uint8_t *streams, const long long *stream_off,
+                                        const long long *sample_off, int n_rows, int16_t *out, int *status);
 extern "C" int mibc_launch_scale_reads(hipStream_t s, const int16_t *sig, const long long *off, int n_reads,
                                        const float *ss, half_t *out, int blocks_per_read);
 extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, half_t *Xout,

@@ -737,6 +737,22 @@ extern "C" int mibc_scale_reads(mibc_engine *e, const int16_t *sig_dev, const in
     return MIBC_OK;
 }
 
+// f2: svb16 + zig-zag + delta stage of the POD5 VBZ signal codec on the device; replaces that
+// half of pod5_get_read_complete_signal (data_loader/DataLoader.cpp:163-170).  Row r of the signal table (after
+// zstd) = streams_dev[stream_off[r] .. stream_off[r+1]), decodes to out_dev[sample_off[r] .. sample_off[r+1]).
+// status_dev[r] = 0 ok, 1 = the stream was not consumed exactly (corrupt row).
+extern "C" int mibc_svb16_decode(mibc_engine *e, const uint8_t *streams_dev, const int64_t *stream_off_dev,
+                                 const int64_t *sample_off_dev, int n_rows, int16_t *out_dev, int *status_dev) {
+    if (!e || !streams_dev || !stream_off_dev || !sample_off_dev || !out_dev || !status_dev || n_rows < 0)
+        return MIBC_ERR_ARG;
+    if (n_rows == 0) return MIBC_OK;
+    HIP_OK(e, hipSetDevice(e->device));
+    mibc_launch_svb16_decode(e->stream, streams_dev, (const long long *)stream_off_dev,
+                             (const long long *)sample_off_dev, n_rows, out_dev, status_dev);
+    HIP_OK(e, hipGetLastError());
+    return MIBC_OK;
+}
+
 extern "C" int mibc_get_stage_ms(mibc_engine *e, mibc_stage_ms *out) {
     if (!e || !out) return MIBC_ERR_ARG;
     memset(out, 0, sizeof(*out));

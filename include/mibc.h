@@ -146,6 +146,17 @@ int mibc_scaler_stats(mibc_engine *e, const int16_t *sig_dev, const int64_t *off
 int mibc_scale_reads(mibc_engine *e, const int16_t *sig_dev, const int64_t *offsets_dev, int n_reads,
                      const float *shift_scale_dev, uint16_t *out_f16_dev);
 
+/* ---- POD5 signal decode ----
+ * The reference obtains a read's int16 samples from pod5_get_read_complete_signal
+ * (dorado/data_loader/DataLoader.cpp:163-170; pod5-file-format 0.3.36, not vendored).  POD5 stores each
+ * signal-table row as zstd(svb16(zigzag(delta(int16)))).  The zstd frame is inflated on the host (libzstd);
+ * this entry point does the StreamVByte-16 + zig-zag + delta stage for a whole batch of rows on the device,
+ * so the samples are born in HBM, next to mibc_scaler_stats / mibc_*_i16.
+ * streams_dev: concatenated inflated rows; stream_off_dev / sample_off_dev: n_rows + 1 prefix offsets
+ * (bytes / samples); status_dev[r] = 0 ok, 1 = row not consumed exactly (corrupt). */
+int mibc_svb16_decode(mibc_engine *e, const uint8_t *streams_dev, const int64_t *stream_off_dev,
+                      const int64_t *sample_off_dev, int n_rows, int16_t *out_dev, int *status_dev);
+
 /* ---- measurement (replaces CudaCaller.cpp:552-569 timing + gpu_profiling.h ranges) ---- */
 int mibc_time_forward(mibc_engine *e, int N, int T_in, float *ms); /* min of 2 runs, like :552-569 */
 int mibc_get_stage_ms(mibc_engine *e, mibc_stage_ms *out);         /* hipEvent times, last call */

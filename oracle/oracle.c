@@ -1024,6 +1024,59 @@ ORC_API int orc_trim(const float *signal, int n, float threshold, int window_siz
 }
 
 /* ------------------------------------------------------------------------------------------
+ * f2: POD5 signal decompression.  The reference reads signals through
+ * pod5_get_read_complete_signal (data_loader/DataLoader.cpp:163-170) of the un-vendored pod5 library
+ * (pod5-file-format 0.3.36, cmake/Pod5.cmake).  Its published "VBZ" signal encoding is
+ *     int16 samples -> delta (x[i] - x[i-1], x[-1] = 0) -> zig-zag ((d << 1) ^ (d >> 15)) ->
+ *     StreamVByte-16 (one control BIT per value, LSB first, 0 = one byte, 1 = two bytes little
+ *     endian; the (n + 7) / 8 control bytes come first, the data bytes follow) -> zstd frame.
+ * The zstd stage stays on the CPU (libzstd); these two functions restate the svb16 stage, which
+ * is what the device kernel replaces.  Parity is anchored on the reference's own POD5 fixtures
+ * (tests/data/pod5/ **) through structural invariants: every stream must be consumed exactly and give
+ * exactly `samples` values — see tests/test_oracle_pinned.py::test_pod5_*.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Returns the number of stream bytes consumed, or -1 if the stream is too short. */
+ORC_API long orc_svb16_decode(const uint8_t *stream, long stream_len, long n, int16_t *out) {
+    const long nk = (n + 7) / 8;
+    if (nk > stream_len) return -1;
+    long pos = nk;
+    uint16_t prev = 0;
+    for (long i = 0; i < n; ++i) {
+        const int two = (stream[i >> 3] >> (i & 7)) & 1;
+        if (pos + 1 + two > stream_len) return -1;
+        uint16_t u = stream[pos];
+        if (two) u |= (uint16_t)stream[pos + 1] << 8;
+        pos += 1 + two;
+        const uint16_t d = (uint16_t)((u >> 1) ^ (uint16_t)(-(int16_t)(u & 1)));  /* zig-zag decode */
+        prev = (uint16_t)(prev + d);                                              /* wraps mod 2^16 */
+        out[i] = (int16_t)prev;
+    }
+    return pos;
+}
+
+/* Inverse (test fixture generator for round trips); `stream` needs (n + 7) / 8 + 2 n bytes. */
+ORC_API long orc_svb16_encode(const int16_t *in, long n, uint8_t *stream) {
+    const long nk = (n + 7) / 8;
+    memset(stream, 0, (size_t)nk);
+    long pos = nk;
+    uint16_t prev = 0;
+    for (long i = 0; i < n; ++i) {
+        const uint16_t d = (uint16_t)((uint16_t)in[i] - prev);
+        prev = (uint16_t)in[i];
+        const uint16_t z = (uint16_t)((d << 1) ^ (uint16_t)(-(int16_t)(d >> 15)));
+        if (z < 256) {
+            stream[pos++] = (uint8_t)z;
+        } else {
+            stream[i >> 3] |= (uint8_t)(1u << (i & 7));
+            stream[pos++] = (uint8_t)(z & 0xff);
+            stream[pos++] = (uint8_t)(z >> 8);
+        }
+    }
+    return pos;
+}
+
+/* ------------------------------------------------------------------------------------------
  * a5-a6: transformer model (sup@v5): conv stack -> TxEncoder x depth -> LinearUpsample ->
  * LinearScaledCRF.  Follows basecall/model/TxModel.cpp:20-41 and nn/TxModules.cpp.
  * ---------------------------------------------------------------------------------------- */

@@ -281,3 +281,20 @@ def trimtest_signal(n=2000):
     out = np.empty(n, np.float32)
     ref().ref_trimtest_signal(_fp(out), C.c_int(n))
     return out
+
+
+# ---------------------------------------------------------------- f2: POD5 VBZ (svb16 stage)
+def svb16_decode(stream_u8, n):
+    s = np.ascontiguousarray(stream_u8, np.uint8)
+    out = np.empty(n, np.int16)
+    lib().orc_svb16_decode.restype = C.c_long
+    used = lib().orc_svb16_decode(s.ctypes.data_as(_u8p), C.c_long(s.size), C.c_long(n), out.ctypes.data_as(_i16p))
+    return out, int(used)
+
+
+def svb16_encode(x_i16):
+    x = np.ascontiguousarray(x_i16, np.int16)
+    buf = np.zeros((x.size + 7) // 8 + 2 * x.size + 8, np.uint8)
+    lib().orc_svb16_encode.restype = C.c_long
+    used = lib().orc_svb16_encode(x.ctypes.data_as(_i16p), C.c_long(x.size), buf.ctypes.data_as(_u8p))
+    return buf[:used].copy()

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""SURVEY.md 8f-1 measurement: the device side of ScalerNode on MI355X.
+"""SURVEY.md 8f-1 / 8f-2 measurement: the device side of ScalerNode and of the POD5 signal decode on MI355X.
+  * mibc_svb16_decode     StreamVByte-16 + zig-zag + delta stage of POD5 VBZ rows
   * mibc_scale_reads      HBM-bound, 2 B read + 2 B written per sample
   * mibc_scaler_stats     one pass over the samples (2 B/sample) + LDS histogram atomics
   * mibc_call_device_i16  the whole hot path fed with raw int16 chunks vs pre-scaled f16 chunks
@@ -57,6 +58,46 @@ def main():
     out["scale_reads"] = {"samples_per_s": total / t, "ms": t * 1e3, "GB_per_s": total * 4 / t / 1e9,
                           "algorithmic_bytes_per_sample": 4, "frac_of_8TBs": total * 4 / t / 8e12}
     for q in (d_sig, d_out, d_off, d_ss, d_raw):
+        eng.device_free(q)
+    # ---- POD5 VBZ svb16 stage: 4096 rows x 102400 samples (the row size MinKNOW writes), ~12 % two-byte values
+    rows, rs = 4096, 102400
+    d = rng.integers(-60, 60, rs).astype(np.int64)
+    d[rng.random(rs) < 0.12] *= 9                       # some deltas need two bytes
+    xw = np.cumsum(d).astype(np.int16)
+    dz = np.diff(np.concatenate([[0], xw.astype(np.int64)])).astype(np.int16).view(np.uint16)
+    z = ((dz << 1) ^ (0 - (dz >> 15))).astype(np.uint16)
+    two = z >= 256
+    keys = np.packbits(two, bitorder="little")
+    lens = 1 + two.astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    data = np.zeros(int(lens.sum()), np.uint8)
+    data[offs] = (z & 0xff).astype(np.uint8)
+    data[offs[two] + 1] = (z[two] >> 8).astype(np.uint8)
+    stream = np.concatenate([keys, data])
+    sl = stream.size
+    d_st = eng.device_alloc(rows * sl)
+    for r in range(rows):
+        L.mibc_memcpy_h2d(eng._h, C.c_void_p(d_st + r * sl), stream.ctypes.data, sl) if r < 64 else None
+    for r in range(64, rows, 64):   # replicate the first 64 rows on the device side through the host copy
+        blk = np.tile(stream, 64)
+        L.mibc_memcpy_h2d(eng._h, C.c_void_p(d_st + r * sl), blk.ctypes.data, blk.nbytes)
+    so = (np.arange(rows + 1, dtype=np.int64) * sl)
+    no = (np.arange(rows + 1, dtype=np.int64) * rs)
+    d_so, d_no = eng.device_alloc(so.nbytes), eng.device_alloc(no.nbytes)
+    eng.h2d(d_so, so)
+    eng.h2d(d_no, no)
+    d_x = eng.device_alloc(rows * rs * 2)
+    d_stat = eng.device_alloc(rows * 4)
+    t = timeit(lambda: L.mibc_svb16_decode(eng._h, d_st, d_so, d_no, rows, d_x, d_stat))
+    chk = np.zeros(rs, np.int16)
+    eng.d2h(chk, d_x + (rows - 1) * rs * 2)
+    stat = np.zeros(rows, np.int32)
+    eng.d2h(stat, d_stat)
+    out["svb16_decode"] = {"samples_per_s": rows * rs / t, "ms": t * 1e3,
+                           "stream_bytes_per_sample": sl / rs, "GB_per_s": rows * (sl + 2 * rs) / t / 1e9,
+                           "frac_of_8TBs": rows * (sl + 2 * rs) / t / 8e12,
+                           "verified": bool((chk == xw).all() and not stat.any())}
+    for q in (d_st, d_so, d_no, d_x, d_stat):
         eng.device_free(q)
     # ---- fused path: hac batch, raw int16 in vs scaled f16 in
     N, T_in = 16384, cfg.chunk_size
