@@ -182,3 +182,58 @@ def basecall_raw_reads(cfg: ModelConfig, weights, reads_i16, shift_scale, trim_s
         so += int(sl[r]); mo += int(ml[r]); oo += int(noff[r])
     return out, {"samples_processed": stats[0], "samples_incl_padding": stats[1],
                  "batches_called": stats[2], "partial_batches_called": stats[3]}
+
+
+# ---------------------------------------------------------------- ".tensor" loader
+_DTYPES = [np.float16, None, np.float32, np.float64, np.int8, np.uint8, np.int16, np.int32, np.int64, np.bool_]
+
+
+def load_tensor_file(path, as_float=False):
+    """libtorch-free read of a TorchScript ".tensor" archive -> list of (name, ndarray).  bf16 tensors are
+    returned as float32 (numpy has no bf16); as_float=True converts everything to float32."""
+    L = lib()
+    L.mibch_tensor_last_error.restype = C.c_char_p
+    n = L.mibch_tensor_open(str(path).encode())
+    if n < 0:
+        raise ValueError(L.mibch_tensor_last_error().decode())
+    out = []
+    for i in range(n):
+        dt, rank, numel = C.c_int(), C.c_int(), C.c_int64()
+        shape = (C.c_int64 * 8)()
+        name = C.create_string_buffer(64)
+        L.mibch_tensor_info(i, C.byref(dt), C.byref(rank), shape, C.byref(numel), name)
+        shp = tuple(shape[d] for d in range(rank.value))
+        npdt = _DTYPES[dt.value]
+        if as_float or npdt is None:
+            a = np.empty(numel.value, np.float32)
+            assert L.mibch_tensor_copy_float(i, a.ctypes.data_as(C.c_void_p), C.c_uint64(numel.value)) == 0
+        else:
+            a = np.empty(numel.value, npdt)
+            assert L.mibch_tensor_copy_raw(i, a.ctypes.data_as(C.c_void_p), C.c_uint64(a.nbytes)) == 0
+        out.append((name.value.decode(), a.reshape(shp)))
+    return out
+
+
+def model_tensor_names(cfg: ModelConfig):
+    """File names in module.parameters() order (basecall/crf_utils.cpp:26-150)."""
+    buf = C.create_string_buffer(1 << 16)
+    if cfg.tx is not None:
+        lib().mibch_model_tensor_names(1, len(cfg.convs), cfg.tx.depth, 0, 0, 0, buf, len(buf))
+    else:
+        lib().mibch_model_tensor_names(0, len(cfg.convs), cfg.lstm_layers, 0, int(cfg.bias),
+                                       int(bool(cfg.out_features)), buf, len(buf))
+    return [s for s in buf.value.decode().split("\n") if s]
+
+
+def load_model_weights(model_dir, cfg: ModelConfig):
+    """Weights of a model directory (config.toml + *.tensor) as float32 arrays in the order mibc_create
+    expects = the order load_{lstm,tx}_model_weights returns them."""
+    import os
+
+    ws = []
+    for name in model_tensor_names(cfg):
+        ts = load_tensor_file(os.path.join(str(model_dir), name), as_float=True)
+        if len(ts) != 1:
+            raise ValueError(f"{name}: expected one tensor, found {len(ts)}")
+        ws.append(np.ascontiguousarray(ts[0][1]))
+    return ws
