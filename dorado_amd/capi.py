@@ -32,6 +32,10 @@ class DecodeOptsC(C.Structure):
                 ("q_shift", C.c_float), ("q_scale", C.c_float)]
 
 
+class VarChunkC(C.Structure):
+    _fields_ = [("row", C.c_int), ("sample_start", C.c_int), ("n_samples", C.c_int)]
+
+
 class StageMsC(C.Structure):
     _fields_ = [("conv", C.c_float), ("lstm", C.c_float), ("head", C.c_float),
                 ("decode", C.c_float), ("total", C.c_float), ("lstm_layer", C.c_float * 8),
@@ -45,7 +49,7 @@ EXPORTS = [
     "mibc_memcpy_d2h", "mibc_forward", "mibc_decode", "mibc_call_device", "mibc_call",
     "mibc_sync", "mibc_time_forward", "mibc_get_stage_ms", "mibc_set_profile", "mibc_debug_tap",
     "mibc_forward_i16", "mibc_call_device_i16", "mibc_call_i16", "mibc_scaler_stats", "mibc_scale_reads",
-    "mibc_svb16_decode",
+    "mibc_svb16_decode", "mibc_forward_var", "mibc_call_device_var", "mibc_call_var",
 ]
 
 SCALE_QUANTILE = 0
@@ -114,6 +118,12 @@ def lib():
         L.mibc_scale_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.mibc_svb16_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p]
+        L.mibc_forward_var.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_void_p]
+        L.mibc_call_device_var.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                           C.POINTER(DecodeOptsC), C.c_void_p]
+        L.mibc_call_var.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                    C.POINTER(DecodeOptsC), C.c_void_p]
         _lib = L
     return _lib
 
@@ -366,6 +376,64 @@ class Engine:
             for q in (d_sig, d_off, d_ss, d_out):
                 self.device_free(q)
         return [out[off[i]:off[i + 1]] for i in range(n)]
+
+    # -- f3: variable chunk sizes (several chunks per batch row)
+    @staticmethod
+    def _var_chunks(chunks):
+        arr = (VarChunkC * len(chunks))()
+        for i, (row, s0, n) in enumerate(chunks):
+            arr[i] = VarChunkC(int(row), int(s0), int(n))
+        return arr
+
+    def forward_var(self, x_rows: np.ndarray, chunks, shift_scale=None) -> np.ndarray:
+        """x_rows [N, T_in] (f16, or int16 with shift_scale [N,2]); chunks = [(row, sample_start, n_samples)].
+        Returns the packed scores [N, T, K] f16 (gaps hold garbage)."""
+        raw = shift_scale is not None
+        x = np.ascontiguousarray(x_rows, np.int16 if raw else np.float16)
+        n, t_in = x.shape
+        t, k = self.output_steps(t_in), self.cfg.outsize
+        self.reserve(n, t_in)
+        d_in, d_sc = self.device_alloc(x.nbytes), self.device_alloc(n * t * k * 2)
+        d_ss = None
+        try:
+            self.h2d(d_in, x)
+            if raw:
+                ss = np.ascontiguousarray(shift_scale, np.float32).reshape(n, 2)
+                d_ss = self.device_alloc(ss.nbytes)
+                self.h2d(d_ss, ss)
+            arr = self._var_chunks(chunks)
+            self._check(lib().mibc_forward_var(self._h, d_in, d_ss, n, t_in, arr, len(chunks), d_sc),
+                        "mibc_forward_var")
+            self.sync()
+            out = np.zeros((n, t, k), np.float16)
+            self.d2h(out, d_sc)
+        finally:
+            for q in (d_in, d_sc, d_ss):
+                if q:
+                    self.device_free(q)
+        return out
+
+    def call_var(self, x_rows: np.ndarray, chunks, shift_scale=None):
+        """-> list of (seq, qstr, moves[T_c]) per chunk, through mibc_call_var."""
+        raw = shift_scale is not None
+        x = np.ascontiguousarray(x_rows, np.int16 if raw else np.float16)
+        n, t_in = x.shape
+        t = self.output_steps(t_in)
+        self.reserve(n, t_in)
+        ss = np.ascontiguousarray(shift_scale, np.float32).reshape(n, 2) if raw else None
+        out = np.zeros((3, n, t), np.int8)
+        arr = self._var_chunks(chunks)
+        self._check(lib().mibc_call_var(self._h, x.ctypes.data, ss.ctypes.data if raw else None, n, t_in, arr,
+                                        len(chunks), C.byref(self.opts), out.ctypes.data), "mibc_call_var")
+        stride = t_in // t
+        res = []
+        for row, s0, ns in chunks:
+            t0, tc = s0 // stride, ns // stride
+            mv = out[0, row, t0:t0 + tc].astype(np.uint8)
+            nb = int(mv.sum())
+            res.append((out[1, row, t0:t0 + nb].tobytes().decode("ascii"),
+                        out[2, row, t0:t0 + nb].tobytes().decode("ascii"), mv))
+        return res
 
     # -- f2: POD5 VBZ (svb16 stage) on the device
     def svb16_decode(self, streams, n_samples):

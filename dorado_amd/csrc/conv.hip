@@ -27,6 +27,9 @@ __global__ __launch_bounds__(C12_TT) void conv12_kernel(
         half_t *__restrict__ a1_tap,     // optional [N][T_in][16] (parity tap) or nullptr
         const float *__restrict__ ss,    // nullptr, or [N][2] (shift, scale): x is raw int16 and the
                                          // ScalerNode map f16((x - shift) / scale) is applied on the fly
+        const uint32_t *__restrict__ smask,  // nullptr, or [N][(T_in + 31) / 32] sample bitmap (variable-chunk
+                                             // mode): samples outside every chunk behave as zero PADDING at
+                                             // each convolution level, exactly as if the chunk stood alone
         int T_in, int Tpitch, int pad) {
     __shared__ float xs[C12_TT + 8];
     __shared__ __attribute__((aligned(16))) float o1[(C12_TT + 4) * C12_ROW];
@@ -35,6 +38,10 @@ __global__ __launch_bounds__(C12_TT) void conv12_kernel(
     const int tid = threadIdx.x;
     const half_t *xn = x + (size_t)n * T_in;
 
+    const int mwords = (T_in + 31) >> 5;
+    auto in_mask = [&](int t) -> bool {
+        return smask == nullptr || ((smask[(size_t)n * mwords + (t >> 5)] >> (t & 31)) & 1u);
+    };
     if (ss != nullptr) {
         // tensor_utils.cpp:89-142 semantics: f32 subtract, IEEE divide, round to f16 — the value the
         // reference's pipeline would have stored in the read before chunking
@@ -42,19 +49,20 @@ __global__ __launch_bounds__(C12_TT) void conv12_kernel(
         const float shift = ss[2 * n], scale = ss[2 * n + 1];
         for (int i = tid; i < C12_TT + 8; i += C12_TT) {
             const int t = t0 - 4 + i;
-            xs[i] = (t >= 0 && t < T_in) ? (float)(half_t)(((float)xi[t] - shift) / scale) : 0.0f;
+            xs[i] = (t >= 0 && t < T_in && in_mask(t)) ? (float)(half_t)(((float)xi[t] - shift) / scale) : 0.0f;
         }
     } else {
         for (int i = tid; i < C12_TT + 8; i += C12_TT) {
             const int t = t0 - 4 + i;
-            xs[i] = (t >= 0 && t < T_in) ? (float)xn[t] : 0.0f;
+            xs[i] = (t >= 0 && t < T_in && in_mask(t)) ? (float)xn[t] : 0.0f;
         }
     }
     __syncthreads();
     // conv1 at times t0-2 .. t0+TT+1 (row r <-> time t0-2+r); zero outside [0,T_in) = conv2's padding
     for (int r = tid; r < C12_TT + 4; r += C12_TT) {
         const int t = t0 - 2 + r;
-        const bool inside = (t >= 0 && t < T_in);
+        bool inside = (t >= 0 && t < T_in);
+        if (inside) inside = in_mask(t);
         float acc[C12_CH];
 #pragma unroll
         for (int c = 0; c < C12_CH; ++c) acc[c] = b1[c];
@@ -100,10 +108,11 @@ __global__ __launch_bounds__(C12_TT) void conv12_kernel(
         }
     }
     half8_t o0, o1v;
+    const bool in2 = in_mask(t);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        o0[c] = (half_t)act_apply(acc[c], ACT2);
-        o1v[c] = (half_t)act_apply(acc[8 + c], ACT2);
+        o0[c] = in2 ? (half_t)act_apply(acc[c], ACT2) : (half_t)0.0f;
+        o1v[c] = in2 ? (half_t)act_apply(acc[8 + c], ACT2) : (half_t)0.0f;
     }
     half8_t *dst = (half8_t *)(a2p + ((size_t)n * Tpitch + pad + t) * C12_CH);
     dst[0] = o0;
@@ -112,11 +121,11 @@ __global__ __launch_bounds__(C12_TT) void conv12_kernel(
 
 extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w1, const float *b1,
                                   const float *w2, const float *b2, half_t *a2p, half_t *a1_tap, const float *ss,
-                                  int N, int T_in, int Tpitch, int pad, int act1, int act2) {
+                                  const uint32_t *smask, int N, int T_in, int Tpitch, int pad, int act1, int act2) {
     dim3 grid((T_in + C12_TT - 1) / C12_TT, N);
 #define LAUNCH(A1, A2)                                                                          \
     hipLaunchKernelGGL((conv12_kernel<A1, A2>), grid, dim3(C12_TT), 0, s, x, w1, b1, w2, b2, a2p, \
-                       a1_tap, ss, T_in, Tpitch, pad)
+                       a1_tap, ss, smask, T_in, Tpitch, pad)
     if (act1 == 0 && act2 == 0) {
         LAUNCH(0, 0);
     } else if (act1 == 1 && act2 == 1) {

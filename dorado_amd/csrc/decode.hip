@@ -22,6 +22,20 @@
 
 #define FLT_LOWEST (-3.402823466e+38f)
 
+// Variable-chunk mode: "chunk" n of a launch is an arbitrary step interval of the packed
+// [N][T] planes instead of a whole row: so = first step (offset into scores / path / output planes),
+// bo = first row of its back-guide / trace block (T_n + 1 rows), T_n = its length.  All null = one chunk per row.
+struct VarIdx {
+    const int *coff, *boff, *clen;
+};
+#define VAR_SETUP(T_)                                                       \
+    size_t so = (size_t)n * (T_), bo = (size_t)n * ((T_) + 1);              \
+    if (vi.coff != nullptr) {                                               \
+        so = (size_t)vi.coff[n];                                            \
+        bo = (size_t)vi.boff[n];                                            \
+        T_ = vi.clen[n];                                                    \
+    }
+
 __device__ __forceinline__ float clampf(float v, float c) {
     return (c > 0.0f) ? fminf(fmaxf(v, -c), c) : v;
 }
@@ -31,7 +45,7 @@ __device__ __forceinline__ float clampf(float v, float c) {
 // ---------------------------------------------------------------------------------------------
 __global__ void bwd_scan_kernel(const half_t *__restrict__ scores,  // [N][T][4S]
                                 float *__restrict__ bwd,            // [N][T+1][S]
-                                int T, int S, float stay, float clampv) {
+                                int T, int S, float stay, float clampv, VarIdx vi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *beta = (float *)smem;                     // [2][S]
     half_t *sc = (half_t *)(smem + 2 * S * 4);       // [2][4][S]  ([buf][base that fell off][dest])
@@ -39,8 +53,9 @@ __global__ void bwd_scan_kernel(const half_t *__restrict__ scores,  // [N][T][4S
     const int s = threadIdx.x;
     const int K = 4 * S;
     const int Q = S >> 2;
-    const half_t *sn = scores + (size_t)n * T * K;
-    float *bn = bwd + (size_t)n * (T + 1) * S;
+    VAR_SETUP(T)
+    const half_t *sn = scores + so * K;
+    float *bn = bwd + bo * S;
 
     beta[s] = 0.0f;
     bn[(size_t)T * S + s] = 0.0f;
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(64) void beam_search_kernel(
         uint32_t *__restrict__ trace,        // [N][T+1][W]  state | prev<<16 | stay<<24
         uint16_t *__restrict__ path_state,   // [N][T]  full k-mer state per block
         int8_t *__restrict__ moves,          // [N][T]
-        int T, int W, float log_cut, float stay, float clampv) {
+        int T, int W, float log_cut, float stay, float clampv, VarIdx vi) {
     constexpr int K = 4 * S;
     constexpr int BITS = (S == 64) ? 6 : (S == 256) ? 8 : (S == 1024) ? 10 : 12;
     constexpr int RPL = (K / 64 / 8) > 0 ? (K / 64 / 8) : 1;  // half8 loads per lane per score row
@@ -168,9 +183,10 @@ __global__ __launch_bounds__(64) void beam_search_kernel(
 
     const int n = blockIdx.x;
     const int lane = threadIdx.x;
-    const half_t *sn = scores + (size_t)n * T * K;
-    const float *bn = bwd + (size_t)n * (T + 1) * S;
-    uint32_t *tr = trace + (size_t)n * (T + 1) * W;
+    VAR_SETUP(T)
+    const half_t *sn = scores + so * K;
+    const float *bn = bwd + bo * S;
+    uint32_t *tr = trace + bo * W;
     const uint32_t mask = S - 1;
 
     // ---- seed (beam_search.cpp:165-198): threshold = W-th largest back-guide at t = 0 ----
@@ -455,8 +471,8 @@ __global__ __launch_bounds__(64) void beam_search_kernel(
         ei = (uint8_t)__shfl((int)ei, 0, 64);
         if (lane < rows) {
             const int blk = lo_blk + lane - 1;  // beam row b describes block b-1
-            path_state[(size_t)n * T + blk] = tb_state[lane];
-            moves[(size_t)n * T + blk] = (blk == 0) ? (int8_t)1 : tb_move[lane];
+            path_state[so + blk] = tb_state[lane];
+            moves[so + blk] = (blk == 0) ? (int8_t)1 : tb_move[lane];
         }
         __syncthreads();
     }
@@ -474,7 +490,7 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
                                   int8_t *__restrict__ qstr_out,          // [N][T]
                                   float *__restrict__ prob_tap,           // [N][T] or nullptr
                                   int T, int S, float stay, float clampv, float q_shift,
-                                  float q_scale) {
+                                  float q_scale, VarIdx vi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *alpha = (float *)smem;                 // [2][S]
     float *red = alpha + 2 * S;                   // [2 * 32] reduction scratch
@@ -489,12 +505,13 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
     const int Q = S >> 2;
     const int nw = (S + 63) >> 6;
     const int wave = s >> 6, lane = s & 63;
-    const half_t *sn = scores + (size_t)n * T * K;
-    const float *bn = bwd + (size_t)n * (T + 1) * S;
+    VAR_SETUP(T)   // after the LDS carve-up above, which uses the launch-wide maximum T
+    const half_t *sn = scores + so * K;
+    const float *bn = bwd + bo * S;
 
     for (int i = s; i < T; i += S) {
-        pst[i] = path_state[(size_t)n * T + i];
-        pmv[i] = moves[(size_t)n * T + i];
+        pst[i] = path_state[so + i];
+        pmv[i] = moves[so + i];
     }
     // log Z = LSE_s(bwd[0][s])  (alpha[0] = 0): shift for the posterior exponent
     float logZ;
@@ -623,8 +640,8 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
             e = -10.0f * log10f(e);
             float q = e * q_scale + q_shift;
             q = fminf(fmaxf(q, 1.0f), 50.0f);
-            seq_out[(size_t)n * T + pos] = (int8_t)alphabet[base];
-            qstr_out[(size_t)n * T + pos] = (int8_t)(33.5f + q);
+            seq_out[so + pos] = (int8_t)alphabet[base];
+            qstr_out[so + pos] = (int8_t)(33.5f + q);
             pos += 1;
         }
     }
@@ -632,19 +649,37 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
     const int len = s_len;
     for (int i = s; i < T; i += S) {
         if (i >= len) {
-            seq_out[(size_t)n * T + i] = 0;
-            qstr_out[(size_t)n * T + i] = 0;
+            seq_out[so + i] = 0;
+            qstr_out[so + i] = 0;
         }
-        if (prob_tap != nullptr) prob_tap[(size_t)n * T + i] = prob[i];
+        if (prob_tap != nullptr) prob_tap[so + i] = prob[i];
     }
 }
 
 // ---------------------------------------------------------------------------------------------
+extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
+                                      float beam_cut, float stay, float clampv, float q_shift, float q_scale,
+                                      float *bwd, uint32_t *trace, uint16_t *path_state, int8_t *out3,
+                                      size_t plane_stride, float *prob_tap, const int *coff, const int *boff,
+                                      const int *clen);
 extern "C" int mibc_launch_decode(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
                                   float beam_cut, float stay, float clampv, float q_shift,
                                   float q_scale, float *bwd, uint32_t *trace,
                                   uint16_t *path_state, int8_t *out3 /* [3][Nplane][T] */,
                                   size_t plane_stride, float *prob_tap) {
+    return mibc_launch_decode_var(st, scores, N, T, S, W, beam_cut, stay, clampv, q_shift, q_scale, bwd, trace,
+                                  path_state, out3, plane_stride, prob_tap, nullptr, nullptr, nullptr);
+}
+
+// N = number of chunks of the launch; with coff / boff / clen (device int32 [N]) chunk n is the step interval
+// [coff[n], coff[n] + clen[n]) of the packed planes and owns back-guide rows [boff[n], boff[n] + clen[n] + 1);
+// T = the largest clen (LDS sizing).
+extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
+                                      float beam_cut, float stay, float clampv, float q_shift, float q_scale,
+                                      float *bwd, uint32_t *trace, uint16_t *path_state, int8_t *out3,
+                                      size_t plane_stride, float *prob_tap, const int *coff, const int *boff,
+                                      const int *clen) {
+    const VarIdx vi{coff, boff, clen};
     if (W > BS_MAXW || W < 1 || (S != 64 && S != 256 && S != 1024) || T < 1) {
         return 1;
     }
@@ -653,23 +688,23 @@ extern "C" int mibc_launch_decode(hipStream_t st, const half_t *scores, int N, i
     int8_t *qstr = out3 + 2 * plane_stride;
     const float log_cut = (beam_cut > 0.0f) ? logf(beam_cut) : 3.402823466e+38f;
     const size_t smem1 = (size_t)2 * S * 4 + (size_t)2 * 4 * S * 2;
-    hipLaunchKernelGGL(bwd_scan_kernel, dim3(N), dim3(S), smem1, st, scores, bwd, T, S, stay, clampv);
+    hipLaunchKernelGGL(bwd_scan_kernel, dim3(N), dim3(S), smem1, st, scores, bwd, T, S, stay, clampv, vi);
     switch (S) {
         case 64:
             hipLaunchKernelGGL((beam_search_kernel<64>), dim3(N), dim3(64), 0, st, scores, bwd, trace,
-                               path_state, moves, T, W, log_cut, stay, clampv);
+                               path_state, moves, T, W, log_cut, stay, clampv, vi);
             break;
         case 256:
             hipLaunchKernelGGL((beam_search_kernel<256>), dim3(N), dim3(64), 0, st, scores, bwd,
-                               trace, path_state, moves, T, W, log_cut, stay, clampv);
+                               trace, path_state, moves, T, W, log_cut, stay, clampv, vi);
             break;
         default:
             hipLaunchKernelGGL((beam_search_kernel<1024>), dim3(N), dim3(64), 0, st, scores, bwd,
-                               trace, path_state, moves, T, W, log_cut, stay, clampv);
+                               trace, path_state, moves, T, W, log_cut, stay, clampv, vi);
             break;
     }
     const size_t smem3 = (size_t)(2 * S + 64) * 4 + (size_t)T * 4 + (size_t)T * 2 + (size_t)T + 16;
     hipLaunchKernelGGL(posts_qual_kernel, dim3(N), dim3(S), smem3, st, scores, bwd, path_state, moves,
-                       seq, qstr, prob_tap, T, S, stay, clampv, q_shift, q_scale);
+                       seq, qstr, prob_tap, T, S, stay, clampv, q_shift, q_scale, vi);
     return 0;
 }

@@ -50,7 +50,7 @@ struct WsArgs {
 extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mode);
 extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w1, const float *b1,
                                   const float *w2, const float *b2, half_t *a2p, half_t *a1_tap, const float *ss,
-                                  int N, int T_in, int Tpitch, int pad, int act1, int act2);
+                                  const uint32_t *smask, int N, int T_in, int Tpitch, int pad, int act1, int act2);
 extern "C" int mibc_launch_read_stats(hipStream_t s, const int16_t *sig, const long long *off, int n_reads,
                                       int strategy, float qa, float qb, float shift_mult, float scale_mult,
                                       float *out_ss, float *out_raw, uint32_t *scratch);
@@ -58,10 +58,18 @@ extern "C" int mibc_launch_svb16_decode(hipStream_t s, const uint8_t *streams, c
                                         const long long *sample_off, int n_rows, int16_t *out, int *status);
 extern "C" int mibc_launch_scale_reads(hipStream_t s, const int16_t *sig, const long long *off, int n_reads,
                                        const float *ss, half_t *out, int blocks_per_read);
+extern "C" int mibc_launch_lstm_layer_masked(hipStream_t s, int C, const half_t *Xin, half_t *Xout,
+                                             const half_t *Wf16, const float *biasn, int T, int N, int reverse,
+                                             const unsigned long long *tmask);
 extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, half_t *Xout,
                                       const half_t *Wf, const half_t *Wf16, const float *biasn, int T, int N,
                                       int reverse);
 extern "C" int mibc_lstm_rows_per_wg(int C);
+extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
+                                      float beam_cut, float stay, float clampv, float q_shift, float q_scale,
+                                      float *bwd, uint32_t *trace, uint16_t *path_state, int8_t *out3,
+                                      size_t plane_stride, float *prob_tap, const int *coff, const int *boff,
+                                      const int *clen);
 extern "C" int mibc_launch_decode(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
                                   float beam_cut, float stay, float clampv, float q_shift,
                                   float q_scale, float *bwd, uint32_t *trace,
@@ -90,6 +98,12 @@ struct mibc_engine {
     int head_act1 = -1, head_act2 = -1;
     // f1 (ScalerNode): per-chunk (shift, scale) of the int16 input of the call in flight, or nullptr
     const float *in_ss = nullptr;
+    // f3 (variable chunks): masks of the call in flight (device), or nullptr
+    const uint32_t *in_smask = nullptr;     // [N][(T_in+31)/32] sample bitmap
+    const unsigned long long *in_tmask = nullptr;  // [T][N/64] valid-step bitmap per 64-row workgroup
+    const int *var_idx = nullptr;           // coff | boff | clen, n_chunks each
+    void *var_scratch = nullptr;            // smask | tmask | var_idx, grown on demand
+    size_t var_scratch_bytes = 0;
     float *ss_stage = nullptr;          // device copy of host-provided pairs (mibc_call_i16)
     uint32_t *stats_scratch = nullptr;  // [256][2][65536] wide-range histograms, allocated on first use
     // geometry

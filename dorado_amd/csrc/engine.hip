@@ -270,7 +270,7 @@ extern "C" void mibc_destroy(mibc_engine *e) {
     free_ws(e);
     if (e->is_tx) tx_destroy(e);
     void *ptrs[] = {e->w1, e->b1, e->w2, e->b2, e->b3, e->w3, e->head_w1, e->head_w2, e->head_b1, e->w3f, e->head_w1f,
-                    e->stats_scratch};
+                    e->stats_scratch, e->var_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto p : e->lstm_w) (void)hipFree(p);
@@ -435,7 +435,7 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     const int T = mibc_output_steps(e, T_in);
     const bool prof = e->profile > 0;
     if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_START], e->stream));
-    if (mibc_launch_conv12(e->stream, in_dev, e->w1, e->b1, e->w2, e->b2, e->a2p, e->a1_tap, e->in_ss, N, T_in,
+    if (mibc_launch_conv12(e->stream, in_dev, e->w1, e->b1, e->w2, e->b2, e->a2p, e->a1_tap, e->in_ss, e->in_smask, N, T_in,
                            e->Tpitch, e->pad3, d.conv_act[0], d.conv_act[1]) != 0)
         return fail(e, MIBC_NOT_SUPPORTED, "conv activation combination not supported");
     bool conv3_done = false;
@@ -476,8 +476,12 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     for (int l = 0; l < d.lstm_layers; ++l) {
         // LSTMStack(layers, size, reverse_first = true): nn/LSTMStack.cpp:29-41, CRFModel.cpp:41
         const int reverse = (l % 2 == 0) ? 1 : 0;
-        if (mibc_launch_lstm_layer(e->stream, e->C, cur, nxt, e->lstm_w[l], e->lstm_w16[l], e->lstm_bn[l], T, N,
-                                   reverse) != 0)
+        if (e->in_tmask != nullptr) {
+            if (mibc_launch_lstm_layer_masked(e->stream, e->C, cur, nxt, e->lstm_w16[l], e->lstm_bn[l], T, N, reverse,
+                                              e->in_tmask) != 0)
+                return fail(e, MIBC_NOT_SUPPORTED, "variable chunks need lstm_size 128 / 256 / 384 and N % 64 == 0");
+        } else if (mibc_launch_lstm_layer(e->stream, e->C, cur, nxt, e->lstm_w[l], e->lstm_w16[l], e->lstm_bn[l], T, N,
+                                          reverse) != 0)
             return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
         if (prof && l < 8) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_LSTM0 + l], e->stream));
         half_t *t = cur;
@@ -750,6 +754,138 @@ extern "C" int mibc_svb16_decode(mibc_engine *e, const uint8_t *streams_dev, con
     mibc_launch_svb16_decode(e->stream, streams_dev, (const long long *)stream_off_dev,
                              (const long long *)sample_off_dev, n_rows, out_dev, status_dev);
     HIP_OK(e, hipGetLastError());
+    return MIBC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// f3: variable chunk sizes.  The reference's CUDA path packs ragged chunks back to back
+// (basecall/CudaModelRunner.cpp:21-49, nn/AuxiliaryData.cpp) so that short reads do not pay for padding.
+// Here the batch keeps its [N][T_in] rows, but a row may hold SEVERAL chunks of any stride-multiple length,
+// separated by >= 2 steps: convolutions see zero padding at every chunk edge (sample bitmap), the LSTM state
+// is forced to zero in the gaps (= fresh initial state for the neighbour in either direction), and the
+// decoder runs once per chunk on its own step interval.  Each chunk's result equals running the network on
+// that chunk alone.  LSTM models with lstm_size 128 / 256 / 384 (the x8 kernels).
+// ---------------------------------------------------------------------------------------------
+static int var_setup(mibc_engine *e, int N, int T_in, const mibc_var_chunk *ch, int n_chunks, int *Tmax_out) {
+    if (!ch || n_chunks <= 0) return fail(e, MIBC_ERR_ARG, "no chunks");
+    if (e->is_tx) return fail(e, MIBC_NOT_SUPPORTED, "variable chunks: LSTM models only");
+    if (N > e->Nd) return fail(e, MIBC_NOT_SUPPORTED, "variable chunks: N must not exceed the decode sub-batch");
+    const int stride = e->stride, T = mibc_output_steps(e, T_in);
+    if (T_in % stride != 0 || T != T_in / stride) return fail(e, MIBC_ERR_ARG, "variable chunks: T_in must be a stride multiple");
+    const int mw = (T_in + 31) / 32, G = N / 64;
+    std::vector<uint32_t> smask((size_t)N * mw, 0u);
+    std::vector<unsigned long long> tmask((size_t)T * G, 0ull);
+    std::vector<int> idx((size_t)3 * n_chunks);
+    std::vector<int> row_end((size_t)N, -2);   // last occupied step per row (chunks must come in row order)
+    long brow = 0;
+    int Tmax = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int r = ch[c].row, s0 = ch[c].sample_start, L = ch[c].n_samples;
+        if (r < 0 || r >= N || s0 < 0 || L <= 0 || s0 % stride || L % stride || s0 + L > T_in)
+            return fail(e, MIBC_ERR_ARG, "variable chunks: chunk outside its row or not stride aligned");
+        const int t0 = s0 / stride, Tc = L / stride;
+        if (t0 < row_end[r] + 3 && row_end[r] >= 0)
+            return fail(e, MIBC_ERR_ARG, "variable chunks: chunks of a row must be ordered and >= 2 steps apart");
+        row_end[r] = t0 + Tc - 1;
+        for (int p = s0; p < s0 + L; ++p) smask[(size_t)r * mw + (p >> 5)] |= 1u << (p & 31);
+        for (int t = t0; t < t0 + Tc; ++t) tmask[(size_t)t * G + (r >> 6)] |= 1ull << (r & 63);
+        idx[c] = r * T + t0;
+        idx[n_chunks + c] = (int)brow;
+        idx[2 * n_chunks + c] = Tc;
+        brow += Tc + 1;
+        Tmax = Tc > Tmax ? Tc : Tmax;
+    }
+    if (brow > (long)e->Nd * (T + 1)) return fail(e, MIBC_ERR_ARG, "variable chunks: too many chunks for the decode workspace");
+    const size_t b0 = smask.size() * 4, b1 = tmask.size() * 8, b2 = idx.size() * 4;
+    const size_t need = ((b0 + 15) & ~size_t(15)) + ((b1 + 15) & ~size_t(15)) + b2;
+    if (need > e->var_scratch_bytes) {
+        HIP_OK(e, hipStreamSynchronize(e->stream));
+        if (e->var_scratch) (void)hipFree(e->var_scratch);
+        e->var_scratch = nullptr;
+        HIP_OK(e, hipMalloc(&e->var_scratch, need));
+        e->var_scratch_bytes = need;
+    }
+    char *base = (char *)e->var_scratch;
+    char *p1 = base + ((b0 + 15) & ~size_t(15));
+    char *p2 = p1 + ((b1 + 15) & ~size_t(15));
+    // pageable sources: hipMemcpyAsync stages them before returning, so the vectors may die with this frame
+    HIP_OK(e, hipMemcpyAsync(base, smask.data(), b0, hipMemcpyHostToDevice, e->stream));
+    HIP_OK(e, hipMemcpyAsync(p1, tmask.data(), b1, hipMemcpyHostToDevice, e->stream));
+    HIP_OK(e, hipMemcpyAsync(p2, idx.data(), b2, hipMemcpyHostToDevice, e->stream));
+    HIP_OK(e, hipStreamSynchronize(e->stream));
+    e->in_smask = (const uint32_t *)base;
+    e->in_tmask = (const unsigned long long *)p1;
+    e->var_idx = (const int *)p2;
+    *Tmax_out = Tmax;
+    return MIBC_OK;
+}
+
+static void var_clear(mibc_engine *e) {
+    e->in_smask = nullptr;
+    e->in_tmask = nullptr;
+    e->var_idx = nullptr;
+    e->in_ss = nullptr;
+}
+
+extern "C" int mibc_forward_var(mibc_engine *e, const void *in_dev, const float *shift_scale_dev, int N, int T_in,
+                                const mibc_var_chunk *chunks, int n_chunks, uint16_t *scores_dev) {
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    int Tmax = 0;
+    rc = var_setup(e, N, T_in, chunks, n_chunks, &Tmax);
+    if (rc != MIBC_OK) return rc;
+    e->in_ss = shift_scale_dev;
+    rc = mibc_forward(e, (const uint16_t *)in_dev, N, T_in, scores_dev);
+    var_clear(e);
+    return rc;
+}
+
+extern "C" int mibc_call_device_var(mibc_engine *e, const void *in_dev, const float *shift_scale_dev, int N, int T_in,
+                                    const mibc_var_chunk *chunks, int n_chunks, const mibc_decode_opts *o,
+                                    int8_t *out_dev) {
+    if (!o) return MIBC_ERR_ARG;
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    const int T = mibc_output_steps(e, T_in);
+    int Tmax = 0;
+    rc = var_setup(e, N, T_in, chunks, n_chunks, &Tmax);
+    if (rc != MIBC_OK) return rc;
+    e->in_ss = shift_scale_dev;
+    rc = run_encoder(e, (const half_t *)in_dev, N, T_in);
+    if (rc == MIBC_OK) rc = run_head(e, N, T, 0, N, e->scores);
+    if (rc == MIBC_OK) {
+        // gaps of the output planes stay zero
+        if (hipMemsetAsync(out_dev, 0, (size_t)3 * N * T, e->stream) != hipSuccess) rc = MIBC_ERR_HIP;
+    }
+    if (rc == MIBC_OK &&
+        mibc_launch_decode_var(e->stream, e->scores, n_chunks, Tmax, e->S, o->beam_width, o->beam_cut, o->blank_score,
+                               clamp_value(e), o->q_shift, o->q_scale, e->bwd, e->trace, e->path_state, out_dev,
+                               (size_t)N * T, nullptr, e->var_idx, e->var_idx + n_chunks, e->var_idx + 2 * n_chunks) != 0)
+        rc = fail(e, MIBC_NOT_SUPPORTED, "decoder: beam_width must be 1..32");
+    var_clear(e);
+    if (rc != MIBC_OK) return rc;
+    e->last_N = N;
+    e->last_T = T;
+    e->last_T_in = T_in;
+    e->timed = false;
+    HIP_OK(e, hipGetLastError());
+    return MIBC_OK;
+}
+
+extern "C" int mibc_call_var(mibc_engine *e, const void *in_host, const float *shift_scale_host, int N, int T_in,
+                             const mibc_var_chunk *chunks, int n_chunks, const mibc_decode_opts *o, int8_t *out_host) {
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    const int T = mibc_output_steps(e, T_in);
+    HIP_OK(e, hipMemcpyAsync(e->in_stage, in_host, (size_t)N * T_in * 2, hipMemcpyHostToDevice, e->stream));
+    if (shift_scale_host)
+        HIP_OK(e, hipMemcpyAsync(e->ss_stage, shift_scale_host, (size_t)N * 2 * sizeof(float), hipMemcpyHostToDevice,
+                                 e->stream));
+    rc = mibc_call_device_var(e, e->in_stage, shift_scale_host ? e->ss_stage : nullptr, N, T_in, chunks, n_chunks, o,
+                              e->out3);
+    if (rc != MIBC_OK) return rc;
+    HIP_OK(e, hipMemcpyAsync(out_host, e->out3, (size_t)3 * N * T, hipMemcpyDeviceToHost, e->stream));
+    HIP_OK(e, hipStreamSynchronize(e->stream));
     return MIBC_OK;
 }
 

@@ -335,13 +335,17 @@ __device__ __forceinline__ float4v mfma16x16x32(half8_t a, half8_t b, float4v c)
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <int C, int PF>
+template <int C, int PF, bool MASKED = false>
 __global__ __launch_bounds__(512, 2) void lstm_layer_x8_kernel(
         const half_t *__restrict__ Xin,   // [T][N][C]
         half_t *__restrict__ Xout,        // [T][N][C]
         const half_t *__restrict__ Wf16,  // [C/16][2C/32][4][64][8]
         const float *__restrict__ biasn,  // [4C]: [(hidden/32)][4][32]  (b_ih + b_hh)
-        int T, int N, int reverse) {
+        int T, int N, int reverse,
+        // variable-chunk mode (MASKED): bit r of tmask[t * gridDim.x + blockIdx.x] = "row r of this workgroup is
+        // inside a chunk at step t"; outside (the >= 2 gap steps between packed chunks) h and c are forced to 0,
+        // which is the zero initial state of the next chunk in either direction (nn/LSTMStack.cpp:29-41)
+        const unsigned long long *__restrict__ tmask = nullptr) {
     constexpr int NB = 64;
     constexpr int NT = 512;
     constexpr int HT = C / 16 / 8;   // 16-unit hidden tiles per wave
@@ -399,6 +403,8 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_x8_kernel(
         const half_t *hprev = hbuf[step & 1];
         half_t *hnext = hbuf[(step + 1) & 1];
 
+        unsigned long long vm = ~0ull;
+        if (MASKED) vm = tmask[(size_t)t * gridDim.x + blockIdx.x];
         half8_t xpf[XPF];
         {
             const half_t *xg = Xin + ((size_t)tn * N + n0) * C;
@@ -451,9 +457,14 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_x8_kernel(
                     const float fg = fast_sigmoid(acc[1][rt][r]);
                     const float gg = fast_tanh(acc[2][rt][r]);
                     const float og = fast_sigmoid(acc[3][rt][r]);
-                    const float c = fmaf(fg, cst[jj][rt][r], ig * gg);
+                    float c = fmaf(fg, cst[jj][rt][r], ig * gg);
+                    float hval = og * fast_tanh(c);
+                    if (MASKED && !((vm >> (rt * 16 + l15)) & 1ull)) {
+                        c = 0.0f;
+                        hval = 0.0f;
+                    }
                     cst[jj][rt][r] = c;
-                    hv[r] = (half_t)(og * fast_tanh(c));
+                    hv[r] = (half_t)hval;
                 }
                 *(half4_t *)(hnext + (rt * 16 + l15) * LD + j * 16 + 4 * lq) = hv;
             }
@@ -633,6 +644,20 @@ extern "C" int mibc_lstm_rows_per_wg(int C) {
     return 0;
 }
 
+// Variable-chunk mode: x8 kernels only (C = 128 / 256 / 384); returns 1 for other widths.
+extern "C" int mibc_launch_lstm_layer_masked(hipStream_t s, int C, const half_t *Xin, half_t *Xout,
+                                             const half_t *Wf16, const float *biasn, int T, int N, int reverse,
+                                             const unsigned long long *tmask) {
+    if (Wf16 == nullptr || tmask == nullptr || N % 64 != 0) return 1;
+    dim3 g8(N / 64);
+    switch (C) {
+        case 128: hipLaunchKernelGGL((lstm_layer_x8_kernel<128, 4, true>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse, tmask); return 0;
+        case 256: hipLaunchKernelGGL((lstm_layer_x8_kernel<256, 4, true>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse, tmask); return 0;
+        case 384: hipLaunchKernelGGL((lstm_layer_x8_kernel<384, 4, true>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse, tmask); return 0;
+        default: return 1;
+    }
+}
+
 extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, half_t *Xout,
                                       const half_t *Wf, const half_t *Wf16, const float *biasn, int T, int N,
                                       int reverse) {
@@ -651,13 +676,13 @@ extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, h
     if (use_x8 && Wf16 != nullptr && (C == 128 || C == 256 || C == 384)) {
         dim3 g8(N / nb);
         switch (C) {
-            case 128: hipLaunchKernelGGL((lstm_layer_x8_kernel<128, 4>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse); return 0;
-            case 256: hipLaunchKernelGGL((lstm_layer_x8_kernel<256, 4>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse); return 0;
+            case 128: hipLaunchKernelGGL((lstm_layer_x8_kernel<128, 4>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse, (const unsigned long long *)nullptr); return 0;
+            case 256: hipLaunchKernelGGL((lstm_layer_x8_kernel<256, 4>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse, (const unsigned long long *)nullptr); return 0;
             default:
                 if (use_x8 == 3)
-                    hipLaunchKernelGGL((lstm_layer_x8_kernel<384, 3>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse);
+                    hipLaunchKernelGGL((lstm_layer_x8_kernel<384, 3>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse, (const unsigned long long *)nullptr);
                 else
-                    hipLaunchKernelGGL((lstm_layer_x8_kernel<384, 4>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse);
+                    hipLaunchKernelGGL((lstm_layer_x8_kernel<384, 4>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse, (const unsigned long long *)nullptr);
                 return 0;
         }
     }

@@ -79,6 +79,31 @@ std::vector<size_t> generate_chunks(size_t num_samples, size_t chunk_size, size_
     return offsets;
 }
 
+std::vector<std::pair<size_t, size_t>> generate_variable_chunks(size_t num_samples, size_t chunk_size, size_t stride,
+                                                               size_t overlap) {
+    if (num_samples == 0) throw std::runtime_error("generate_variable_chunks: empty read");
+    if (stride == 0) throw std::logic_error("generate_variable_chunks: invalid stride 0");
+    if (chunk_size == 0 || (chunk_size % stride) != 0 || chunk_size == stride || chunk_size <= overlap)
+        throw std::logic_error("generate_variable_chunks: invalid chunk size " + std::to_string(chunk_size));
+    if ((overlap % stride) != 0 || (stride != 1 && overlap == 0))
+        throw std::logic_error("generate_variable_chunks: invalid overlap " + std::to_string(overlap));
+    const size_t num_chunks =
+            1 + (num_samples > chunk_size
+                         ? size_t(std::ceil(double(num_samples - chunk_size) / double(chunk_size - overlap)))
+                         : 0);
+    const size_t with_overlaps = num_samples + (num_chunks - 1) * overlap;
+    const size_t num_longer = with_overlaps % num_chunks, adjusted = with_overlaps / num_chunks;
+    std::vector<std::pair<size_t, size_t>> iv;
+    for (size_t i = 0, start = 0; i < num_chunks; ++i) {
+        iv.emplace_back(start, start + adjusted + (i < num_longer ? 1 : 0));
+        start = iv.back().second - overlap;
+    }
+    for (size_t i = 1; i < num_chunks; ++i)
+        if (const size_t mis = iv[i].first % stride; mis != 0) iv[i].first += stride - mis;
+    for (size_t i = 0; i + 1 < num_chunks; ++i) iv[i].second -= iv[i].second % stride;
+    return iv;
+}
+
 StitchedRead stitch_chunks(const std::vector<const Chunk *> &cc, size_t raw_samples, int stride) {
     StitchedRead r;
     int start_pos = 0, mid_front = 0;
@@ -162,6 +187,40 @@ std::vector<DecodedChunk> HipCaller::call_chunks_i16(const int16_t *in, const fl
                                                      int num_chunks) {
     if (!ss) throw std::invalid_argument("call_chunks_i16: shift/scale pairs missing");
     return submit(reinterpret_cast<const uint16_t *>(in), ss, out, num_chunks);
+}
+
+std::vector<DecodedChunk> HipCaller::call_chunks_var(const uint16_t *in, int8_t *out,
+                                                     const std::vector<mibc_var_chunk> &chunks) {
+    if (chunks.empty()) return {};
+    auto task = std::make_shared<NNTask>();
+    task->in = in;
+    task->out = out;
+    task->num_chunks = int(chunks.size());
+    task->var = &chunks;
+    {
+        std::lock_guard<std::mutex> lk(m_mutex);
+        m_queue.push_front(task);
+    }
+    m_cv.notify_one();
+    {
+        std::unique_lock<std::mutex> lk(task->mut);
+        task->cv.wait(lk, [&] { return task->done; });
+    }
+    if (task->rc != MIBC_OK) throw std::runtime_error(std::string("mibc_call_var: ") + mibc_last_error(m_engine));
+    const size_t N = size_t(m_batch_size), T = size_t(m_T);
+    const int stride = model_stride();
+    std::vector<DecodedChunk> res(chunks.size());
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        const size_t t0 = size_t(chunks[i].sample_start / stride), tc = size_t(chunks[i].n_samples / stride);
+        const size_t base = size_t(chunks[i].row) * T + t0;
+        const int8_t *mv = out + base, *sq = out + N * T + base, *qs = out + 2 * N * T + base;
+        size_t nb = 0;
+        for (size_t t = 0; t < tc; ++t) nb += size_t(mv[t]);
+        res[i].moves.assign(mv, mv + tc);
+        res[i].sequence.assign(reinterpret_cast<const char *>(sq), nb);
+        res[i].qstring.assign(reinterpret_cast<const char *>(qs), nb);
+    }
+    return res;
 }
 
 std::vector<DecodedChunk> HipCaller::submit(const uint16_t *in, const float *ss, int8_t *out, int num_chunks) {
@@ -252,6 +311,9 @@ void HipCaller::gpu_thread_fn() {
         {
             std::lock_guard<std::mutex> elk(m_engine_mutex);
             auto run = [&]() {
+                if (task->var)
+                    return mibc_call_var(m_engine, task->in, nullptr, m_batch_size, m_chunk_size, task->var->data(),
+                                         int(task->var->size()), &m_opts, task->out);
                 return task->ss ? mibc_call_i16(m_engine, reinterpret_cast<const int16_t *>(task->in), task->ss,
                                                 m_batch_size, m_chunk_size, &m_opts, task->out)
                                 : mibc_call(m_engine, task->in, m_batch_size, m_chunk_size, &m_opts, task->out);
@@ -423,6 +485,12 @@ std::vector<DecodedChunk> HipModelRunner::call_chunks(int num_chunks) {
     return m_caller->call_chunks(m_in, m_out, num_chunks);
 }
 
+std::vector<DecodedChunk> HipModelRunner::call_chunks_var(const std::vector<mibc_var_chunk> &chunks) {
+    ++m_batches;
+    m_mode = 0;
+    return m_caller->call_chunks_var(m_in, m_out, chunks);
+}
+
 std::string HipModelRunner::get_name() const {  // unique per instance (CudaModelRunner.cpp:61-67)
     return "HipModelRunner_" + std::to_string(m_id) + "_hip:" + std::to_string(m_caller->device());
 }
@@ -543,6 +611,87 @@ std::vector<CalledRead> SimplexBasecaller::basecall_views(const std::vector<Read
     return out;
 }
 
+std::vector<CalledRead> SimplexBasecaller::basecall_variable(const std::vector<std::vector<uint16_t>> &reads) {
+    const size_t chunk_size = m_runners.at(0)->chunk_size(), stride = size_t(m_stride);
+    const size_t gap = 2 * stride;
+    struct Work {
+        size_t read, idx, offset, len;   // len = raw interval length (before the stride top-up)
+    };
+    std::vector<CalledRead> out(reads.size());
+    std::vector<std::vector<Chunk>> chunks(reads.size());
+    std::deque<Work> queue;
+    for (size_t r = 0; r < reads.size(); ++r) {
+        const auto iv = generate_variable_chunks(reads[r].size(), chunk_size, stride, size_t(m_overlap));
+        chunks[r].resize(iv.size());
+        for (size_t i = 0; i < iv.size(); ++i) {
+            out[r].chunk_offsets.push_back(iv[i].first);
+            chunks[r][i].input_offset = iv[i].first;
+            chunks[r][i].raw_chunk_size = iv[i].second - iv[i].first;
+            queue.push_back({r, i, iv[i].first, iv[i].second - iv[i].first});
+        }
+    }
+    std::mutex qmut;
+    auto worker = [&](ModelRunnerBase *base) {
+        auto *runner = dynamic_cast<HipModelRunner *>(base);
+        if (!runner) throw std::runtime_error("variable chunk sizes need a HipModelRunner");
+        const size_t batch = runner->batch_size();
+        while (true) {
+            // fill the rows first-fit in queue order (one lock per batch)
+            std::vector<Work> mine;
+            std::vector<mibc_var_chunk> table;
+            {
+                std::lock_guard<std::mutex> lk(qmut);
+                size_t row = 0, fill = 0;
+                while (!queue.empty()) {
+                    const Work w = queue.front();
+                    const size_t padded = (w.len + stride - 1) / stride * stride;   // BasecallerNode.cpp:408-416
+                    size_t start = fill ? fill + gap : 0;
+                    if (start + padded > chunk_size) {
+                        ++row;
+                        fill = 0;
+                        start = 0;
+                    }
+                    if (row >= batch) break;
+                    queue.pop_front();
+                    mine.push_back(w);
+                    table.push_back({int(row), int(start), int(padded)});
+                    fill = start + padded;
+                }
+            }
+            if (mine.empty()) return;
+            for (size_t r = 0; r < batch; ++r) std::memset(runner->batch_row(int(r)), 0, chunk_size * 2);
+            for (size_t k = 0; k < mine.size(); ++k) {
+                const uint16_t *src = reads[mine[k].read].data() + mine[k].offset;
+                uint16_t *dst = runner->batch_row(table[k].row) + table[k].sample_start;
+                for (size_t p = 0; p < size_t(table[k].n_samples); ++p) dst[p] = src[p % mine[k].len];
+            }
+            // rows must be presented in (row, start) order: they are, by construction
+            auto decoded = runner->call_chunks_var(table);
+            ++m_batches;
+            m_samples_incl_padding += int64_t(batch * chunk_size);
+            for (size_t k = 0; k < mine.size(); ++k) {
+                Chunk &c = chunks[mine[k].read][mine[k].idx];
+                c.seq = std::move(decoded[k].sequence);
+                c.qstring = std::move(decoded[k].qstring);
+                c.moves = std::move(decoded[k].moves);
+            }
+        }
+    };
+    std::vector<std::thread> threads;
+    for (auto &r : m_runners) threads.emplace_back(worker, r.get());
+    for (auto &t : threads) t.join();
+    for (size_t r = 0; r < reads.size(); ++r) {
+        std::vector<const Chunk *> cc;
+        for (auto &c : chunks[r]) cc.push_back(&c);
+        StitchedRead st = stitch_chunks(cc, reads[r].size(), m_stride);
+        out[r].seq = std::move(st.seq);
+        out[r].qstring = std::move(st.qstring);
+        out[r].moves = std::move(st.moves);
+        m_samples_processed += int64_t(reads[r].size());
+    }
+    return out;
+}
+
 NamedStats SimplexBasecaller::sample_stats() const {  // BasecallerNode.cpp:597-616
     return {{"samples_processed", double(m_samples_processed.load())},
             {"samples_incl_padding", double(m_samples_incl_padding.load())},
@@ -584,6 +733,54 @@ int mibch_dna_trim_start(int standardise, const uint16_t *f16, uint64_t n) {
     SignalNormalisationParams p;
     p.standardisation.standardise = standardise != 0;
     return dna_trim_start(p, f16, size_t(n));
+}
+
+// Same as mibch_basecall_reads but with variable chunk sizes (SimplexBasecaller::basecall_variable).
+int mibch_basecall_reads_variable(const mibc_model_desc *desc, const float *const *weights, int n_weights,
+                                  const char *device_string, int num_runners, int chunk_size, int overlap,
+                                  int batch_size, const mibc_decode_opts *opts, const uint16_t *signals,
+                                  const int64_t *read_len, int n_reads, char *seq_out, char *qstr_out,
+                                  int64_t *seq_len_out, uint8_t *moves_out, int64_t *moves_len_out,
+                                  int64_t *offsets_out, int64_t *n_offsets_out, double *stats4) {
+    try {
+        int stride = 1;
+        for (int i = 0; i < desc->n_convs; ++i) stride *= desc->conv_stride[i];
+        auto per_dev = create_basecall_runners(*desc, weights, n_weights, device_string, num_runners,
+                                               chunk_size, batch_size, *opts);
+        std::vector<RunnerPtr> flat;
+        for (auto &d : per_dev)
+            for (auto &r : d) flat.push_back(std::move(r));
+        SimplexBasecaller node(std::move(flat), overlap, stride);
+        std::vector<std::vector<uint16_t>> reads(static_cast<size_t>(n_reads));
+        size_t pos = 0;
+        for (int r = 0; r < n_reads; ++r) {
+            reads[size_t(r)].assign(signals + pos, signals + pos + read_len[r]);
+            pos += size_t(read_len[r]);
+        }
+        auto called = node.basecall_variable(reads);
+        size_t so = 0, mo = 0, oo = 0;
+        for (int r = 0; r < n_reads; ++r) {
+            const auto &c = called[size_t(r)];
+            std::memcpy(seq_out + so, c.seq.data(), c.seq.size());
+            std::memcpy(qstr_out + so, c.qstring.data(), c.qstring.size());
+            so += c.seq.size();
+            seq_len_out[r] = int64_t(c.seq.size());
+            std::memcpy(moves_out + mo, c.moves.data(), c.moves.size());
+            mo += c.moves.size();
+            moves_len_out[r] = int64_t(c.moves.size());
+            for (size_t o : c.chunk_offsets) offsets_out[oo++] = int64_t(o);
+            n_offsets_out[r] = int64_t(c.chunk_offsets.size());
+        }
+        auto st = node.sample_stats();
+        stats4[0] = st["samples_processed"];
+        stats4[1] = st["samples_incl_padding"];
+        stats4[2] = st["batches_called"];
+        stats4[3] = st["partial_batches_called"];
+        return 0;
+    } catch (const std::exception &e) {
+        g_herr = e.what();
+        return -1;
+    }
 }
 
 // Whole raw reads (int16) with per-read (shift, scale, trim_start): ScalerNode's host half decides the
@@ -631,6 +828,21 @@ int mibch_basecall_raw_reads(const mibc_model_desc *desc, const float *const *we
         stats4[2] = st["batches_called"];
         stats4[3] = st["partial_batches_called"];
         return 0;
+    } catch (const std::exception &e) {
+        g_herr = e.what();
+        return -1;
+    }
+}
+
+long mibch_generate_variable_chunks(uint64_t num_samples, uint64_t chunk_size, uint64_t stride, uint64_t overlap,
+                                    uint64_t *out_pairs, long max_out) {
+    try {
+        auto v = generate_variable_chunks(num_samples, chunk_size, stride, overlap);
+        for (size_t i = 0; i < v.size() && long(i) < max_out; ++i) {
+            out_pairs[2 * i] = v[i].first;
+            out_pairs[2 * i + 1] = v[i].second;
+        }
+        return long(v.size());
     } catch (const std::exception &e) {
         g_herr = e.what();
         return -1;

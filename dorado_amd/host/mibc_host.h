@@ -70,6 +70,10 @@ bool try_parse_device_ids(const std::string &device_string, size_t num_devices,
 std::vector<size_t> generate_chunks(size_t num_samples, size_t chunk_size, size_t stride,
                                     size_t overlap);  // throws like chunk.cpp:11-30
 
+// read_pipeline/base/chunk.cpp:49-107: nearly equal chunks, interior edges aligned to the stride (throws alike)
+std::vector<std::pair<size_t, size_t>> generate_variable_chunks(size_t num_samples, size_t chunk_size, size_t stride,
+                                                               size_t overlap);
+
 struct Chunk {  // read_pipeline/base/include/read_pipeline/base/messages.h (utils::Chunk)
     size_t input_offset = 0;
     size_t raw_chunk_size = 0;
@@ -141,6 +145,10 @@ public:
     // Raw int16 batch + pinned [batch][2] (shift, scale): scaling fused into conv1 (mibc_call_i16).
     std::vector<DecodedChunk> call_chunks_i16(const int16_t *in_pinned, const float *shift_scale_pinned,
                                               int8_t *out_pinned, int num_chunks);
+    // Several chunks per row (mibc_call_var); returns one DecodedChunk per entry of `chunks`.
+    std::vector<DecodedChunk> call_chunks_var(const uint16_t *in_pinned, int8_t *out_pinned,
+                                              const std::vector<mibc_var_chunk> &chunks);
+    int model_stride() const { return m_chunk_size / m_T; }
     // Per-read (shift, scale) of the QUANTILE / MED_MAD strategies on the device (mibc_scaler_stats).
     std::vector<std::pair<float, float>> scaler_stats(const std::vector<std::pair<const int16_t *, size_t>> &reads,
                                                       const SignalNormalisationParams &p);
@@ -159,6 +167,7 @@ private:
     struct NNTask {
         const uint16_t *in;
         const float *ss = nullptr;   // non-null: `in` holds raw int16 samples
+        const std::vector<mibc_var_chunk> *var = nullptr;   // non-null: several chunks per row
         int8_t *out;
         int num_chunks;
         int rc = 0;
@@ -192,6 +201,10 @@ public:
     // A batch is either all-f16 or all-int16 (the mode resets after every call_chunks).
     void accept_chunk_i16(int chunk_idx, const int16_t *chunk_raw, size_t n_samples, float shift, float scale);
     std::vector<DecodedChunk> call_chunks(int num_chunks) override;
+    // variable mode: write samples anywhere into the pinned batch, then call with the chunk table
+    uint16_t *batch_row(int row) { return m_in + size_t(row) * m_caller->chunk_size(); }
+    std::vector<DecodedChunk> call_chunks_var(const std::vector<mibc_var_chunk> &chunks);
+    bool variable_chunk_sizes() const override { return true; }
     const mibc_model_desc &config() const override { return m_caller->config(); }
     size_t chunk_size() const override { return size_t(m_caller->chunk_size()); }
     size_t batch_size() const override { return size_t(m_caller->batch_size()); }
@@ -239,6 +252,10 @@ public:
         float shift, scale;
     };
     std::vector<CalledRead> basecall_raw(const std::vector<RawRead> &reads);
+    // Variable chunk sizes (BasecallerNode.cpp:397-430 with m_variable_chunk_sizes): reads are cut with
+    // generate_variable_chunks, each chunk is topped up to a stride multiple by repeating its head, chunks of any
+    // length share batch rows (2-step gaps) and go through mibc_call_var.  f16 reads.
+    std::vector<CalledRead> basecall_variable(const std::vector<std::vector<uint16_t>> &reads_f16);
     NamedStats sample_stats() const;
 
 private:

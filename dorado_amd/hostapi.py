@@ -79,8 +79,19 @@ def stitch_chunks(offsets, raw_chunk_sizes, moves_list, seqs, qstrs, raw_samples
     return so.raw[:L].decode(), qo.raw[:L].decode(), mo[: nm.value].copy()
 
 
+def generate_variable_chunks(num_samples, chunk_size, stride, overlap):
+    cap = 1 << 17
+    out = (C.c_uint64 * (2 * cap))()
+    lib().mibch_generate_variable_chunks.restype = C.c_long
+    n = lib().mibch_generate_variable_chunks(C.c_uint64(num_samples), C.c_uint64(chunk_size), C.c_uint64(stride),
+                                             C.c_uint64(overlap), out, C.c_long(cap))
+    if n < 0:
+        raise ValueError(lib().mibch_last_error().decode())
+    return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
+
+
 def basecall_reads(cfg: ModelConfig, weights, reads_f16, device="hip:0", num_runners=2, batch_size=64,
-                   beam_width=32):
+                   beam_width=32, variable_chunks=False):
     """reads_f16: list of 1-D f16 arrays.  Returns (list of (seq, qstr, moves, chunk_offsets), stats)."""
     L = lib()
     d = cfg.to_desc()
@@ -100,7 +111,8 @@ def basecall_reads(cfg: ModelConfig, weights, reads_f16, device="hip:0", num_run
     offs = np.zeros(max_off, np.int64)
     noff = np.zeros(n, np.int64)
     stats = (C.c_double * 4)()
-    rc = L.mibch_basecall_reads(C.byref(d), arr, len(ws), device.encode(), num_runners, cfg.chunk_size,
+    fn = L.mibch_basecall_reads_variable if variable_chunks else L.mibch_basecall_reads
+    rc = fn(C.byref(d), arr, len(ws), device.encode(), num_runners, cfg.chunk_size,
                                 cfg.overlap, batch_size, C.byref(opts), sig.ctypes.data_as(C.c_void_p),
                                 lens.ctypes.data_as(_i64p), n, seq, qs, sl.ctypes.data_as(_i64p),
                                 mv.ctypes.data_as(_u8p), ml.ctypes.data_as(_i64p),

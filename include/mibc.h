@@ -146,6 +146,30 @@ int mibc_scaler_stats(mibc_engine *e, const int16_t *sig_dev, const int64_t *off
 int mibc_scale_reads(mibc_engine *e, const int16_t *sig_dev, const int64_t *offsets_dev, int n_reads,
                      const float *shift_scale_dev, uint16_t *out_f16_dev);
 
+/* ---- variable chunk sizes ----
+ * The reference's CUDA path packs ragged chunks (utils::generate_variable_chunks, read_pipeline/base/chunk.cpp:
+ * 49-107; basecall/CudaModelRunner.cpp:21-49; nn/AuxiliaryData.cpp) so that short reads are not repeat-padded to
+ * chunk_size.  Here a batch row [T_in] may hold several chunks: chunk = (row, sample_start, n_samples), both
+ * multiples of the model stride, chunks of one row in ascending order and >= 2 output steps (2 * stride samples)
+ * apart; samples outside every chunk are ignored.  Every chunk is called exactly as if it stood alone
+ * (zero padding at its edges, zero initial LSTM state, its own decode).  Output planes int8 [3][N][T]: chunk c
+ * occupies steps [sample_start / stride, (sample_start + n_samples) / stride) of its row in each plane (bases and
+ * qstring packed at the front of that interval, NUL padded); everything else is 0.
+ * shift_scale: NULL (input rows are scaled f16) or float [N][2] (input rows are raw int16, see above).
+ * LSTM models with lstm_size 128 / 256 / 384; others return MIBC_NOT_SUPPORTED. */
+typedef struct mibc_var_chunk {
+    int row;
+    int sample_start;
+    int n_samples;
+} mibc_var_chunk;
+int mibc_forward_var(mibc_engine *e, const void *in_dev, const float *shift_scale_dev, int N, int T_in,
+                     const mibc_var_chunk *chunks_host, int n_chunks, uint16_t *scores_dev);
+int mibc_call_device_var(mibc_engine *e, const void *in_dev, const float *shift_scale_dev, int N, int T_in,
+                         const mibc_var_chunk *chunks_host, int n_chunks, const mibc_decode_opts *opts,
+                         int8_t *out_dev);
+int mibc_call_var(mibc_engine *e, const void *in_host, const float *shift_scale_host, int N, int T_in,
+                  const mibc_var_chunk *chunks_host, int n_chunks, const mibc_decode_opts *opts, int8_t *out_host);
+
 /* ---- POD5 signal decode ----
  * The reference obtains a read's int16 samples from pod5_get_read_complete_signal
  * (dorado/data_loader/DataLoader.cpp:163-170; pod5-file-format 0.3.36, not vendored).  POD5 stores each

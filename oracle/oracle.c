@@ -128,6 +128,39 @@ ORC_API long orc_generate_chunks(uint64_t num_samples, uint64_t chunk_size, uint
     return n;
 }
 
+/* read_pipeline/base/chunk.cpp:49-107 (f3): nearly equal chunks, every interior edge
+ * aligned to the stride.  out = pairs (begin, end).  Returns the number of chunks or -1 where the
+ * reference throws. */
+ORC_API long orc_generate_variable_chunks(uint64_t num_samples, uint64_t chunk_size, uint64_t stride,
+                                          uint64_t overlap, uint64_t *out, long max_out) {
+    if (num_samples == 0 || stride == 0) return -1;
+    if (chunk_size == 0 || (chunk_size % stride) != 0 || chunk_size == stride || chunk_size <= overlap) return -1;
+    if ((overlap % stride) != 0 || (stride != 1 && overlap == 0)) return -1;
+    uint64_t num_chunks = 1;
+    if (num_samples > chunk_size) {
+        num_chunks += (uint64_t)ceil((double)(num_samples - chunk_size) / (double)(chunk_size - overlap));
+    }
+    const uint64_t with_overlaps = num_samples + (num_chunks - 1) * overlap;
+    const uint64_t num_longer = with_overlaps % num_chunks;
+    const uint64_t adjusted = with_overlaps / num_chunks;
+    uint64_t start = 0;
+    for (uint64_t i = 0; i < num_chunks; ++i) {
+        const uint64_t end = start + adjusted + (i < num_longer ? 1 : 0);
+        if ((long)i < max_out) {
+            out[2 * i] = start;
+            out[2 * i + 1] = end;
+        }
+        start = end - overlap;
+    }
+    const uint64_t n = num_chunks < (uint64_t)max_out ? num_chunks : (uint64_t)max_out;
+    for (uint64_t i = 1; i < n; ++i) {
+        const uint64_t mis = out[2 * i] % stride;
+        if (mis != 0) out[2 * i] += stride - mis;
+    }
+    for (uint64_t i = 0; i + 1 < n; ++i) out[2 * i + 1] -= out[2 * i + 1] % stride;
+    return (long)num_chunks;
+}
+
 /* read_pipeline/base/stitch.cpp:12-96.  Chunks i = 0..n-1 with input_offset[i],
  * raw_chunk_size[i], per-chunk moves (T_i each, concatenated; moves_off[i] = start), seq/qstr
  * (concatenated; seq_off[i], seq_len[i]).  Outputs the stitched read; returns the stitched

@@ -298,3 +298,20 @@ def svb16_encode(x_i16):
     lib().orc_svb16_encode.restype = C.c_long
     used = lib().orc_svb16_encode(x.ctypes.data_as(_i16p), C.c_long(x.size), buf.ctypes.data_as(_u8p))
     return buf[:used].copy()
+
+
+# ---------------------------------------------------------------- f3: variable chunks
+def generate_variable_chunks(num_samples, chunk_size, stride, overlap, use_ref=False):
+    """-> list of (begin, end), or raises ValueError where the reference throws (chunk.cpp:49-107)."""
+    cap = 1 << 17
+    out = (C.c_uint64 * (2 * cap))()
+    if use_ref:
+        n = ref().ref_generate_variable_chunks(C.c_uint64(num_samples), C.c_uint64(chunk_size), C.c_uint64(stride),
+                                               C.c_uint64(overlap), out, cap)
+    else:
+        lib().orc_generate_variable_chunks.restype = C.c_long
+        n = lib().orc_generate_variable_chunks(C.c_uint64(num_samples), C.c_uint64(chunk_size), C.c_uint64(stride),
+                                               C.c_uint64(overlap), out, C.c_long(cap))
+    if n < 0:
+        raise ValueError("generate_variable_chunks: invalid arguments")
+    return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]

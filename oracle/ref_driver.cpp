@@ -277,6 +277,22 @@ int ref_generate_chunks(uint64_t num_samples, uint64_t chunk_size, uint64_t stri
     }
 }
 
+// read_pipeline/base/chunk.cpp:49-107. Returns count, or -1 if the reference throws.
+int ref_generate_variable_chunks(uint64_t num_samples, uint64_t chunk_size, uint64_t stride, uint64_t overlap,
+                                 uint64_t *out_pairs, int max_out) {
+    try {
+        auto v = utils::generate_variable_chunks(num_samples, chunk_size, stride, overlap);
+        for (size_t i = 0; i < v.size() && int(i) < max_out; ++i) {
+            out_pairs[2 * i] = v[i].first;
+            out_pairs[2 * i + 1] = v[i].second;
+        }
+        return int(v.size());
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 // ---- signal scaling: the reference's own utils, torch_utils/tensor_utils.cpp ----
 
 // utils::quantile_counting (tensor_utils.cpp:217-245)

@@ -1,0 +1,183 @@
+"""variable chunk sizes.
+
+CPU: generate_variable_chunks (oracle restatement + the C++ host mirror) on the reference's known answers
+and properties (tests/ChunkTest.cpp:83-165) and against the compiled reference.
+GPU: several chunks per batch row through mibc_*_var — every chunk must come out exactly as if it had been
+called alone: scores vs the f32 oracle run on that chunk only (stated network tolerance), decoder bit-exact on
+the engine's own scores, and packed == alone on the engine itself (bit-identical scores)."""
+import numpy as np
+import pytest
+
+from dorado_amd import capi, config, hostapi, synth
+from oracle import oracle_py as O
+
+Interval = tuple
+
+
+def test_generate_variable_chunks_known_answers():
+    g = O.generate_variable_chunks
+    assert g(9996 // 2, 9996, 6, 498) == [(0, 4998)]
+    assert g(9996, 9996, 6, 498) == [(0, 9996)]
+    assert g(9996 + 1, 9996, 6, 498) == [(0, 5244), (4752, 9997)]
+    assert g(9996 + 9996 // 2, 9996, 6, 498) == [(0, 7746), (7248, 14994)]
+    assert g(2 * 9996 + 9996 // 2, 9996, 1, 0) == [(0, 8330), (8330, 16660), (16660, 24990)]
+    assert g(3 * 9996, 9996, 6, 498) == [(0, 7866), (7374, 15240), (14748, 22614), (22122, 29988)]
+    for bad in [(0, 9996, 6, 498), (12345, 0, 6, 498), (12345, 9996, 0, 498), (12345, 9996, 10, 498),
+                (12345, 6, 6, 498), (12345, 9996, 7, 498), (12345, 9996, 7, 0), (12345, 9996, 6, 9996),
+                (12345, 9996, 6, 9997)]:
+        with pytest.raises(ValueError):
+            g(*bad)
+        with pytest.raises(ValueError):
+            hostapi.generate_variable_chunks(*bad)
+
+
+@pytest.mark.parametrize("cs,st,ov", [(9996, 6, 498), (9996, 7, 497), (9996, 12, 492), (9996, 17, 510), (555, 5, 25),
+                                      (83, 1, 13), (123, 1, 0)])
+def test_generate_variable_chunks_properties(cs, st, ov):
+    rng = np.random.default_rng(42)
+    for n in rng.integers(1024, 2097152, 16):
+        iv = O.generate_variable_chunks(int(n), cs, st, ov)
+        assert iv == hostapi.generate_variable_chunks(int(n), cs, st, ov)
+        if O.have_ref():
+            assert iv == O.generate_variable_chunks(int(n), cs, st, ov, use_ref=True)
+        assert iv and iv[0][0] == 0 and iv[-1][1] == n
+        assert all(b % st == 0 for b, _ in iv[1:]) and all(e % st == 0 for _, e in iv[:-1])
+        assert all(0 < e - b <= cs for b, e in iv)
+        assert all(iv[i - 1][1] - iv[i][0] <= ov for i in range(1, len(iv)))
+
+
+# ---------------------------------------------------------------- GPU
+def _pack(lengths, t_in, stride, n_rows):
+    """first-fit rows, 2-step gaps -> [(row, sample_start, n_samples)]"""
+    fill = [0] * n_rows
+    out = []
+    for L in lengths:
+        for r in range(n_rows):
+            start = fill[r] + (2 * stride if fill[r] else 0)
+            if start + L <= t_in:
+                out.append((r, start, L))
+                fill[r] = start + L
+                break
+        else:
+            raise AssertionError("does not fit")
+    order = sorted(range(len(out)), key=lambda i: (out[i][0], out[i][1]))
+    return [out[i] for i in order], order
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("raw", [False, True])
+def test_packed_chunks_equal_standalone_chunks(raw):
+    cfg = config.tiny(128, 4)
+    cfg.lstm_layers = 5
+    ws = synth.make_weights(cfg, seed=61)
+    stride, t_in, N = cfg.stride, 2400, 64
+    rng = np.random.default_rng(5)
+    lengths = [int(v) * stride for v in rng.integers(12, 400, 95)] + [t_in, stride * 2, stride * 399]
+    chunks, order = _pack(lengths, t_in, stride, N)
+    sigs = [synth.make_signal(1, L, seed=300 + i)[0] for i, L in enumerate(lengths)]
+    sigs = [sigs[i] for i in order]
+    if raw:
+        X = np.zeros((N, t_in), np.int16)
+        ss = np.stack([rng.uniform(400, 560, N), rng.uniform(60, 120, N)], 1).astype(np.float32)
+        raws = [(480 + 95 * s.astype(np.float32)).astype(np.int16) for s in sigs]
+        for (r, s0, L), x in zip(chunks, raws):
+            X[r, s0:s0 + L] = x
+        X[X == 0] = 777                                   # garbage in the gaps must not matter
+        for (r, s0, L), x in zip(chunks, raws):
+            X[r, s0:s0 + L] = x
+        sigs = [O.shift_scale_i16_to_f16(x, float(ss[r, 0]), float(ss[r, 1])) for (r, _, _), x in zip(chunks, raws)]
+    else:
+        X = np.full((N, t_in), 3.0, np.float16)           # garbage in the gaps must not matter
+        ss = None
+        for (r, s0, L), x in zip(chunks, sigs):
+            X[r, s0:s0 + L] = x
+    eng = capi.Engine(cfg, ws)
+    S = eng.forward_var(X, chunks, ss)
+    calls = eng.call_var(X, chunks, ss)
+    K = cfg.outsize
+    worst_rms = 0.0
+    for i, ((r, s0, L), x) in enumerate(zip(chunks, sigs)):
+        t0, tc = s0 // stride, L // stride
+        got = S[r, t0:t0 + tc]
+        # (1) decoder on the engine's own scores of this chunk: bit-exact moves / bases, qstring +-1
+        dec_in = got[None].astype(np.float32)
+        if cfg.clamp:
+            dec_in = np.clip(dec_in, -5.0, 5.0)            # the engine folds the clamp into the decoder's score read
+        want = O.decode(dec_in, q_shift=cfg.qbias, q_scale=cfg.qscale, det=1)[0]
+        assert calls[i][0] == want[0] and (calls[i][2] == want[2]).all()
+        assert np.abs(np.frombuffer(calls[i][1].encode(), np.uint8).astype(int) -
+                      np.frombuffer(want[1].encode(), np.uint8).astype(int)).max(initial=0) <= 1
+        # (2) network vs the f32 oracle run on this chunk alone (stated tolerance of the scores contract)
+        if i % 6 == 0 or L <= 4 * stride:
+            ref = O.lstm_crf_forward(cfg, ws, x.astype(np.float32)[None, None, :])[0]
+            assert ref.shape == (tc, K)
+            d = np.clip(got.astype(np.float32), -5, 5) - np.clip(ref, -5, 5)
+            worst_rms = max(worst_rms, float(np.sqrt((d ** 2).mean())))
+            assert np.abs(d).max() <= 0.15
+    assert worst_rms <= 0.012
+    # (3) packed == alone on the engine itself: a chunk at the start of an otherwise empty row
+    for i in (0, len(chunks) // 2, len(chunks) - 1):
+        r, s0, L = chunks[i]
+        Xa = np.zeros((N, t_in), np.float16)
+        Xa[0, :L] = sigs[i]
+        Sa = eng.forward_var(Xa, [(0, 0, L)])
+        assert (Sa[0, :L // stride].view(np.uint16) == S[r, s0 // stride:(s0 + L) // stride].view(np.uint16)).all()
+    # full-length single chunk per row vs the fixed-size path: same mathematics through a separately compiled
+    # (masked) LSTM instance -> identical up to f16 rounding of individual activations
+    Xf = synth.make_signal(N, t_in, seed=9)
+    dv = np.abs(eng.forward_var(Xf, [(r, 0, t_in) for r in range(N)]).astype(np.float32) -
+                eng.forward(Xf).astype(np.float32))
+    assert dv.max() <= 0.02 and float(np.sqrt((dv ** 2).mean())) <= 1e-3
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_variable_chunk_argument_errors():
+    cfg = config.tiny(128, 4)
+    eng = capi.Engine(cfg, synth.make_weights(cfg, seed=1))
+    X = np.zeros((64, 1200), np.float16)
+    for bad in [[(0, 0, 1201)], [(0, 3, 600)], [(0, 0, 601)], [(64, 0, 600)], [(0, 0, 600), (0, 606, 300)],
+                [(0, 600, 300), (0, 0, 300)], []]:
+        with pytest.raises(capi.MibcError):
+            eng.forward_var(X, bad)
+    eng.forward_var(X, [(0, 0, 600), (0, 612, 300)])           # exactly 2 steps apart is fine
+    eng.close()
+    c512 = config.tiny(512, 5)
+    e2 = capi.Engine(c512, synth.make_weights(c512, seed=1))
+    with pytest.raises(capi.MibcNotSupported):
+        e2.forward_var(np.zeros((64, 1200), np.float16), [(0, 0, 600)])
+    e2.close()
+
+
+@pytest.mark.gpu
+def test_host_layer_variable_chunks_vs_reference_order_of_operations():
+    """C++ host layer with variable chunk sizes (SimplexBasecaller::basecall_variable -> mibc_call_var): chunk
+    intervals bit-exact vs the oracle, stitched reads == oracle stitch of the per-chunk calls the engine gives
+    for the same chunks packed differently (one chunk per row), and fewer padded samples than fixed chunks."""
+    cfg = config.tiny(128, 4)
+    cfg.lstm_layers = 5
+    cfg.chunk_size, cfg.overlap = 1200, 120
+    cfg.normalise_basecaller_params()
+    ws = synth.make_weights(cfg, seed=71)
+    lens = [300, 1200, 1201, 2500, 3333, 5000, 799, 4096, 61, 1800]
+    reads = [synth.make_signal(1, L, seed=500 + i)[0] for i, L in enumerate(lens)]
+    got, stats = hostapi.basecall_reads(cfg, ws, reads, num_runners=2, batch_size=64, variable_chunks=True)
+    _, stats_fixed = hostapi.basecall_reads(cfg, ws, reads, num_runners=2, batch_size=64)
+    assert stats["samples_processed"] == sum(lens)
+    eng = capi.Engine(cfg, ws)
+    st = cfg.stride
+    for r, sig in enumerate(reads):
+        iv = O.generate_variable_chunks(len(sig), cfg.chunk_size, st, cfg.overlap)
+        assert got[r][3] == [b for b, _ in iv]
+        rows, table = np.zeros((64, cfg.chunk_size), np.float16), []
+        for k, (b, e) in enumerate(iv):
+            L = e - b
+            P = (L + st - 1) // st * st                                 # BasecallerNode.cpp:408-416 top-up
+            rows[k, :P] = np.resize(sig[b:e], P)
+            table.append((k, 0, P))
+        calls = eng.call_var(rows, table)
+        want = O.stitch_chunks([b for b, _ in iv], [e - b for b, e in iv], [c[2] for c in calls],
+                               [c[0] for c in calls], [c[1] for c in calls], len(sig), st)
+        assert got[r][0] == want[0] and got[r][1] == want[1] and (got[r][2] == want[2]).all()
+    eng.close()
+    assert sum(len(g[0]) for g in got) > 1000
