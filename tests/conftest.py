@@ -11,6 +11,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    # torch.jit is only used by test_tensor_loader.py to WRITE archives in the reference's format
+    config.addinivalue_line("filterwarnings", "ignore:.*torch.jit.*:DeprecationWarning")
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
