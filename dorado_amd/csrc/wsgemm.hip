@@ -265,7 +265,7 @@ extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mod
     if (mode == 1 && CT == 4 && NW == 8) RT = 6;   // 128 rows x 64 columns per wave would spill
     if (mode == 0) {
         if (NW == 8) RT = (CT == 4) ? (KT >= 16 ? 5 : KT >= 8 ? 6 : 8) : 8;
-        else RT = (KT >= 16) ? 4 : (KT >= 12) ? 5 : 8;
+        else RT = (KT >= 12) ? 4 : 8;
     }
     const int rows = RT * 16;
     size_t smem;
@@ -317,7 +317,7 @@ extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mod
     WS_CASE(4, 0, 4, 8, 8) WS_CASE(8, 0, 4, 6, 8) WS_CASE(12, 0, 4, 6, 8) WS_CASE(16, 0, 4, 5, 8)
     WS_CASE(4, 0, 2, 8, 8) WS_CASE(8, 0, 2, 8, 8)
     WS_CASE(10, 1, 4, 6, 8) WS_CASE(10, 1, 3, 8, 8) WS_CASE(10, 1, 2, 8, 8)
-    WS_CASE(10, 1, 3, 8, 4)
+    WS_CASE(10, 1, 3, 8, 4) WS_CASE(12, 0, 4, 4, 4)
 #undef WS_CASE
 #undef WS_ONE
     return 1;
