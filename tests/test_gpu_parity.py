@@ -418,3 +418,30 @@ def test_host_layer_raw_reads_equal_prescaled_reads():
     for g, w in zip(got, want):
         assert g[0] == w[0] and g[1] == w[1] and (g[2] == w[2]).all() and g[3] == w[3]
     assert sum(len(g[0]) for g in got) > 500
+
+
+@pytest.mark.parametrize("W,cut,stay", [(32, 100.0, 2.0), (16, 100.0, 2.0), (5, 10.0, 2.0), (1, 100.0, 2.0),
+                                         (32, 3.0, 0.5), (24, 1e9, 3.5)])
+def test_decoder_options_bit_exact(W, cut, stay):
+    """DecoderOptions other than the defaults (basecall/include/basecall/DecodedChunk.h:15-23): beam width,
+    beam cut and the fixed stay score go through the same code paths of beam_search.cpp:125-455 — narrower
+    beams exercise the bisection cut-off and the in-order compaction much harder.  Moves / bases bit-exact vs
+    the oracle (det), qstring +-1."""
+    g = np.load(os.path.join(GOLDEN, "dec_s4.npz"))
+    s16 = g["scores_f16"]
+    cfg = _cfg(128, 4, 0)
+    eng = capi.Engine(cfg, synth.make_weights(cfg, seed=1))
+    eng.opts.beam_width, eng.opts.beam_cut, eng.opts.blank_score = W, cut, stay
+    eng.opts.q_shift, eng.opts.q_scale = -0.5, 0.9
+    dec = eng.decode(s16)
+    dec_o = O.decode(s16.astype(np.float32), beam_width=W, beam_cut=cut, blank=stay, q_shift=-0.5, q_scale=0.9, det=1)
+    for (seq, qs, mv), (so, qo, mo) in zip(dec, dec_o):
+        assert seq == so and (mv == mo).all()
+        dq = np.abs(np.frombuffer(qs.encode(), np.uint8).astype(int) -
+                    np.frombuffer(qo.encode(), np.uint8).astype(int))
+        assert dq.max(initial=0) <= 1
+    eng.close()
+    with pytest.raises(capi.MibcNotSupported):
+        e2 = capi.Engine(cfg, synth.make_weights(cfg, seed=1))
+        e2.opts.beam_width = 33
+        e2.decode(s16)
