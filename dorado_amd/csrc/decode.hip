@@ -19,6 +19,7 @@
 //                        HBM —, then sequence / qstring emission.
 #include "common.h"
 #include "detmath.h"
+#include <stdlib.h>
 
 #define FLT_LOWEST (-3.402823466e+38f)
 
@@ -85,6 +86,62 @@ __global__ void bwd_scan_kernel(const half_t *__restrict__ scores,  // [N][T][4S
         mine = v;
         beta[(p ^ 1) * S + s] = v;
         bn[(size_t)t * S + s] = v;
+        p ^= 1;
+    }
+}
+
+// k1 (two states per thread): thread j owns states j and j + S/2.  Both read the SAME four successor back-guides
+// (their successor index (s << 2) mod S coincides) and differ only in the score row (fell-off base hi and hi + 2),
+// so the log-sum-exp runs on the packed-f32 pipe for two states at once and the LDS guide reads are halved.
+// Element-wise the arithmetic is the scalar kernel's: bit-identical output.
+__global__ void bwd_scan2_kernel(const half_t *__restrict__ scores,  // [N][T][4S]
+                                 float *__restrict__ bwd,            // [N][T+1][S]
+                                 int T, int S, float stay, float clampv, VarIdx vi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *beta = (float *)smem;                     // [2][S]
+    half_t *sc = (half_t *)(smem + 2 * S * 4);       // [2][4][S]  ([buf][base that fell off][dest])
+    const int n = blockIdx.x;
+    const int j = threadIdx.x;                       // 0 .. S/2 - 1
+    const int H = S >> 1;
+    const int K = 4 * S;
+    const int Q = S >> 2;
+    VAR_SETUP(T)
+    const half_t *sn = scores + so * K;
+    float *bn = bwd + bo * S;
+
+    beta[j] = 0.0f;
+    beta[j + H] = 0.0f;
+    bn[(size_t)T * S + j] = 0.0f;
+    bn[(size_t)T * S + j + H] = 0.0f;
+    dm_f2 mine = (dm_f2)(0.0f);
+    half8_t row = *(const half8_t *)(sn + (size_t)(T - 1) * K + 8 * j);   // scores of dest states 2j, 2j+1
+    const int hi = j / Q;                            // fell-off base of state j; state j + S/2 has hi + 2
+    const int n0 = (j << 2) & (S - 1);
+    const half_t ch = (half_t)((clampv > 0.0f) ? fminf(clampv, 65504.0f) : 65504.0f);
+    typedef _Float16 half2_l __attribute__((ext_vector_type(2)));
+    int p = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        half_t *scw = sc + p * K;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) *(half2_l *)(scw + b * S + 2 * j) = half2_l{row[b], row[4 + b]};
+        __syncthreads();
+        if (t > 0) {
+            row = *(const half8_t *)(sn + (size_t)(t - 1) * K + 8 * j);
+        }
+        const float4_t b4 = *(const float4_t *)(beta + p * S + n0);
+        const half4_t ma = __builtin_elementwise_min(
+                __builtin_elementwise_max(*(const half4_t *)(scw + hi * S + n0), (half4_t)(-ch)), (half4_t)(ch));
+        const half4_t mb = __builtin_elementwise_min(
+                __builtin_elementwise_max(*(const half4_t *)(scw + (hi + 2) * S + n0), (half4_t)(-ch)), (half4_t)(ch));
+        const dm_f2 v = dm2_lse5(mine + (dm_f2)(stay), dm_f2{b4[0] + (float)ma[0], b4[0] + (float)mb[0]},
+                                 dm_f2{b4[1] + (float)ma[1], b4[1] + (float)mb[1]},
+                                 dm_f2{b4[2] + (float)ma[2], b4[2] + (float)mb[2]},
+                                 dm_f2{b4[3] + (float)ma[3], b4[3] + (float)mb[3]});
+        mine = v;
+        beta[(p ^ 1) * S + j] = v[0];
+        beta[(p ^ 1) * S + j + H] = v[1];
+        bn[(size_t)t * S + j] = v[0];
+        bn[(size_t)t * S + j + H] = v[1];
         p ^= 1;
     }
 }
@@ -688,7 +745,11 @@ extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int 
     int8_t *qstr = out3 + 2 * plane_stride;
     const float log_cut = (beam_cut > 0.0f) ? logf(beam_cut) : 3.402823466e+38f;
     const size_t smem1 = (size_t)2 * S * 4 + (size_t)2 * 4 * S * 2;
-    hipLaunchKernelGGL(bwd_scan_kernel, dim3(N), dim3(S), smem1, st, scores, bwd, T, S, stay, clampv, vi);
+    static const int k1_pair = getenv("MIBC_K1_PAIR") ? atoi(getenv("MIBC_K1_PAIR")) : 1;
+    if (k1_pair && S >= 128)
+        hipLaunchKernelGGL(bwd_scan2_kernel, dim3(N), dim3(S / 2), smem1, st, scores, bwd, T, S, stay, clampv, vi);
+    else
+        hipLaunchKernelGGL(bwd_scan_kernel, dim3(N), dim3(S), smem1, st, scores, bwd, T, S, stay, clampv, vi);
     switch (S) {
         case 64:
             hipLaunchKernelGGL((beam_search_kernel<64>), dim3(N), dim3(64), 0, st, scores, bwd, trace,
