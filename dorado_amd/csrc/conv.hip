@@ -16,7 +16,10 @@
 #define C12_W 5
 #define C12_ROW 20   // padded LDS row (floats): 80 B stride => conflict-free ds_read_b128
 
-template <int ACT1, int ACT2>
+// RAW: x holds raw int16 samples and `ss` the per-chunk (shift, scale) (ScalerNode fused);
+// VAR: `smask` marks the samples that belong to a chunk (variable chunk sizes, 8f-3).  Both are compile-time
+// so that the plain f16 / fixed-size instantiation keeps its scalar-register weight schedule.
+template <int ACT1, int ACT2, bool RAW, bool VAR>
 __global__ __launch_bounds__(C12_TT) void conv12_kernel(
         const half_t *__restrict__ x,    // [N][T_in]
         const float *__restrict__ w1,    // [5][16]     (k, co)
@@ -32,6 +35,7 @@ __global__ __launch_bounds__(C12_TT) void conv12_kernel(
                                              // each convolution level, exactly as if the chunk stood alone
         int T_in, int Tpitch, int pad) {
     __shared__ float xs[C12_TT + 8];
+    __shared__ unsigned char xm[C12_TT + 8];   // VAR: sample t0 - 4 + i belongs to a chunk
     __shared__ __attribute__((aligned(16))) float o1[(C12_TT + 4) * C12_ROW];
     const int n = blockIdx.y;
     const int t0 = blockIdx.x * C12_TT;
@@ -40,21 +44,26 @@ __global__ __launch_bounds__(C12_TT) void conv12_kernel(
 
     const int mwords = (T_in + 31) >> 5;
     auto in_mask = [&](int t) -> bool {
-        return smask == nullptr || ((smask[(size_t)n * mwords + (t >> 5)] >> (t & 31)) & 1u);
+        if constexpr (!VAR) return true;
+        return (smask[(size_t)n * mwords + (t >> 5)] >> (t & 31)) & 1u;
     };
-    if (ss != nullptr) {
+    if constexpr (RAW) {
         // tensor_utils.cpp:89-142 semantics: f32 subtract, IEEE divide, round to f16 — the value the
         // reference's pipeline would have stored in the read before chunking
         const int16_t *xi = (const int16_t *)x + (size_t)n * T_in;
         const float shift = ss[2 * n], scale = ss[2 * n + 1];
         for (int i = tid; i < C12_TT + 8; i += C12_TT) {
             const int t = t0 - 4 + i;
-            xs[i] = (t >= 0 && t < T_in && in_mask(t)) ? (float)(half_t)(((float)xi[t] - shift) / scale) : 0.0f;
+            const bool ok = (t >= 0 && t < T_in && in_mask(t));
+            xs[i] = ok ? (float)(half_t)(((float)xi[t] - shift) / scale) : 0.0f;
+            if constexpr (VAR) xm[i] = ok;
         }
     } else {
         for (int i = tid; i < C12_TT + 8; i += C12_TT) {
             const int t = t0 - 4 + i;
-            xs[i] = (t >= 0 && t < T_in && in_mask(t)) ? (float)xn[t] : 0.0f;
+            const bool ok = (t >= 0 && t < T_in && in_mask(t));
+            xs[i] = ok ? (float)xn[t] : 0.0f;
+            if constexpr (VAR) xm[i] = ok;
         }
     }
     __syncthreads();
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(C12_TT) void conv12_kernel(
     for (int r = tid; r < C12_TT + 4; r += C12_TT) {
         const int t = t0 - 2 + r;
         bool inside = (t >= 0 && t < T_in);
-        if (inside) inside = in_mask(t);
+        if constexpr (VAR) inside = inside && xm[r + 2];   // time t <-> xs index t - (t0 - 4) = r + 2
         float acc[C12_CH];
 #pragma unroll
         for (int c = 0; c < C12_CH; ++c) acc[c] = b1[c];
@@ -108,11 +117,14 @@ __global__ __launch_bounds__(C12_TT) void conv12_kernel(
         }
     }
     half8_t o0, o1v;
-    const bool in2 = in_mask(t);
+    // VAR: samples outside every chunk become +0 through a bit mask (a select here makes the compiler branch
+    // around the whole conv2 accumulation and lose its scalar-register weight schedule)
+    uint32_t mk = 0xffffffffu;
+    if constexpr (VAR) mk = xm[tid + 4] ? 0xffffffffu : 0u;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        o0[c] = in2 ? (half_t)act_apply(acc[c], ACT2) : (half_t)0.0f;
-        o1v[c] = in2 ? (half_t)act_apply(acc[8 + c], ACT2) : (half_t)0.0f;
+        o0[c] = (half_t)__builtin_bit_cast(float, __builtin_bit_cast(uint32_t, act_apply(acc[c], ACT2)) & mk);
+        o1v[c] = (half_t)__builtin_bit_cast(float, __builtin_bit_cast(uint32_t, act_apply(acc[8 + c], ACT2)) & mk);
     }
     half8_t *dst = (half8_t *)(a2p + ((size_t)n * Tpitch + pad + t) * C12_CH);
     dst[0] = o0;
@@ -123,9 +135,16 @@ extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w
                                   const float *w2, const float *b2, half_t *a2p, half_t *a1_tap, const float *ss,
                                   const uint32_t *smask, int N, int T_in, int Tpitch, int pad, int act1, int act2) {
     dim3 grid((T_in + C12_TT - 1) / C12_TT, N);
-#define LAUNCH(A1, A2)                                                                          \
-    hipLaunchKernelGGL((conv12_kernel<A1, A2>), grid, dim3(C12_TT), 0, s, x, w1, b1, w2, b2, a2p, \
-                       a1_tap, ss, smask, T_in, Tpitch, pad)
+#define LAUNCH4(A1, A2, R, V)                                                                          \
+    hipLaunchKernelGGL((conv12_kernel<A1, A2, R, V>), grid, dim3(C12_TT), 0, s, x, w1, b1, w2, b2, a2p, a1_tap, ss, \
+                       smask, T_in, Tpitch, pad)
+#define LAUNCH(A1, A2)                                                                                 \
+    do {                                                                                               \
+        if (ss != nullptr && smask != nullptr) LAUNCH4(A1, A2, true, true);                            \
+        else if (ss != nullptr) LAUNCH4(A1, A2, true, false);                                          \
+        else if (smask != nullptr) LAUNCH4(A1, A2, false, true);                                       \
+        else LAUNCH4(A1, A2, false, false);                                                            \
+    } while (0)
     if (act1 == 0 && act2 == 0) {
         LAUNCH(0, 0);
     } else if (act1 == 1 && act2 == 1) {
@@ -138,5 +157,6 @@ extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w
         return 1;
     }
 #undef LAUNCH
+#undef LAUNCH4
     return 0;
 }
