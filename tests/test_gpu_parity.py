@@ -445,3 +445,36 @@ def test_decoder_options_bit_exact(W, cut, stay):
         e2 = capi.Engine(cfg, synth.make_weights(cfg, seed=1))
         e2.opts.beam_width = 33
         e2.decode(s16)
+
+
+def test_stage_time_ratios_guard():
+    """Not a benchmark: a tripwire for code-generation accidents (a run-time select in conv12 once made the
+    compiler abandon its scalar-register weight schedule: 6 -> 97 ms at the bench size with all parity tests
+    still green).  hac shape, 1024 chunks: the front-end convolutions, the head and the decoder must each stay
+    well below the LSTM stack."""
+    cfg = config.hac_v43()
+    eng = capi.Engine(cfg, synth.make_weights(cfg, seed=1))
+    N, T_in = 1024, cfg.chunk_size
+    x = synth.make_signal(64, T_in, seed=2)
+    X = np.tile(x, (N // 64, 1))
+    eng.set_profile(1)
+    d_in = eng.device_alloc(X.nbytes)
+    d_out = eng.device_alloc(3 * N * eng.output_steps(T_in))
+    try:
+        eng.reserve(N, T_in)
+        eng.h2d(d_in, X)
+        for _ in range(2):
+            eng.call_device(d_in, N, T_in, d_out)
+            eng.sync()
+        st = eng.stage_ms()
+    finally:
+        eng.device_free(d_in)
+        eng.device_free(d_out)
+        eng.close()
+    print("stage_ms", st)
+    assert st["lstm"] > 0
+    # measured on MI355X at this size: conv 1.1, head 1.5, decode 9.6, LSTM 207 ms; limits = ~2.5-3x
+    assert st["conv"] < 3.5, st
+    assert st["head"] < 5.0, st
+    assert st["decode"] < 28.0, st
+    assert st["lstm"] < 450.0, st
