@@ -20,6 +20,16 @@ extern "C" int mibc_device_count(void) {
     return n;
 }
 
+// free / total bytes of a device (utils::available_memory, torch_utils/cuda_utils.cpp:250-262)
+extern "C" int mibc_device_memory(int device_id, size_t *free_bytes, size_t *total_bytes) {
+    if (hipSetDevice(device_id) != hipSuccess) return MIBC_ERR_HIP;
+    size_t f = 0, t = 0;
+    if (hipMemGetInfo(&f, &t) != hipSuccess) return MIBC_ERR_HIP;
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return MIBC_OK;
+}
+
 extern "C" const char *mibc_last_error(const mibc_engine *e) {
     return e ? e->err.c_str() : g_err.c_str();
 }

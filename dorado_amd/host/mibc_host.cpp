@@ -149,6 +149,24 @@ HipCaller::HipCaller(const mibc_model_desc &desc, const float *const *weights, i
     const int rc = mibc_create(device, &desc, weights, n_weights, &m_engine);
     if (rc != MIBC_OK) throw std::runtime_error(std::string("mibc_create: ") + mibc_last_error(nullptr));
     const int g = mibc_batch_granularity(m_engine);
+    if (batch_size <= 0) {
+        // Auto batch size (the role of CudaCaller::determine_batch_dims, CudaCaller.cpp:323-569, whose timing sweep
+        // looks for the knee of a GPU that batches across SMs).  On this engine the LSTM runs one 64-chunk workgroup
+        // per CU for the whole chunk, so the knee is known: one workgroup on every CU (256 * granularity), bounded by
+        // what fits in 80 % of the free device memory (mibc_query_memory = the memory model of :323-369).
+        size_t per_chunk = 0, fixed = 0, free_b = 0, total_b = 0;
+        if (mibc_query_memory(m_engine, chunk_size, &per_chunk, &fixed) != MIBC_OK ||
+            mibc_device_memory(device, &free_b, &total_b) != MIBC_OK || per_chunk == 0) {
+            const std::string msg = mibc_last_error(m_engine);
+            mibc_destroy(m_engine);
+            throw std::runtime_error("auto batch size: " + msg);
+        }
+        const double budget = 0.8 * double(free_b) - double(fixed);
+        long cap = budget > 0 ? long(budget / double(per_chunk)) : 0;
+        long want = (desc.tx_d_model > 0) ? 1024 : 256L * g;
+        long n = std::min(want, cap / g * g);
+        batch_size = int(std::max<long>(g, n));
+    }
     m_batch_size = (batch_size + g - 1) / g * g;
     m_T = mibc_output_steps(m_engine, chunk_size);
     if (mibc_reserve(m_engine, m_batch_size, chunk_size) != MIBC_OK) {

@@ -75,6 +75,7 @@ typedef struct mibc_engine mibc_engine;
 
 /* ---- devices (replaces torch_utils/cuda_utils.cpp:224-248,364-384 device discovery) ---- */
 int mibc_device_count(void);
+int mibc_device_memory(int device_id, size_t *free_bytes, size_t *total_bytes); /* cuda_utils.cpp:250-262 */
 const char *mibc_last_error(const mibc_engine *e); /* e may be NULL: last global error */
 
 /* ---- lifetime (replaces CudaCaller ctor: basecall/CudaCaller.cpp:149-200) ----

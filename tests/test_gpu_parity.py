@@ -478,3 +478,18 @@ def test_stage_time_ratios_guard():
     assert st["head"] < 5.0, st
     assert st["decode"] < 28.0, st
     assert st["lstm"] < 450.0, st
+
+
+def test_host_layer_auto_batch_size():
+    """batch_size = 0 -> the caller sizes the batch itself (one LSTM workgroup per CU, bounded by
+    mibc_query_memory against mibc_device_memory); calls are independent of the batch size."""
+    cfg = _cfg(128, 4, 5)
+    cfg.chunk_size, cfg.overlap = 1200, 120
+    cfg.normalise_basecaller_params()
+    ws = synth.make_weights(cfg, seed=31)
+    reads = [synth.make_signal(1, L, seed=100 + i)[0] for i, L in enumerate([300, 2500, 5000, 1201])]
+    auto, st_auto = hostapi.basecall_reads(cfg, ws, reads, num_runners=1, batch_size=0)
+    fixed, _ = hostapi.basecall_reads(cfg, ws, reads, num_runners=1, batch_size=64)
+    assert st_auto["samples_incl_padding"] >= st_auto["samples_processed"] == sum(len(r) for r in reads)
+    for a, f in zip(auto, fixed):
+        assert a[0] == f[0] and a[1] == f[1] and (a[2] == f[2]).all()
