@@ -539,6 +539,9 @@ __global__ __launch_bounds__(64) void beam_search_kernel(
 // k3: forward scan + posterior of the called path + sequence/qstring
 //     (CPUDecoder.cpp:43-64,130; beam_search.cpp:459-517; beam_search.cpp:54-102)
 // ---------------------------------------------------------------------------------------------
+// PAIR: S/2 threads, thread j owns states j and j + S/2 (half the waves per chunk, half the wave reductions,
+// plain arithmetic on the packed-f32 pipe); !PAIR: one state per thread (S = 64).
+template <bool PAIR>
 __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N][T][4S]
                                   const float *__restrict__ bwd,          // [N][T+1][S]
                                   const uint16_t *__restrict__ path_state,  // [N][T]
@@ -555,36 +558,45 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
     uint16_t *pst = (uint16_t *)(prob + T);       // [T]
     int8_t *pmv = (int8_t *)(pst + T);            // [T]
     __shared__ int s_len;
+    constexpr int NS = PAIR ? 2 : 1;
 
     const int n = blockIdx.x;
-    const int s = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int NT = PAIR ? (S >> 1) : S;           // threads of this workgroup
     const int K = 4 * S;
     const int Q = S >> 2;
-    const int nw = (S + 63) >> 6;
-    const int wave = s >> 6, lane = s & 63;
+    const int nw = (NT + 63) >> 6;
+    const int wave = tid >> 6, lane = tid & 63;
     VAR_SETUP(T)   // after the LDS carve-up above, which uses the launch-wide maximum T
     const half_t *sn = scores + so * K;
     const float *bn = bwd + bo * S;
+    int sid[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) sid[k] = tid + k * NT;
 
-    for (int i = s; i < T; i += S) {
+    for (int i = tid; i < T; i += NT) {
         pst[i] = path_state[so + i];
         pmv[i] = moves[so + i];
     }
     // log Z = LSE_s(bwd[0][s])  (alpha[0] = 0): shift for the posterior exponent
     float logZ;
     {
-        const float v = bn[s];
-        float m = v;
+        float v[NS], m = FLT_LOWEST;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        for (int k = 0; k < NS; ++k) {
+            v[k] = bn[sid[k]];
+            m = fmaxf(m, v[k]);
+        }
+        m = wave_max(m);
         if (lane == 0) red[wave] = m;
         __syncthreads();
         float mm = red[0];
         for (int i = 1; i < nw; ++i) mm = fmaxf(mm, red[i]);
         __syncthreads();
-        float e = dm_expf(v - mm);
+        float e = 0.0f;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+        for (int k = 0; k < NS; ++k) e += dm_expf(v[k] - mm);
+        e = wave_sum(e);
         if (lane == 0) red[wave] = e;
         __syncthreads();
         float es = red[0];
@@ -592,44 +604,65 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
         logZ = mm + dm_logf(es);
         __syncthreads();
     }
-    alpha[s] = 0.0f;
-    float mine = 0.0f;
-    const int pred = s >> 2;
-    half4_t row = *(const half4_t *)(sn + 4 * s);
-    float bnext = bn[(size_t)S + s];
+    float mine[NS], bnext[NS];
+    half4_t row[NS];
+    int pred[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        alpha[sid[k]] = 0.0f;
+        mine[k] = 0.0f;
+        pred[k] = sid[k] >> 2;
+        row[k] = *(const half4_t *)(sn + 4 * sid[k]);
+        bnext[k] = bn[(size_t)S + sid[k]];
+    }
     int p = 0;
     __syncthreads();
+    constexpr float LOG2E = 1.44269504f, LN2 = 0.693147181f;
     for (int t = 0; t < T; ++t) {
-        const half4_t m4 = row;
-        const float bw = bnext;
+        half4_t m4[NS];
+        float bw[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            m4[k] = row[k];
+            bw[k] = bnext[k];
+        }
         if (t + 1 < T) {
-            row = *(const half4_t *)(sn + (size_t)(t + 1) * K + 4 * s);
-            bnext = bn[(size_t)(t + 2) * S + s];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                row[k] = *(const half4_t *)(sn + (size_t)(t + 1) * K + 4 * sid[k]);
+                bnext[k] = bn[(size_t)(t + 2) * S + sid[k]];
+            }
         }
         const float *a = alpha + p * S;
         // The forward scan only feeds the posteriors (-> qstring, +-1 contract), not the called
         // bases, so it uses the hardware exp/log (v_exp_f32 / v_log_f32) instead of detmath.
-        float v;
-        {
-            const float v0 = mine + stay, v1 = a[pred] + clampf((float)m4[0], clampv),
-                        v2 = a[pred + Q] + clampf((float)m4[1], clampv),
-                        v3 = a[pred + 2 * Q] + clampf((float)m4[2], clampv),
-                        v4 = a[pred + 3 * Q] + clampf((float)m4[3], clampv);
-            const float m = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), v4);
-            const float sum = __expf(v0 - m) + __expf(v1 - m) + __expf(v2 - m) + __expf(v3 - m) +
-                              __expf(v4 - m);
-            v = m + __logf(sum);
-        }
-        mine = v;
-        alpha[(p ^ 1) * S + s] = v;
-        p ^= 1;
-        // posterior mass of the called k-mer and its distinct shifted neighbours
         const int st = pst[t];
-        const bool in_set = (s == st) ||
-                            ((s & (Q - 1)) == (st >> 2)) ||  // left-shifted:  (st >> 2) + b * Q
-                            ((s >> 2) == (st & (Q - 1)));    // right-shifted: ((st << 2) % S) + b
-        const float e = __expf((v + bw) - logZ);
-        const float e_all = wave_sum(e), e_sel = wave_sum(in_set ? e : 0.0f);
+        float e_all = 0.0f, e_sel = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const float v0 = mine[k] + stay, v1 = a[pred[k]] + clampf((float)m4[k][0], clampv),
+                        v2 = a[pred[k] + Q] + clampf((float)m4[k][1], clampv),
+                        v3 = a[pred[k] + 2 * Q] + clampf((float)m4[k][2], clampv),
+                        v4 = a[pred[k] + 3 * Q] + clampf((float)m4[k][3], clampv);
+            const float m = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), v4);
+            const float sum = __builtin_amdgcn_exp2f((v0 - m) * LOG2E) + __builtin_amdgcn_exp2f((v1 - m) * LOG2E) +
+                              __builtin_amdgcn_exp2f((v2 - m) * LOG2E) + __builtin_amdgcn_exp2f((v3 - m) * LOG2E) +
+                              __builtin_amdgcn_exp2f((v4 - m) * LOG2E);
+            const float v = m + __builtin_amdgcn_logf(sum) * LN2;
+            mine[k] = v;
+            alpha[(p ^ 1) * S + sid[k]] = v;
+            // posterior mass of the called k-mer and its distinct shifted neighbours
+            const int s = sid[k];
+            const bool in_set = (s == st) ||
+                                ((s & (Q - 1)) == (st >> 2)) ||  // left-shifted:  (st >> 2) + b * Q
+                                ((s >> 2) == (st & (Q - 1)));    // right-shifted: ((st << 2) % S) + b
+            const float e = __builtin_amdgcn_exp2f(((v + bw[k]) - logZ) * LOG2E);
+            e_all += e;
+            e_sel += in_set ? e : 0.0f;
+        }
+        p ^= 1;
+        e_all = wave_sum(e_all);
+        e_sel = wave_sum(e_sel);
         if (lane == 0) {
             red[(t & 1) * 32 + wave] = e_all;
             red[(t & 1) * 32 + 16 + wave] = e_sel;
@@ -642,10 +675,10 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
             ta += red[(t & 1) * 32 + i];
             ts += red[(t & 1) * 32 + 16 + i];
         }
-        if (s == (t & (S - 1))) prob[t] = ts / ta;
+        if (tid == (t & (NT - 1))) prob[t] = ts / ta;
     }
     __syncthreads();
-    for (int i = s; i < T; i += S) {  // beam_search.cpp:505-506
+    for (int i = tid; i < T; i += NT) {  // beam_search.cpp:505-506
         const float pr = fminf(fmaxf(prob[i], 0.0f), 1.0f);
         prob[i] = powf(pr, 0.4f);
     }
@@ -655,24 +688,24 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
     //      walks its run (same summation order as the reference's sequential accumulation) and
     //      emits base and quality at position = (number of moves up to and including it) - 1. ----
     {
-        const int per = (T + S - 1) / S;
-        const int b0 = s * per;
+        const int per = (T + NT - 1) / NT;
+        const int b0 = tid * per;
         int local = 0;
         for (int i = 0; i < per; ++i) {
             const int blk = b0 + i;
             if (blk < T) local += (blk == 0) ? 1 : pmv[blk];
         }
-        int *scan = (int *)alpha;  // alpha is dead after the scan; S ints
-        scan[s] = local;
+        int *scan = (int *)alpha;  // alpha is dead after the scan; NT ints
+        scan[tid] = local;
         __syncthreads();
-        for (int o = 1; o < S; o <<= 1) {
-            const int add = (s >= o) ? scan[s - o] : 0;
+        for (int o = 1; o < NT; o <<= 1) {
+            const int add = (tid >= o) ? scan[tid - o] : 0;
             __syncthreads();
-            scan[s] += add;
+            scan[tid] += add;
             __syncthreads();
         }
-        int pos = scan[s] - local;  // exclusive prefix: bases before this thread's blocks
-        if (s == S - 1) s_len = scan[s];
+        int pos = scan[tid] - local;  // exclusive prefix: bases before this thread's blocks
+        if (tid == NT - 1) s_len = scan[tid];
         const char alphabet[4] = {'A', 'C', 'G', 'T'};
         for (int i = 0; i < per; ++i) {
             const int blk = b0 + i;
@@ -704,7 +737,7 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
     }
     __syncthreads();
     const int len = s_len;
-    for (int i = s; i < T; i += S) {
+    for (int i = tid; i < T; i += NT) {
         if (i >= len) {
             seq_out[so + i] = 0;
             qstr_out[so + i] = 0;
@@ -765,7 +798,12 @@ extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int 
             break;
     }
     const size_t smem3 = (size_t)(2 * S + 64) * 4 + (size_t)T * 4 + (size_t)T * 2 + (size_t)T + 16;
-    hipLaunchKernelGGL(posts_qual_kernel, dim3(N), dim3(S), smem3, st, scores, bwd, path_state, moves,
-                       seq, qstr, prob_tap, T, S, stay, clampv, q_shift, q_scale, vi);
+    static const int k3_pair = getenv("MIBC_K3_PAIR") ? atoi(getenv("MIBC_K3_PAIR")) : 1;
+    if (k3_pair && S >= 128)
+        hipLaunchKernelGGL(posts_qual_kernel<true>, dim3(N), dim3(S / 2), smem3, st, scores, bwd, path_state, moves,
+                           seq, qstr, prob_tap, T, S, stay, clampv, q_shift, q_scale, vi);
+    else
+        hipLaunchKernelGGL(posts_qual_kernel<false>, dim3(N), dim3(S), smem3, st, scores, bwd, path_state, moves,
+                           seq, qstr, prob_tap, T, S, stay, clampv, q_shift, q_scale, vi);
     return 0;
 }
