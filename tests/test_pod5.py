@@ -174,3 +174,27 @@ def test_pod5_to_calls_device_pipeline():
     want, _ = hostapi.basecall_reads(cfg, ws, pre, num_runners=2, batch_size=64)
     for g, w in zip(got, want):
         assert g[0] == w[0] and g[1] == w[1] and (g[2] == w[2]).all() and g[3] == w[3]
+
+
+REF_DATA = "/root/reference/tests/data"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="reference tree not present (GPU box)")
+def test_every_reference_pod5_file_parses_and_decodes():
+    """All POD5 files of the reference's test data (pod5 writer versions 0.1.5 - 0.3.35): footer, tables, read
+    metadata, and every signal row inflates and is consumed exactly by the svb16 restatement."""
+    files = sorted(glob.glob(os.path.join(REF_DATA, "**", "*.pod5"), recursive=True))
+    assert len(files) >= 30
+    versions, n_reads, n_samples = set(), 0, 0
+    for path in files:
+        f = pod5.Pod5File(path)
+        versions.add(f.footer["pod5_version"])
+        for r in f.reads():
+            streams, ns = f.inflated_rows(r.signal_rows)
+            assert sum(ns) == r.num_samples and r.sample_rate > 0 and r.scaling > 0
+            for s, n in zip(streams, ns):
+                x, used = O.svb16_decode(np.frombuffer(s, np.uint8), n)
+                assert used == len(s) and x.size == n
+            n_reads += 1
+            n_samples += r.num_samples
+    assert len(versions) >= 5 and n_reads >= 45 and n_samples > 3_000_000
