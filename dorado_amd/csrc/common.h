@@ -12,6 +12,16 @@ typedef float float16_t __attribute__((ext_vector_type(16)));
 
 #define MIBC_WAVE 64
 
+// Environment switches and ablation kernels exist only in the debug build (`make DEBUG_KERNELS=1`, used by
+// tools/): the product library selects its kernels from the shape alone, so a stray MIBC_* variable can never
+// change the arithmetic of a bit-exact path.
+#include <stdlib.h>
+#ifdef MIBC_DEBUG_KERNELS
+#define MIBC_ENV_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define MIBC_ENV_INT(name, dflt) (dflt)
+#endif
+
 // D[row][col] layout of v_mfma_f32_32x32x16_f16 (cdna_hip_programming.md §3):
 //   col = lane & 31,  row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5),  reg in [0,16)
 // A operand: lane holds A[i = lane & 31][k = 8 * (lane >> 5) + 0..7]; B likewise with j.

@@ -778,7 +778,7 @@ extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int 
     int8_t *qstr = out3 + 2 * plane_stride;
     const float log_cut = (beam_cut > 0.0f) ? logf(beam_cut) : 3.402823466e+38f;
     const size_t smem1 = (size_t)2 * S * 4 + (size_t)2 * 4 * S * 2;
-    static const int k1_pair = getenv("MIBC_K1_PAIR") ? atoi(getenv("MIBC_K1_PAIR")) : 1;
+    static const int k1_pair = MIBC_ENV_INT("MIBC_K1_PAIR", 1);
     if (k1_pair && S >= 128)
         hipLaunchKernelGGL(bwd_scan2_kernel, dim3(N), dim3(S / 2), smem1, st, scores, bwd, T, S, stay, clampv, vi);
     else
@@ -798,7 +798,7 @@ extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int 
             break;
     }
     const size_t smem3 = (size_t)(2 * S + 64) * 4 + (size_t)T * 4 + (size_t)T * 2 + (size_t)T + 16;
-    static const int k3_pair = getenv("MIBC_K3_PAIR") ? atoi(getenv("MIBC_K3_PAIR")) : 1;
+    static const int k3_pair = MIBC_ENV_INT("MIBC_K3_PAIR", 1);
     if (k3_pair && S >= 128)
         hipLaunchKernelGGL(posts_qual_kernel<true>, dim3(N), dim3(S / 2), smem3, st, scores, bwd, path_state, moves,
                            seq, qstr, prob_tap, T, S, stay, clampv, q_shift, q_scale, vi);

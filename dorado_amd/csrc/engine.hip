@@ -54,6 +54,17 @@ static int upload(mibc_engine *e, T **dst, const std::vector<T> &src) {
     return 0;
 }
 
+// common tail of mibc_create: hand the engine over, or destroy everything that was built so far
+static int finish_create(mibc_engine *e, int rc, mibc_engine **out) {
+    if (rc != MIBC_OK) {
+        g_err = e->err.empty() ? g_err : e->err;
+        mibc_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return MIBC_OK;
+}
+
 extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const float *const *weights,
                            int n_weights, mibc_engine **out) {
     if (!desc || !weights || !out) {
@@ -71,21 +82,19 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
         e->C = d.tx_d_model;
         e->S = S_;
         e->K = 4 * S_;
-        HIP_OK(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-        for (auto &ev : e->ev) HIP_OK(e, hipEventCreate(&ev));
-        const int rc = tx_create(e, d, weights, n_weights);
-        if (rc != MIBC_OK) {
-            g_err = e->err;
-            mibc_destroy(e);
-            return rc;
-        }
-        const char *tp = getenv("MIBC_TAPS");
-        e->taps = tp ? atoi(tp) : 0;
-        // weight uploads are null-stream copies from pageable memory: hipMemcpy may return once the data
-        // sits in the staging buffer, and the engine's stream is non-blocking, so finish them here
-        HIP_OK(e, hipDeviceSynchronize());
-        *out = e;
-        return MIBC_OK;
+        auto body = [&]() -> int {
+            HIP_OK(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+            for (auto &ev : e->ev) HIP_OK(e, hipEventCreate(&ev));
+            const int rc = tx_create(e, d, weights, n_weights);
+            if (rc != MIBC_OK) return rc;
+            const char *tp = getenv("MIBC_TAPS");
+            e->taps = tp ? atoi(tp) : 0;
+            // weight uploads are null-stream copies from pageable memory: hipMemcpy may return once the data
+            // sits in the staging buffer, and the engine's stream is non-blocking, so finish them here
+            HIP_OK(e, hipDeviceSynchronize());
+            return MIBC_OK;
+        };
+        return finish_create(e, body(), out);
     }
     if (d.n_convs != 3 || d.num_features != 1 || d.conv_insize[0] != 1 || d.conv_size[0] != 16 ||
         d.conv_size[1] != 16 || d.conv_winlen[0] != 5 || d.conv_winlen[1] != 5 ||
@@ -129,6 +138,8 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
     e->K = 4 * S;
     e->stride = d.conv_stride[2];
     e->pad3 = d.conv_winlen[2] / 2;
+    // every failure past this point goes through finish_create -> mibc_destroy (no leaked stream / events / weights)
+    auto body = [&]() -> int {
     HIP_OK(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     for (auto &ev : e->ev) HIP_OK(e, hipEventCreate(&ev));
 
@@ -245,14 +256,15 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
         if (upload(e, &e->head_b1, std::vector<float>(B, B + e->K))) return MIBC_ERR_HIP;
         e->head_act1 = 3;
     }
-    if (const char *wsv = getenv("MIBC_WSGEMM")) e->use_ws = atoi(wsv);
+    e->use_ws = MIBC_ENV_INT("MIBC_WSGEMM", 1);
     const char *tp = getenv("MIBC_TAPS");
     e->taps = tp ? atoi(tp) : 0;
     // weight uploads are null-stream copies from pageable memory: hipMemcpy may return once the data sits
     // in the staging buffer, and the engine's stream is non-blocking, so finish them before first use
     HIP_OK(e, hipDeviceSynchronize());
-    *out = e;
     return MIBC_OK;
+    };
+    return finish_create(e, body(), out);
 }
 
 static void free_ws(mibc_engine *e) {
@@ -309,11 +321,10 @@ static int decode_sub_default(const mibc_engine *e) {
 }
 
 static int decode_sub(const mibc_engine *e, int N) {
-    const char *s = getenv("MIBC_DECODE_SUB");
     // Largest sub-batch whose scores + back-guides + trace stay under ~100 GB of the 288 GB: every
     // decode kernel is one wave / workgroup per chunk, so the more chunks per launch the better the
     // latency hiding (hac: 16384 chunks in one launch 70 ms vs 81 ms in four launches of 4096).
-    int nd = s ? atoi(s) : decode_sub_default(e);
+    int nd = MIBC_ENV_INT("MIBC_DECODE_SUB", decode_sub_default(e));
     if (nd < 64) nd = 64;
     nd = (nd / 64) * 64;
     return N < nd ? N : nd;

@@ -214,7 +214,7 @@ int tx_reserve(mibc_engine *e, int N_max, int T_in, size_t *total_out) {
     const size_t R = N * (size_t)T;
     if (alloc(&tx.x, R * tx.D, false)) return MIBC_ERR_MEM;
     if (alloc(&tx.qkv, R * 3 * tx.D, false)) return MIBC_ERR_MEM;
-    static const int att_v2 = getenv("MIBC_ATT_V2") ? atoi(getenv("MIBC_ATT_V2")) : 1;
+    static const int att_v2 = MIBC_ENV_INT("MIBC_ATT_V2", 1);
     if (att_v2 && T % 128 == 0)
         if (alloc(&tx.vT, R * tx.D, false)) return MIBC_ERR_MEM;
     if (alloc(&tx.attn, R * tx.D, false)) return MIBC_ERR_MEM;

@@ -408,7 +408,7 @@ extern "C" int mibc_launch_gemm_tn(hipStream_t s, const GemmArgs *a) {
     const int ncol = a->Ncols / G_BN;
     const int nrow = (a->M + G_BM - 1) / G_BM;
     dim3 grid(((nrow + 7) / 8) * 8 * ncol);
-    static const int use_dma = getenv("MIBC_GEMM_DMA") ? atoi(getenv("MIBC_GEMM_DMA")) : 1;
+    static const int use_dma = MIBC_ENV_INT("MIBC_GEMM_DMA", 1);
     if (use_dma && a->K % D_BK == 0) {
         hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(256), 0, s, *a);
         return 0;

@@ -30,8 +30,6 @@
 // Wave w owns hidden tiles [w*HT, (w+1)*HT), HT = C/32/NW.
 #include "common.h"
 
-#include <stdlib.h>
-
 #define XG_PF 4
 
 __device__ __forceinline__ half8_t wload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
@@ -81,6 +79,7 @@ __device__ __forceinline__ void gates(const float16_t (&acc)[4][RT], float16_t (
     }
 }
 
+#ifdef MIBC_DEBUG_KERNELS   // superseded by x8 (kept for A/B timing in the debug build)
 // ---------------------------------------------------------------------------------------------
 // xl: x_t and h_{t-1} both in LDS (C <= 384)
 // ---------------------------------------------------------------------------------------------
@@ -201,6 +200,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_xl_kernel(
         __syncthreads();  // x_{t+1} visible
     }
 }
+
+#endif  // MIBC_DEBUG_KERNELS
 
 // ---------------------------------------------------------------------------------------------
 // xg: x_t fragments straight from global/L2 (any C); NB = 32*RT rows, NW waves
@@ -487,6 +488,7 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_x8_kernel(
     }
 }
 
+#ifdef MIBC_DEBUG_KERNELS
 // Ablation copy of x8 for timing experiments (MIBC_LSTM_DBG=<bits>; results are wrong when a bit is
 // set): bit0 = no gate math, bit1 = no weight reloads, bit2 = no activation fragment reads;
 // 8 = unmodified.  DESIGN.md "what bounds the LSTM kernel" quotes these runs.
@@ -637,6 +639,8 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_x8dbg_kernel(
     }
 }
 
+#endif  // MIBC_DEBUG_KERNELS
+
 // batch granularity (rows per workgroup) for a given layer width
 extern "C" int mibc_lstm_rows_per_wg(int C) {
     if (C == 96 || C == 128 || C == 256 || C == 384 || C == 512) return 64;
@@ -665,41 +669,38 @@ extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, h
     if (nb == 0 || N % nb != 0) {
         return 1;
     }
-    static const int dbg8 = getenv("MIBC_LSTM_DBG") ? atoi(getenv("MIBC_LSTM_DBG")) : 0;
+    dim3 grid(N / nb);
+#define XG(CC, RT, NW) hipLaunchKernelGGL((lstm_layer_xg_kernel<CC, RT, NW, ((CC / 16) % 4 == 0 ? 4 : 2)>), grid, dim3(64 * NW), 0, s, Xin, Xout, Wf, biasn, T, N, reverse)
+#define X8(CC) hipLaunchKernelGGL((lstm_layer_x8_kernel<CC, 4>), grid, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse, (const unsigned long long *)nullptr)
+#ifdef MIBC_DEBUG_KERNELS
+    static const int dbg8 = MIBC_ENV_INT("MIBC_LSTM_DBG", 0);
     if (dbg8 && C == 384 && Wf16 != nullptr) {
-        dim3 gd(N / nb);
-#define X8D(D) case D: hipLaunchKernelGGL((lstm_layer_x8dbg_kernel<384, 4, D>), gd, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse); return 0;
+#define X8D(D) case D: hipLaunchKernelGGL((lstm_layer_x8dbg_kernel<384, 4, D>), grid, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse); return 0;
         switch (dbg8) { X8D(1) X8D(2) X8D(4) X8D(7) X8D(8) default: break; }
 #undef X8D
     }
-    static const int use_x8 = getenv("MIBC_LSTM_X8") ? atoi(getenv("MIBC_LSTM_X8")) : 1;
-    if (use_x8 && Wf16 != nullptr && (C == 128 || C == 256 || C == 384)) {
-        dim3 g8(N / nb);
-        switch (C) {
-            case 128: hipLaunchKernelGGL((lstm_layer_x8_kernel<128, 4>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse, (const unsigned long long *)nullptr); return 0;
-            case 256: hipLaunchKernelGGL((lstm_layer_x8_kernel<256, 4>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse, (const unsigned long long *)nullptr); return 0;
-            default:
-                if (use_x8 == 3)
-                    hipLaunchKernelGGL((lstm_layer_x8_kernel<384, 3>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse, (const unsigned long long *)nullptr);
-                else
-                    hipLaunchKernelGGL((lstm_layer_x8_kernel<384, 4>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse, (const unsigned long long *)nullptr);
-                return 0;
-        }
-    }
-    static const int force_xg = getenv("MIBC_LSTM_XG") ? atoi(getenv("MIBC_LSTM_XG")) : 0;
-    dim3 grid(N / nb);
+    static const int use_x8 = MIBC_ENV_INT("MIBC_LSTM_X8", 1);
+    static const int force_xg = MIBC_ENV_INT("MIBC_LSTM_XG", 0);
+    if (!use_x8 && (C == 128 || C == 256 || C == 384)) {
 #define XL(CC, PF) hipLaunchKernelGGL((lstm_layer_xl_kernel<CC, PF>), grid, dim3(256), 0, s, Xin, Xout, Wf, biasn, T, N, reverse)
-#define XG(CC, RT, NW) hipLaunchKernelGGL((lstm_layer_xg_kernel<CC, RT, NW, ((CC / 16) % 4 == 0 ? 4 : 2)>), grid, dim3(64 * NW), 0, s, Xin, Xout, Wf, biasn, T, N, reverse)
+        switch (C) {
+            case 128: if (force_xg) XG(128, 2, 4); else XL(128, 8); return 0;
+            case 256: if (force_xg) XG(256, 2, 4); else XL(256, 8); return 0;
+            default: if (force_xg) XG(384, 2, 4); else XL(384, 4); return 0;
+        }
+#undef XL
+    }
+#endif
     switch (C) {
         case 96: XG(96, 2, 3); return 0;   // fast models: 3 hidden tiles of 32 -> 3 waves
-        case 128: if (force_xg) XG(128, 2, 4); else XL(128, 8); return 0;
-        case 256: if (force_xg) XG(256, 2, 4); else XL(256, 8); return 0;
-        case 384: if (force_xg) XG(384, 2, 4); else XL(384, 4); return 0;
+        case 128: if (Wf16 == nullptr) return 1; X8(128); return 0;
+        case 256: if (Wf16 == nullptr) return 1; X8(256); return 0;
+        case 384: if (Wf16 == nullptr) return 1; X8(384); return 0;
         case 512: XG(512, 2, 4); return 0;
         case 768: XG(768, 1, 8); return 0;
         case 1024: XG(1024, 1, 8); return 0;
         default: return 1;
     }
-#undef XL
+#undef X8
 #undef XG
 }

@@ -248,13 +248,13 @@ extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mod
     const int KT = K / 32;
     // NW = waves per workgroup: 8 (one workgroup per CU) or 4 (two independent workgroups per CU,
     // so that one's MFMA k-loop runs beside the other's VALU epilogue)
-    static const int ws_dbg = getenv("MIBC_WS_DBG") ? atoi(getenv("MIBC_WS_DBG")) : 0;
+    static const int ws_dbg = MIBC_ENV_INT("MIBC_WS_DBG", 0);
     WsArgs adbg = *a;
     if (ws_dbg) {
         adbg.dbg = ws_dbg;
         a = &adbg;
     }
-    static const int nw_env = getenv("MIBC_WS_NW") ? atoi(getenv("MIBC_WS_NW")) : 8;
+    static const int nw_env = MIBC_ENV_INT("MIBC_WS_NW", 8);
     const int NW = (nw_env == 4) ? 4 : 8;
     // columns per wave per pass: whichever of 64 / 48 / 32 keeps all waves busy
     const int per = NW * 16;

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <exception>
 #include <numeric>
 #include <set>
 #include <stdexcept>
@@ -539,6 +540,31 @@ std::vector<std::vector<RunnerPtr>> create_basecall_runners(const mibc_model_des
 }
 
 // ------------------------------------------------------------------ SimplexBasecaller
+namespace {
+// One thread per runner.  An exception must not leave a std::thread (std::terminate would take the whole
+// host process down on a transient HIP / allocation error): the first one is kept, the other workers stop
+// at their next batch boundary, and it is rethrown on the calling thread after join().
+template <typename Worker>
+void run_workers(std::vector<RunnerPtr> &runners, Worker &&worker) {
+    std::atomic<bool> failed{false};
+    std::exception_ptr first;
+    std::mutex emut;
+    std::vector<std::thread> threads;
+    for (auto &r : runners)
+        threads.emplace_back([&, runner = r.get()] {
+            try {
+                worker(runner, failed);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(emut);
+                if (!first) first = std::current_exception();
+                failed.store(true);
+            }
+        });
+    for (auto &t : threads) t.join();
+    if (first) std::rethrow_exception(first);
+}
+}  // namespace
+
 SimplexBasecaller::SimplexBasecaller(std::vector<RunnerPtr> runners, int overlap, int model_stride)
         : m_runners(std::move(runners)), m_overlap(overlap), m_stride(model_stride) {}
 
@@ -573,10 +599,10 @@ std::vector<CalledRead> SimplexBasecaller::basecall_views(const std::vector<Read
         }
     }
     std::mutex qmut;
-    auto worker = [&](ModelRunnerBase *runner) {
+    auto worker = [&](ModelRunnerBase *runner, std::atomic<bool> &failed) {
         const size_t batch = runner->batch_size();
         std::vector<uint16_t> padded(chunk_size);
-        while (true) {
+        while (!failed.load()) {
             std::vector<Work> mine;
             {
                 std::lock_guard<std::mutex> lk(qmut);
@@ -614,9 +640,7 @@ std::vector<CalledRead> SimplexBasecaller::basecall_views(const std::vector<Read
             }
         }
     };
-    std::vector<std::thread> threads;
-    for (auto &r : m_runners) threads.emplace_back(worker, r.get());
-    for (auto &t : threads) t.join();
+    run_workers(m_runners, worker);
     for (size_t r = 0; r < reads.size(); ++r) {
         std::vector<const Chunk *> cc;
         for (auto &c : chunks[r]) cc.push_back(&c);
@@ -649,11 +673,11 @@ std::vector<CalledRead> SimplexBasecaller::basecall_variable(const std::vector<s
         }
     }
     std::mutex qmut;
-    auto worker = [&](ModelRunnerBase *base) {
+    auto worker = [&](ModelRunnerBase *base, std::atomic<bool> &failed) {
         auto *runner = dynamic_cast<HipModelRunner *>(base);
         if (!runner) throw std::runtime_error("variable chunk sizes need a HipModelRunner");
         const size_t batch = runner->batch_size();
-        while (true) {
+        while (!failed.load()) {
             // fill the rows first-fit in queue order (one lock per batch)
             std::vector<Work> mine;
             std::vector<mibc_var_chunk> table;
@@ -695,9 +719,7 @@ std::vector<CalledRead> SimplexBasecaller::basecall_variable(const std::vector<s
             }
         }
     };
-    std::vector<std::thread> threads;
-    for (auto &r : m_runners) threads.emplace_back(worker, r.get());
-    for (auto &t : threads) t.join();
+    run_workers(m_runners, worker);
     for (size_t r = 0; r < reads.size(); ++r) {
         std::vector<const Chunk *> cc;
         for (auto &c : chunks[r]) cc.push_back(&c);
@@ -722,6 +744,55 @@ NamedStats SimplexBasecaller::sample_stats() const {  // BasecallerNode.cpp:597-
 // ------------------------------------------------------------------ C test/driver entry points
 using namespace dorado_amd::host;
 static thread_local std::string g_herr;
+
+// Samples per output step: the product of the conv strides, divided by the upsample factor of the
+// transformer models (config/BasecallModelConfig.cpp:447-454: sup@v5 = 1*1*3*2*2 / 2 = 6).
+static int model_stride_of(const mibc_model_desc &d) {
+    int stride = 1;
+    for (int i = 0; i < d.n_convs; ++i) stride *= d.conv_stride[i];
+    if (d.tx_d_model > 0 && d.up_scale_factor > 1) stride /= d.up_scale_factor;
+    return stride;
+}
+
+namespace {
+struct ReadOutputs {
+    char *seq_out, *qstr_out;
+    int64_t *seq_len_out;
+    uint8_t *moves_out;
+    int64_t *moves_len_out, *offsets_out, *n_offsets_out;
+    double *stats4;
+};
+void write_outputs(const std::vector<CalledRead> &called, SimplexBasecaller &node, const ReadOutputs &o) {
+    size_t so = 0, mo = 0, oo = 0;
+    for (size_t r = 0; r < called.size(); ++r) {
+        const auto &c = called[r];
+        std::memcpy(o.seq_out + so, c.seq.data(), c.seq.size());
+        std::memcpy(o.qstr_out + so, c.qstring.data(), c.qstring.size());
+        so += c.seq.size();
+        o.seq_len_out[r] = int64_t(c.seq.size());
+        std::memcpy(o.moves_out + mo, c.moves.data(), c.moves.size());
+        mo += c.moves.size();
+        o.moves_len_out[r] = int64_t(c.moves.size());
+        for (size_t off : c.chunk_offsets) o.offsets_out[oo++] = int64_t(off);
+        o.n_offsets_out[r] = int64_t(c.chunk_offsets.size());
+    }
+    auto st = node.sample_stats();
+    o.stats4[0] = st["samples_processed"];
+    o.stats4[1] = st["samples_incl_padding"];
+    o.stats4[2] = st["batches_called"];
+    o.stats4[3] = st["partial_batches_called"];
+}
+std::unique_ptr<SimplexBasecaller> make_node(const mibc_model_desc *desc, const float *const *weights, int n_weights,
+                                             const char *device_string, int num_runners, int chunk_size, int overlap,
+                                             int batch_size, const mibc_decode_opts *opts) {
+    auto per_dev = create_basecall_runners(*desc, weights, n_weights, device_string, num_runners, chunk_size,
+                                           batch_size, *opts);
+    std::vector<RunnerPtr> flat;
+    for (auto &d : per_dev)
+        for (auto &r : d) flat.push_back(std::move(r));
+    return std::make_unique<SimplexBasecaller>(std::move(flat), overlap, model_stride_of(*desc));
+}
+}  // namespace
 
 extern "C" {
 
@@ -761,39 +832,16 @@ int mibch_basecall_reads_variable(const mibc_model_desc *desc, const float *cons
                                   int64_t *seq_len_out, uint8_t *moves_out, int64_t *moves_len_out,
                                   int64_t *offsets_out, int64_t *n_offsets_out, double *stats4) {
     try {
-        int stride = 1;
-        for (int i = 0; i < desc->n_convs; ++i) stride *= desc->conv_stride[i];
-        auto per_dev = create_basecall_runners(*desc, weights, n_weights, device_string, num_runners,
-                                               chunk_size, batch_size, *opts);
-        std::vector<RunnerPtr> flat;
-        for (auto &d : per_dev)
-            for (auto &r : d) flat.push_back(std::move(r));
-        SimplexBasecaller node(std::move(flat), overlap, stride);
+        auto node = make_node(desc, weights, n_weights, device_string, num_runners, chunk_size, overlap, batch_size, opts);
         std::vector<std::vector<uint16_t>> reads(static_cast<size_t>(n_reads));
         size_t pos = 0;
         for (int r = 0; r < n_reads; ++r) {
             reads[size_t(r)].assign(signals + pos, signals + pos + read_len[r]);
             pos += size_t(read_len[r]);
         }
-        auto called = node.basecall_variable(reads);
-        size_t so = 0, mo = 0, oo = 0;
-        for (int r = 0; r < n_reads; ++r) {
-            const auto &c = called[size_t(r)];
-            std::memcpy(seq_out + so, c.seq.data(), c.seq.size());
-            std::memcpy(qstr_out + so, c.qstring.data(), c.qstring.size());
-            so += c.seq.size();
-            seq_len_out[r] = int64_t(c.seq.size());
-            std::memcpy(moves_out + mo, c.moves.data(), c.moves.size());
-            mo += c.moves.size();
-            moves_len_out[r] = int64_t(c.moves.size());
-            for (size_t o : c.chunk_offsets) offsets_out[oo++] = int64_t(o);
-            n_offsets_out[r] = int64_t(c.chunk_offsets.size());
-        }
-        auto st = node.sample_stats();
-        stats4[0] = st["samples_processed"];
-        stats4[1] = st["samples_incl_padding"];
-        stats4[2] = st["batches_called"];
-        stats4[3] = st["partial_batches_called"];
+        auto called = node->basecall_variable(reads);
+        write_outputs(called, *node, {seq_out, qstr_out, seq_len_out, moves_out, moves_len_out, offsets_out,
+                                      n_offsets_out, stats4});
         return 0;
     } catch (const std::exception &e) {
         g_herr = e.what();
@@ -811,14 +859,7 @@ int mibch_basecall_raw_reads(const mibc_model_desc *desc, const float *const *we
                              uint8_t *moves_out, int64_t *moves_len_out, int64_t *offsets_out,
                              int64_t *n_offsets_out, double *stats4) {
     try {
-        int stride = 1;
-        for (int i = 0; i < desc->n_convs; ++i) stride *= desc->conv_stride[i];
-        auto per_dev = create_basecall_runners(*desc, weights, n_weights, device_string, num_runners,
-                                               chunk_size, batch_size, *opts);
-        std::vector<RunnerPtr> flat;
-        for (auto &d : per_dev)
-            for (auto &r : d) flat.push_back(std::move(r));
-        SimplexBasecaller node(std::move(flat), overlap, stride);
+        auto node = make_node(desc, weights, n_weights, device_string, num_runners, chunk_size, overlap, batch_size, opts);
         std::vector<SimplexBasecaller::RawRead> reads;
         size_t pos = 0;
         for (int r = 0; r < n_reads; ++r) {
@@ -826,25 +867,9 @@ int mibch_basecall_raw_reads(const mibc_model_desc *desc, const float *const *we
             reads.push_back({signals + pos + ts, size_t(read_len[r]) - ts, shift_scale[2 * r], shift_scale[2 * r + 1]});
             pos += size_t(read_len[r]);
         }
-        auto called = node.basecall_raw(reads);
-        size_t so = 0, mo = 0, oo = 0;
-        for (int r = 0; r < n_reads; ++r) {
-            const auto &c = called[size_t(r)];
-            std::memcpy(seq_out + so, c.seq.data(), c.seq.size());
-            std::memcpy(qstr_out + so, c.qstring.data(), c.qstring.size());
-            so += c.seq.size();
-            seq_len_out[r] = int64_t(c.seq.size());
-            std::memcpy(moves_out + mo, c.moves.data(), c.moves.size());
-            mo += c.moves.size();
-            moves_len_out[r] = int64_t(c.moves.size());
-            for (size_t o : c.chunk_offsets) offsets_out[oo++] = int64_t(o);
-            n_offsets_out[r] = int64_t(c.chunk_offsets.size());
-        }
-        auto st = node.sample_stats();
-        stats4[0] = st["samples_processed"];
-        stats4[1] = st["samples_incl_padding"];
-        stats4[2] = st["batches_called"];
-        stats4[3] = st["partial_batches_called"];
+        auto called = node->basecall_raw(reads);
+        write_outputs(called, *node, {seq_out, qstr_out, seq_len_out, moves_out, moves_len_out, offsets_out,
+                                      n_offsets_out, stats4});
         return 0;
     } catch (const std::exception &e) {
         g_herr = e.what();
@@ -927,39 +952,16 @@ int mibch_basecall_reads(const mibc_model_desc *desc, const float *const *weight
                          int64_t *seq_len_out, uint8_t *moves_out, int64_t *moves_len_out,
                          int64_t *offsets_out, int64_t *n_offsets_out, double *stats4) {
     try {
-        int stride = 1;
-        for (int i = 0; i < desc->n_convs; ++i) stride *= desc->conv_stride[i];
-        auto per_dev = create_basecall_runners(*desc, weights, n_weights, device_string, num_runners,
-                                               chunk_size, batch_size, *opts);
-        std::vector<RunnerPtr> flat;
-        for (auto &d : per_dev)
-            for (auto &r : d) flat.push_back(std::move(r));
-        SimplexBasecaller node(std::move(flat), overlap, stride);
+        auto node = make_node(desc, weights, n_weights, device_string, num_runners, chunk_size, overlap, batch_size, opts);
         std::vector<std::vector<uint16_t>> reads(static_cast<size_t>(n_reads));
         size_t pos = 0;
         for (int r = 0; r < n_reads; ++r) {
             reads[size_t(r)].assign(signals + pos, signals + pos + read_len[r]);
             pos += size_t(read_len[r]);
         }
-        auto called = node.basecall(reads);
-        size_t so = 0, mo = 0, oo = 0;
-        for (int r = 0; r < n_reads; ++r) {
-            const auto &c = called[size_t(r)];
-            std::memcpy(seq_out + so, c.seq.data(), c.seq.size());
-            std::memcpy(qstr_out + so, c.qstring.data(), c.qstring.size());
-            so += c.seq.size();
-            seq_len_out[r] = int64_t(c.seq.size());
-            std::memcpy(moves_out + mo, c.moves.data(), c.moves.size());
-            mo += c.moves.size();
-            moves_len_out[r] = int64_t(c.moves.size());
-            for (size_t o : c.chunk_offsets) offsets_out[oo++] = int64_t(o);
-            n_offsets_out[r] = int64_t(c.chunk_offsets.size());
-        }
-        auto st = node.sample_stats();
-        stats4[0] = st["samples_processed"];
-        stats4[1] = st["samples_incl_padding"];
-        stats4[2] = st["batches_called"];
-        stats4[3] = st["partial_batches_called"];
+        auto called = node->basecall(reads);
+        write_outputs(called, *node, {seq_out, qstr_out, seq_len_out, moves_out, moves_len_out, offsets_out,
+                                      n_offsets_out, stats4});
         return 0;
     } catch (const std::exception &e) {
         g_herr = e.what();

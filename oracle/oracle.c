@@ -90,6 +90,30 @@ ORC_API float orc_det_expf(float x) { return det_expf(x); }
 ORC_API float orc_det_logf(float x) { return det_logf(x); }
 
 /* ------------------------------------------------------------------------------------------
+ * f16-storage emulation (checker-side only).  The device path stores weights of every MFMA
+ * GEMM, the activations between kernels and the recurrent state h in IEEE half precision and
+ * accumulates in f32 (the reference's own GPU path does the same, CRFModel.cpp:111).  With
+ * orc_set_f16_emulation(1) the network functions below round at exactly those points, so that
+ * "device vs this oracle" isolates kernel errors from the expected precision noise, while
+ * "this oracle vs the f32 reference" measures the precision noise alone.  Default 0 = the plain
+ * f32 restatement that is pinned to the compiled reference.
+ * ---------------------------------------------------------------------------------------- */
+#include <immintrin.h>
+static int g_f16 = 0;
+ORC_API void orc_set_f16_emulation(int on) { g_f16 = on; }
+ORC_API int orc_get_f16_emulation(void) { return g_f16; }
+static inline float rf16(float v) { return _cvtsh_ss(_cvtss_sh(v, _MM_FROUND_TO_NEAREST_INT)); }
+static void round_f16_inplace(float *x, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; ++i) x[i] = rf16(x[i]);
+}
+static float *rounded_copy(const float *w, size_t n) {
+    float *r = (float *)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; ++i) r[i] = rf16(w[i]);
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------
  * a12: chunking and stitching (integer, bit-exact contract)
  * ---------------------------------------------------------------------------------------- */
 
@@ -293,56 +317,78 @@ ORC_API int orc_conv1d(const float *in, int N, int T_in, int Cin, const float *W
 ORC_API void orc_lstm_layer(const float *in, int N, int T, int C, const float *Wih,
                             const float *Whh, const float *bih, const float *bhh, int reverse,
                             float *out) {
+    /* transposed copies Wt[k][4C]: the loop over the gate index j vectorises while every gate
+     * keeps the plain left-to-right sum over k of the scalar formulation */
+    const int G = 4 * C;
+    float *WiT = (float *)malloc((size_t)C * G * sizeof(float));
+    float *WhT = (float *)malloc((size_t)C * G * sizeof(float));
+    for (int j = 0; j < G; ++j)
+        for (int k = 0; k < C; ++k) {
+            WiT[(size_t)k * G + j] = Wih[(size_t)j * C + k];
+            WhT[(size_t)k * G + j] = Whh[(size_t)j * C + k];
+        }
+    const int f16 = g_f16;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int n = 0; n < N; ++n) {
         float *h = (float *)calloc((size_t)C, sizeof(float));
         float *c = (float *)calloc((size_t)C, sizeof(float));
-        float *g = (float *)malloc((size_t)4 * C * sizeof(float));
+        float *a0 = (float *)malloc((size_t)G * sizeof(float));
+        float *a1 = (float *)malloc((size_t)G * sizeof(float));
         for (int step = 0; step < T; ++step) {
             const int t = reverse ? (T - 1 - step) : step;
             const float *x = in + ((size_t)n * T + t) * C;
-            for (int j = 0; j < 4 * C; ++j) {
-                const float *wi = Wih + (size_t)j * C;
-                const float *wh = Whh + (size_t)j * C;
-                float a0 = 0.f, a1 = 0.f;
-                for (int k = 0; k < C; ++k) {
-                    a0 += wi[k] * x[k];
+            for (int j = 0; j < G; ++j) a0[j] = 0.f, a1[j] = 0.f;
+            for (int k = 0; k < C; ++k) {
+                const float xv = x[k], hv = h[k];
+                const float *wi = WiT + (size_t)k * G;
+                const float *wh = WhT + (size_t)k * G;
+#pragma omp simd
+                for (int j = 0; j < G; ++j) {
+                    a0[j] += wi[j] * xv;
+                    a1[j] += wh[j] * hv;
                 }
-                for (int k = 0; k < C; ++k) {
-                    a1 += wh[k] * h[k];
-                }
-                g[j] = (a0 + bih[j]) + (a1 + bhh[j]);
             }
             float *y = out + ((size_t)n * T + t) * C;
             for (int j = 0; j < C; ++j) {
-                const float ig = sigmoidf_(g[j]);
-                const float fg = sigmoidf_(g[C + j]);
-                const float gg = tanhf(g[2 * C + j]);
-                const float og = sigmoidf_(g[3 * C + j]);
+                const float ig = sigmoidf_((a0[j] + bih[j]) + (a1[j] + bhh[j]));
+                const float fg = sigmoidf_((a0[C + j] + bih[C + j]) + (a1[C + j] + bhh[C + j]));
+                const float gg = tanhf((a0[2 * C + j] + bih[2 * C + j]) + (a1[2 * C + j] + bhh[2 * C + j]));
+                const float og = sigmoidf_((a0[3 * C + j] + bih[3 * C + j]) + (a1[3 * C + j] + bhh[3 * C + j]));
                 c[j] = fg * c[j] + ig * gg;
                 h[j] = og * tanhf(c[j]);
+                if (f16) h[j] = rf16(h[j]); /* the device keeps h_t (state and output) in f16, c in f32 */
                 y[j] = h[j];
             }
         }
         free(h);
         free(c);
-        free(g);
+        free(a0);
+        free(a1);
     }
+    free(WiT);
+    free(WhT);
 }
 
 /* nn/CRFModules.cpp:24-34: y = x W^T (+ b); optional tanh * scale.  W [Cout,Cin]. */
 ORC_API void orc_linear(const float *in, long rows, int Cin, const float *W, const float *b,
                         int Cout, int use_tanh, float scale, float *out) {
+    /* Wt[k][Cout]: vectorises over the output index, each output keeps the left-to-right k sum */
+    float *Wt = (float *)malloc((size_t)Cin * Cout * sizeof(float));
+    for (int j = 0; j < Cout; ++j)
+        for (int k = 0; k < Cin; ++k) Wt[(size_t)k * Cout + j] = W[(size_t)j * Cin + k];
 #pragma omp parallel for schedule(static)
     for (long r = 0; r < rows; ++r) {
         const float *x = in + (size_t)r * Cin;
         float *y = out + (size_t)r * Cout;
+        for (int j = 0; j < Cout; ++j) y[j] = 0.f;
+        for (int k = 0; k < Cin; ++k) {
+            const float xv = x[k];
+            const float *w = Wt + (size_t)k * Cout;
+#pragma omp simd
+            for (int j = 0; j < Cout; ++j) y[j] += w[j] * xv;
+        }
         for (int j = 0; j < Cout; ++j) {
-            const float *w = W + (size_t)j * Cin;
-            float a = 0.f;
-            for (int k = 0; k < Cin; ++k) {
-                a += w[k] * x[k];
-            }
+            float a = y[j];
             if (b) {
                 a += b[j];
             }
@@ -352,6 +398,7 @@ ORC_API void orc_linear(const float *in, long rows, int Cin, const float *W, con
             y[j] = a;
         }
     }
+    free(Wt);
 }
 
 /* nn/CRFModules.cpp:128-134 */
@@ -392,6 +439,7 @@ ORC_API int orc_lstm_crf_forward(const orc_model_desc *d, const float *const *we
                                  float *layer_out) {
     int wi = 0;
     const int F = d->num_features;
+    const int f16 = g_f16;
     float *cur = (float *)malloc((size_t)N * T_in * F * sizeof(float));
     for (int n = 0; n < N; ++n)
         for (int f = 0; f < F; ++f)
@@ -402,8 +450,14 @@ ORC_API int orc_lstm_crf_forward(const orc_model_desc *d, const float *const *we
         const int To = orc_conv1d(cur, N, T, C, NULL, NULL, d->conv_size[i], d->conv_winlen[i],
                                   d->conv_stride[i], d->conv_act[i], NULL);
         float *nxt = (float *)malloc((size_t)N * To * d->conv_size[i] * sizeof(float));
-        orc_conv1d(cur, N, T, C, weights[wi], weights[wi + 1], d->conv_size[i], d->conv_winlen[i],
+        /* f16 emulation: conv1/conv2 run in f32 with f32 weights (conv1's output never leaves the CU);
+         * the last conv is an MFMA GEMM with f16 weights; conv2's and the last conv's outputs are stored f16 */
+        const int last = (i == d->n_convs - 1);
+        float *wq = (f16 && last) ? rounded_copy(weights[wi], (size_t)d->conv_size[i] * C * d->conv_winlen[i]) : NULL;
+        orc_conv1d(cur, N, T, C, wq ? wq : weights[wi], weights[wi + 1], d->conv_size[i], d->conv_winlen[i],
                    d->conv_stride[i], d->conv_act[i], nxt);
+        free(wq);
+        if (f16 && i >= 1) round_f16_inplace(nxt, (size_t)N * To * d->conv_size[i]);
         wi += 2;
         free(cur);
         cur = nxt;
@@ -414,8 +468,12 @@ ORC_API int orc_lstm_crf_forward(const orc_model_desc *d, const float *const *we
     float *buf = (float *)malloc((size_t)N * T * C * sizeof(float));
     for (int l = 0; l < d->lstm_layers; ++l) {
         const int reverse = (l % 2 == 0);
-        orc_lstm_layer(cur, N, T, C, weights[wi], weights[wi + 1], weights[wi + 2],
+        float *wq0 = f16 ? rounded_copy(weights[wi], (size_t)4 * C * C) : NULL;
+        float *wq1 = f16 ? rounded_copy(weights[wi + 1], (size_t)4 * C * C) : NULL;
+        orc_lstm_layer(cur, N, T, C, f16 ? wq0 : weights[wi], f16 ? wq1 : weights[wi + 1], weights[wi + 2],
                        weights[wi + 3], reverse, buf);
+        free(wq0);
+        free(wq1);
         wi += 4;
         float *tmp = cur;
         cur = buf;
@@ -432,21 +490,35 @@ ORC_API int orc_lstm_crf_forward(const orc_model_desc *d, const float *const *we
         float *mid = (float *)malloc((size_t)rows * D * sizeof(float));
         const float *w1 = weights[wi++];
         const float *b1 = d->bias ? weights[wi++] : NULL;
-        orc_linear(cur, rows, C, w1, b1, D, 0, 1.0f, mid);
-        orc_linear(mid, rows, D, weights[wi++], NULL, d->outsize, tanh_x5, 5.0f, scores_out);
+        const float *w2 = weights[wi++];
+        float *q1 = f16 ? rounded_copy(w1, (size_t)D * C) : NULL;
+        float *q2 = f16 ? rounded_copy(w2, (size_t)d->outsize * D) : NULL;
+        orc_linear(cur, rows, C, f16 ? q1 : w1, b1, D, 0, 1.0f, mid);
+        if (f16) round_f16_inplace(mid, (size_t)rows * D);
+        orc_linear(mid, rows, D, f16 ? q2 : w2, NULL, d->outsize, tanh_x5, 5.0f, scores_out);
+        free(q1);
+        free(q2);
         free(mid);
+        if (f16) round_f16_inplace(scores_out, (size_t)rows * d->outsize);
         if (d->clamp) {
             orc_clamp(scores_out, rows * d->outsize, -5.0f, 5.0f);
         }
     } else if (d->conv_size[0] > 4 && d->num_features == 1) {
-        orc_linear(cur, rows, C, weights[wi++], NULL, d->outsize, tanh_x5, 5.0f, scores_out);
+        const float *w1 = weights[wi++];
+        float *q1 = f16 ? rounded_copy(w1, (size_t)d->outsize * C) : NULL;
+        orc_linear(cur, rows, C, f16 ? q1 : w1, NULL, d->outsize, tanh_x5, 5.0f, scores_out);
+        free(q1);
+        if (f16) round_f16_inplace(scores_out, (size_t)rows * d->outsize);
         if (d->clamp) {
             orc_clamp(scores_out, rows * d->outsize, -5.0f, 5.0f);
         }
     } else {
         const float *w1 = weights[wi++];
         const float *b1 = weights[wi++];
-        orc_linear(cur, rows, C, w1, b1, d->outsize, 1, 5.0f, scores_out);
+        float *q1 = f16 ? rounded_copy(w1, (size_t)d->outsize * C) : NULL;
+        orc_linear(cur, rows, C, f16 ? q1 : w1, b1, d->outsize, 1, 5.0f, scores_out);
+        free(q1);
+        if (f16) round_f16_inplace(scores_out, (size_t)rows * d->outsize);
     }
     free(cur);
     return T;
@@ -1130,6 +1202,7 @@ static void residual_rmsnorm(float *x, const float *in, const float *w, long row
         const float rstd = 1.0f / sqrtf(ss / (float)C + 1e-5f);
         for (int c = 0; c < C; ++c) {
             xr[c] = (xr[c] * rstd) * w[c];
+            if (g_f16) xr[c] = rf16(xr[c]);
         }
     }
 }
@@ -1142,7 +1215,11 @@ static void tx_attention(const float *x, int N, int T, int C, int H, const float
     const int D = C / H;
     const long rows = (long)N * T;
     float *qkv = (float *)malloc((size_t)rows * 3 * C * sizeof(float));
-    orc_linear(x, rows, C, Wqkv, NULL, 3 * C, 0, 1.0f, qkv);
+    const int f16 = g_f16;
+    float *wq = f16 ? rounded_copy(Wqkv, (size_t)3 * C * C) : NULL;
+    float *woq = f16 ? rounded_copy(Wo, (size_t)C * C) : NULL;
+    orc_linear(x, rows, C, f16 ? wq : Wqkv, NULL, 3 * C, 0, 1.0f, qkv);
+    free(wq);
     /* rotary tables */
     float *cs = (float *)malloc((size_t)T * (D / 2) * sizeof(float));
     float *sn = (float *)malloc((size_t)T * (D / 2) * sizeof(float));
@@ -1171,6 +1248,8 @@ static void tx_attention(const float *x, int N, int T, int C, int H, const float
             }
         }
     }
+    /* device: the QKV GEMM epilogue applies the rotation to the f32 accumulators and stores q, k, v as f16 */
+    if (f16) round_f16_inplace(qkv, (size_t)rows * 3 * C);
     const int num_splits = 12;
     int es = (T + num_splits - 1) / num_splits;
     es = (es + 3) / 4 * 4; /* utils::pad_to(div_round_up(T, 12), 4) */
@@ -1208,13 +1287,17 @@ static void tx_attention(const float *x, int N, int T, int C, int H, const float
                 for (int d = 0; d < D; ++d) o[d] = 0.f;
                 for (int jj = 0; jj < nk; ++jj) {
                     const float *v = qkv + ((size_t)n * T + jlo + jj) * 3 * C + 2 * C + (size_t)h * D;
-                    const float p = w[jj] / sum;
+                    float p = w[jj] / sum;
+                    if (f16) p = rf16(p); /* probabilities are the f16 B operand of the PV MFMA */
                     for (int d = 0; d < D; ++d) o[d] += p * v[d];
                 }
             }
         }
     }
-    orc_linear(att, rows, C, Wo, bo, C, 0, 1.0f, out);
+    if (f16) round_f16_inplace(att, (size_t)rows * C);
+    orc_linear(att, rows, C, f16 ? woq : Wo, bo, C, 0, 1.0f, out);
+    if (f16) round_f16_inplace(out, (size_t)rows * C);
+    free(woq);
     free(qkv); free(cs); free(sn); free(att);
 }
 
@@ -1236,8 +1319,12 @@ ORC_API int orc_tx_forward(const orc_model_desc *d, const float *const *weights,
         const int To = orc_conv1d(cur, N, T, C, NULL, NULL, d->conv_size[i], d->conv_winlen[i],
                                   d->conv_stride[i], d->conv_act[i], NULL);
         float *nxt = (float *)malloc((size_t)N * To * d->conv_size[i] * sizeof(float));
-        orc_conv1d(cur, N, T, C, weights[wi], weights[wi + 1], d->conv_size[i], d->conv_winlen[i],
+        /* f16 emulation: conv1 is a direct f32 kernel, conv2.. are MFMA GEMMs with f16 weights; every output f16 */
+        float *wq = (g_f16 && i >= 1) ? rounded_copy(weights[wi], (size_t)d->conv_size[i] * C * d->conv_winlen[i]) : NULL;
+        orc_conv1d(cur, N, T, C, wq ? wq : weights[wi], weights[wi + 1], d->conv_size[i], d->conv_winlen[i],
                    d->conv_stride[i], d->conv_act[i], nxt);
+        free(wq);
+        if (g_f16) round_f16_inplace(nxt, (size_t)N * To * d->conv_size[i]);
         wi += 2;
         free(cur);
         cur = nxt;
@@ -1261,12 +1348,18 @@ ORC_API int orc_tx_forward(const orc_model_desc *d, const float *const *weights,
                      d->tx_theta, attn);
         residual_rmsnorm(cur, attn, n1, rows, C, d->tx_deepnorm_alpha);
         /* GatedMLP (nn/TxModules.cpp:140-182): y = first half, gate = second half */
-        orc_linear(cur, rows, C, Wfc1, NULL, 2 * FF, 0, 1.0f, t1);
+        float *w1q = g_f16 ? rounded_copy(Wfc1, (size_t)2 * FF * C) : NULL;
+        float *w2q = g_f16 ? rounded_copy(Wfc2, (size_t)C * FF) : NULL;
+        orc_linear(cur, rows, C, g_f16 ? w1q : Wfc1, NULL, 2 * FF, 0, 1.0f, t1);
 #pragma omp parallel for schedule(static)
         for (long r = 0; r < rows; ++r)
             for (int j = 0; j < FF; ++j)
                 t2[(size_t)r * FF + j] = siluf_(t1[(size_t)r * 2 * FF + FF + j]) * t1[(size_t)r * 2 * FF + j];
-        orc_linear(t2, rows, FF, Wfc2, NULL, C, 0, 1.0f, attn);
+        if (g_f16) round_f16_inplace(t2, (size_t)rows * FF); /* SwiGLU output = f16 operand of FC2 */
+        orc_linear(t2, rows, FF, g_f16 ? w2q : Wfc2, NULL, C, 0, 1.0f, attn);
+        if (g_f16) round_f16_inplace(attn, (size_t)rows * C);
+        free(w1q);
+        free(w2q);
         residual_rmsnorm(cur, attn, n2, rows, C, d->tx_deepnorm_alpha);
     }
     if (tokens_out) memcpy(tokens_out, cur, (size_t)rows * C * sizeof(float));
@@ -1274,14 +1367,23 @@ ORC_API int orc_tx_forward(const orc_model_desc *d, const float *const *weights,
     /* LinearUpsample (nn/LinearUpsample.cpp:17-23): linear C -> sf*C (+bias), reshape [N, sf*T, C] */
     const int sf = d->up_scale_factor;
     float *up = (float *)malloc((size_t)rows * sf * C * sizeof(float));
-    orc_linear(cur, rows, C, weights[wi], weights[wi + 1], sf * C, 0, 1.0f, up);
+    {
+        float *wuq = g_f16 ? rounded_copy(weights[wi], (size_t)sf * C * C) : NULL;
+        orc_linear(cur, rows, C, g_f16 ? wuq : weights[wi], weights[wi + 1], sf * C, 0, 1.0f, up);
+        free(wuq);
+        if (g_f16) round_f16_inplace(up, (size_t)rows * sf * C);
+    }
     wi += 2;
     free(cur);
     /* LinearScaledCRF (nn/TxModules.cpp:1010-1016): weight *= scale once, then linear, no bias */
     const int K = d->outsize;
     float *ws = (float *)malloc((size_t)K * C * sizeof(float));
-    for (size_t i = 0; i < (size_t)K * C; ++i) ws[i] = weights[wi][i] * d->crf_scale;
+    for (size_t i = 0; i < (size_t)K * C; ++i) {
+        ws[i] = weights[wi][i] * d->crf_scale;
+        if (g_f16) ws[i] = rf16(ws[i]);
+    }
     orc_linear(up, rows * sf, C, ws, NULL, K, 0, 1.0f, scores_out);
+    if (g_f16) round_f16_inplace(scores_out, (size_t)rows * sf * K);
     free(ws); free(up);
     return T * sf;
 }

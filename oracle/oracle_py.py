@@ -105,6 +105,23 @@ def stitch_chunks(offsets, raw_chunk_sizes, moves_list, seqs, qstrs, raw_samples
 
 
 # ---------------------------------------------------------------- network
+class f16_emulation:
+    """with f16_emulation(): the network functions of the C restatement round weights / activations /
+    recurrent state to IEEE half exactly where the device path stores them in f16 (oracle.c, g_f16)."""
+
+    def __init__(self, on=True):
+        self.on = int(bool(on))
+
+    def __enter__(self):
+        self.prev = lib().orc_get_f16_emulation()
+        lib().orc_set_f16_emulation(self.on)
+        return self
+
+    def __exit__(self, *a):
+        lib().orc_set_f16_emulation(self.prev)
+        return False
+
+
 def _wptrs(weights):
     ws = [np.ascontiguousarray(w, np.float32) for w in weights]
     arr = (_f32p * len(ws))(*[_fp(w) for w in ws])

@@ -1,0 +1,102 @@
+"""BASELINE-size parity fixtures (tests/golden/base_*.npz): the three GPU configurations of
+BASELINE.json (hac@v4.3.0 64 x 9996, sup@v4.3.0-shape 32 x 9996, sup@v5.0.0 depth 18 2 x 12288) run through
+
+  (a) the REFERENCE ITSELF (oracle/_ref/libdorado_ref.so = the reference's CPU sources compiled in
+      place, f32) -> calls + a sample of the scores, and
+  (b) the C restatement in f16-storage emulation (oracle.c, orc_set_f16_emulation: rounds weights /
+      activations / recurrent state where the device path stores f16) -> calls + the same score sample.
+
+(a) is the contract; (b) separates the expected precision noise of an f16 data path (the reference's
+own GPU path is f16 too, CRFModel.cpp:111) from kernel error: device-vs-(b) must be tight, (b)-vs-(a)
+is the published precision floor of the synthetic random-weight model.  The weights and signals are
+regenerated from seeds by the tests (dorado_amd.synth), only outputs are stored.
+
+    python tests/golden/make_golden_baseline.py [hac] [sup43] [sup5]
+"""
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from dorado_amd import config, synth  # noqa: E402
+from oracle import oracle_py as O  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+# name -> (config factory, N, weight seed, signal seed, sampled steps per chunk)
+CASES = {
+    "hac": (config.hac_v43, 64, 42, 0xBA5E0, 4),
+    "sup43": (config.sup_v43, 32, 42, 0xBA5E1, 4),
+    "sup5": (config.sup_v50, 2, 42, 0xBA5E2, 48),
+}
+
+
+def wsum(ws):
+    c = 0
+    for w in ws:
+        c = zlib.crc32(np.ascontiguousarray(w).tobytes(), c)
+    return np.uint32(c)
+
+
+def planes(dec, T):
+    n = len(dec)
+    seq = np.zeros((n, T), np.uint8)
+    qs = np.zeros((n, T), np.uint8)
+    mv = np.zeros((n, T), np.uint8)
+    ln = np.zeros((n,), np.int32)
+    for i, (s, q, m) in enumerate(dec):
+        seq[i, : len(s)] = np.frombuffer(s.encode(), np.uint8)
+        qs[i, : len(q)] = np.frombuffer(q.encode(), np.uint8)
+        mv[i] = m
+        ln[i] = len(s)
+    return seq, qs, mv, ln
+
+
+def sample_steps(N, T, per, seed):
+    rng = np.random.default_rng(seed)
+    return np.sort(np.stack([rng.choice(T, size=per, replace=False) for _ in range(N)]), axis=1).astype(np.int32)
+
+
+def make(name):
+    factory, N, wseed, sseed, per = CASES[name]
+    cfg = factory()
+    t_in = cfg.chunk_size
+    ws = synth.make_weights(cfg, seed=wseed)
+    x16 = synth.make_signal(N, t_in, seed=sseed)
+    x = x16.astype(np.float32)[:, None, :]
+    t0 = time.time()
+    s_ref = O.forward(cfg, ws, x, use_ref=True)
+    d_ref = O.decode(s_ref, q_shift=cfg.qbias, q_scale=cfg.qscale, use_ref=True)
+    t1 = time.time()
+    with O.f16_emulation():
+        s_h = O.forward(cfg, ws, x)
+    d_h = O.decode(s_h, q_shift=cfg.qbias, q_scale=cfg.qscale, det=1)
+    t2 = time.time()
+    T = s_ref.shape[1]
+    sel = sample_steps(N, T, per, sseed + 7)
+    rows = np.arange(N)[:, None]
+    e = np.abs(s_h - s_ref)
+    seq, qs, mv, ln = planes(d_ref, T)
+    seq_h, qs_h, mv_h, ln_h = planes(d_h, T)
+    np.savez_compressed(
+        os.path.join(OUT, f"base_{name}.npz"),
+        N=np.int64(N), T_in=np.int64(t_in), T=np.int64(T), weight_seed=np.int64(wseed), signal_seed=np.int64(sseed),
+        weights_crc=wsum(ws), signal_crc=np.uint32(zlib.crc32(x16.tobytes())),
+        steps=sel, ref_scores=s_ref[rows, sel].astype(np.float32), f16_scores=s_h[rows, sel].astype(np.float16),
+        ref_seq=seq, ref_qstr=qs, ref_moves=mv, ref_len=ln,
+        f16_seq=seq_h, f16_qstr=qs_h, f16_moves=mv_h, f16_len=ln_h,
+        f16_vs_ref_max=np.float32(e.max()), f16_vs_ref_rms=np.float32(np.sqrt((e.astype(np.float64) ** 2).mean())),
+    )
+    print(f"{name}: scores {s_ref.shape} range {s_ref.min():.2f}..{s_ref.max():.2f}; reference {t1 - t0:.0f}s, "
+          f"f16 emulation {t2 - t1:.0f}s; f16-vs-ref max {e.max():.4f} rms {np.sqrt((e ** 2).mean()):.5f}; "
+          f"bases/step {ln.mean() / T:.3f}", flush=True)
+
+
+if __name__ == "__main__":
+    assert O.have_ref(), "build oracle/_ref first: make -C oracle -f Makefile.ref"
+    for nm in (sys.argv[1:] or list(CASES)):
+        make(nm)

@@ -309,6 +309,43 @@ def test_host_layer_whole_reads_vs_oracle_pipeline():
     eng.close()
 
 
+def test_host_layer_whole_reads_transformer_stride():
+    """Transformer models emit one step per conv_stride / up_scale_factor samples (sup@v5: 12 / 2 = 6,
+    config/BasecallModelConfig.cpp:447-454); the host layer must chunk by the model's chunk granularity and
+    stitch with THAT stride: stitched whole reads == oracle stitch of the same per-chunk calls, and the move
+    table has len(read) // stride entries (multi-chunk reads must not duplicate the overlap steps)."""
+    cfg = config.tiny_tx()
+    cfg.chunk_size, cfg.overlap = 1536, 192
+    cfg.normalise_basecaller_params()
+    assert cfg.stride * cfg.tx.up_scale_factor == cfg.conv_stride
+    ws = synth.make_weights(cfg, seed=33)
+    lens = [700, 1536, 1537, 4000, 5555]
+    reads = [synth.make_signal(1, L, seed=300 + i)[0] for i, L in enumerate(lens)]
+    got, stats = hostapi.basecall_reads(cfg, ws, reads, device="hip:0", num_runners=2, batch_size=8)
+    assert stats["samples_processed"] == sum(lens)
+    eng = capi.Engine(cfg, ws)
+    all_chunks, owner = [], []
+    for r, sig in enumerate(reads):
+        offs = O.generate_chunks(len(sig), cfg.chunk_size, cfg.stride, cfg.overlap)
+        assert got[r][3] == offs
+        for o in offs:
+            sl = sig[o:o + cfg.chunk_size]
+            if len(sl) != cfg.chunk_size:
+                n, ov = divmod(cfg.chunk_size, len(sl))
+                sl = np.concatenate([np.tile(sl, n), sl[:ov]])
+            all_chunks.append(sl)
+            owner.append((r, o))
+    calls = eng.call(np.stack(all_chunks))
+    for r, sig in enumerate(reads):
+        idx = [i for i, (rr, _) in enumerate(owner) if rr == r]
+        offs = [owner[i][1] for i in idx]
+        st = O.stitch_chunks(offs, [cfg.chunk_size] * len(idx), [calls[i][2] for i in idx],
+                             [calls[i][0] for i in idx], [calls[i][1] for i in idx], len(sig), cfg.stride)
+        assert got[r][0] == st[0] and got[r][1] == st[1] and (got[r][2] == st[2]).all()
+        assert len(got[r][2]) == len(sig) // cfg.stride
+    eng.close()
+
+
 # ---------------------------------------------------------------- f1: ScalerNode on the device
 def _scaler_fixture():
     g = np.load(os.path.join(GOLDEN, "scaler.npz"))
