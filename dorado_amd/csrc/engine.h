@@ -65,6 +65,10 @@ extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, h
                                       const half_t *Wf, const half_t *Wf16, const float *biasn, int T, int N,
                                       int reverse);
 extern "C" int mibc_lstm_rows_per_wg(int C);
+// lstm_cluster.hip: hidden-split cluster kernel (C = 512 / 768 / 1024, N a multiple of 256); 1 = shape not covered
+extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin, half_t *Xout, const half_t *Wt,
+                                         const float *biascl, const half_t *zeros, unsigned *flags, unsigned *err,
+                                         int T, int N, int reverse, const unsigned long long *tmask);
 extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
                                       float beam_cut, float stay, float clampv, float q_shift, float q_scale,
                                       float *bwd, uint32_t *trace, uint16_t *path_state, int8_t *out3,
@@ -93,6 +97,15 @@ struct mibc_engine {
     std::vector<half_t *> lstm_w;    // 32-unit tiles, k-steps of 16 (v_mfma 32x32x16)
     std::vector<half_t *> lstm_w16;  // 16-unit tiles, k-steps of 32 (v_mfma 16x16x32); C <= 384 only
     std::vector<float *> lstm_bn;  // b_ih + b_hh, [C/32][4][32]
+    // cluster kernel (lstm_cluster.hip), C = 512 / 768 / 1024 only
+    std::vector<half_t *> lstm_wcl;  // [C/128 members][2 passes][2C/32 slabs][256 gate rows][32] swizzled LDS images
+    std::vector<float *> lstm_bcl;   // [C/128][2][2][4][32]
+    half_t *lstm_zero = nullptr;     // [256][C] zeros (h_{-1})
+    unsigned *cl_flags = nullptr;    // [N_res/256][C/128][16] completed-step counters (zeroed per launch)
+    unsigned *cl_err = nullptr;      // device [4]: sticky hand-off time-out word
+    unsigned *cl_err_host = nullptr; // pinned copy, checked after every stream synchronisation
+    bool cl_used = false;
+    int use_cluster = 1;             // debug build: MIBC_LSTM_CLUSTER=0 forces the per-workgroup kernels
     half_t *head_w1 = nullptr, *head_w2 = nullptr;
     float *head_b1 = nullptr;
     int head_act1 = -1, head_act2 = -1;

@@ -7,6 +7,8 @@
 // (per-device FIFO, runners, pinned batch buffers) lives in dorado_amd/host/.
 #include "engine.h"
 
+static int check_cluster_error(mibc_engine *e);
+
 std::string &mibc_gerr() {
     static thread_local std::string g;
     return g;
@@ -223,6 +225,45 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
         if (upload(e, &dw, wf) || upload(e, &dbn, bn)) return MIBC_ERR_HIP;
         e->lstm_w.push_back(dw);
         e->lstm_bn.push_back(dbn);
+        if (C == 512 || C == 768 || C == 1024) {
+            // cluster kernel (lstm_cluster.hip): member j of a cluster owns hidden units [128 j, 128 j + 128); its
+            // weight slab (pass p, k-slab ks) is stored as the exact LDS image it is DMA'd into: 256 gate rows
+            // [hidden group hg][gate g][32 units] x 32 k, 64-byte rows with the 16-byte column XOR-swizzled by
+            // (row >> 2) & 3 (the read side applies the same XOR)
+            const int KCL = C / 128, KSL = 2 * C / 32;
+            std::vector<half_t> wcl((size_t)4 * C * 2 * C);
+            std::vector<float> bcl((size_t)4 * C);
+            for (int jm = 0; jm < KCL; ++jm)
+                for (int p = 0; p < 2; ++p) {
+                    for (int row = 0; row < 256; ++row) {
+                        const int hgi = row >> 7, g = (row >> 5) & 3, hl = row & 31;
+                        const int hidden = jm * 128 + p * 64 + hgi * 32 + hl;
+                        const size_t G = (size_t)g * C + hidden;
+                        bcl[(((size_t)(jm * 2 + p) * 2 + hgi) * 4 + g) * 32 + hl] = bih[G] + bhh[G];
+                        for (int ks = 0; ks < KSL; ++ks) {
+                            half_t *dst = wcl.data() + ((((size_t)(jm * 2 + p)) * KSL + ks) * 256 + row) * 32;
+                            for (int kk = 0; kk < 32; ++kk) {
+                                const int k = ks * 32 + kk;
+                                const float v = (k < C) ? Wih[G * C + k] : Whh[G * C + (k - C)];
+                                dst[(((kk >> 3) ^ ((row >> 2) & 3)) << 3) + (kk & 7)] = (half_t)v;
+                            }
+                        }
+                    }
+                }
+            half_t *dwcl = nullptr;
+            float *dbcl = nullptr;
+            if (upload(e, &dwcl, wcl) || upload(e, &dbcl, bcl)) return MIBC_ERR_HIP;
+            e->lstm_wcl.push_back(dwcl);
+            e->lstm_bcl.push_back(dbcl);
+        }
+    }
+    if (!e->lstm_wcl.empty()) {
+        HIP_OK(e, hipMalloc((void **)&e->lstm_zero, (size_t)256 * C * 2));
+        HIP_OK(e, hipMemset(e->lstm_zero, 0, (size_t)256 * C * 2));
+        HIP_OK(e, hipMalloc((void **)&e->cl_err, 16));
+        HIP_OK(e, hipMemset(e->cl_err, 0, 16));
+        HIP_OK(e, hipHostMalloc((void **)&e->cl_err_host, 16, hipHostMallocDefault));
+        e->cl_err_host[0] = 0;
     }
     // head (basecall/model/CRFModel.cpp:43-61)
     const int tanh_x5 = (d.scale == 5.0f) ? 3 : -1;
@@ -257,6 +298,7 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
         e->head_act1 = 3;
     }
     e->use_ws = MIBC_ENV_INT("MIBC_WSGEMM", 1);
+    e->use_cluster = MIBC_ENV_INT("MIBC_LSTM_CLUSTER", 1);
     const char *tp = getenv("MIBC_TAPS");
     e->taps = tp ? atoi(tp) : 0;
     // weight uploads are null-stream copies from pageable memory: hipMemcpy may return once the data sits
@@ -270,9 +312,10 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
 static void free_ws(mibc_engine *e) {
     if (e->is_tx) tx_free_ws(e);
     void *ptrs[] = {e->in_stage, e->a2p, e->xa, e->xb, e->scores, e->mid, e->a1_tap, e->bwd,
-                    e->prob_tap, e->trace, e->path_state, e->out3, e->ss_stage};
+                    e->prob_tap, e->trace, e->path_state, e->out3, e->ss_stage, e->cl_flags};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    e->cl_flags = nullptr;
     e->in_stage = e->a2p = e->xa = e->xb = e->scores = e->mid = e->a1_tap = nullptr;
     e->bwd = e->prob_tap = nullptr;
     e->trace = nullptr;
@@ -299,6 +342,11 @@ extern "C" void mibc_destroy(mibc_engine *e) {
     for (auto p : e->lstm_w16)
         if (p) (void)hipFree(p);
     for (auto p : e->lstm_bn) (void)hipFree(p);
+    for (auto p : e->lstm_wcl) (void)hipFree(p);
+    for (auto p : e->lstm_bcl) (void)hipFree(p);
+    if (e->lstm_zero) (void)hipFree(e->lstm_zero);
+    if (e->cl_err) (void)hipFree(e->cl_err);
+    if (e->cl_err_host) (void)hipHostFree(e->cl_err_host);
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -387,6 +435,8 @@ extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
         HIP_OK(e, hipMemsetAsync(e->a2p, 0, (N * e->Tpitch + 64) * 16 * 2, e->stream));
         if (alloc((void **)&e->xa, T * N * e->C * 2)) return MIBC_ERR_MEM;
         if (alloc((void **)&e->xb, T * N * e->C * 2)) return MIBC_ERR_MEM;
+        if (!e->lstm_wcl.empty() && N >= 256)
+            if (alloc((void **)&e->cl_flags, (N / 256) * (size_t)(e->C / 128) * 16 * sizeof(unsigned))) return MIBC_ERR_MEM;
     }
     if (alloc((void **)&e->scores, Nd * T * e->K * 2)) return MIBC_ERR_MEM;
     if (e->d.out_features > 0)
@@ -438,12 +488,12 @@ extern "C" int mibc_memcpy_d2h(mibc_engine *e, void *dst, const void *src, size_
     HIP_OK(e, hipSetDevice(e->device));
     HIP_OK(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
     HIP_OK(e, hipStreamSynchronize(e->stream));
-    return MIBC_OK;
+    return check_cluster_error(e);
 }
 extern "C" int mibc_sync(mibc_engine *e) {
     HIP_OK(e, hipSetDevice(e->device));
     HIP_OK(e, hipStreamSynchronize(e->stream));
-    return MIBC_OK;
+    return check_cluster_error(e);
 }
 extern "C" int mibc_set_profile(mibc_engine *e, int level) {
     e->profile = level;
@@ -497,10 +547,18 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     for (int l = 0; l < d.lstm_layers; ++l) {
         // LSTMStack(layers, size, reverse_first = true): nn/LSTMStack.cpp:29-41, CRFModel.cpp:41
         const int reverse = (l % 2 == 0) ? 1 : 0;
-        if (e->in_tmask != nullptr) {
-            if (mibc_launch_lstm_layer_masked(e->stream, e->C, cur, nxt, e->lstm_w16[l], e->lstm_bn[l], T, N, reverse,
-                                              e->in_tmask) != 0)
-                return fail(e, MIBC_NOT_SUPPORTED, "variable chunks need lstm_size 128 / 256 / 384 and N % 64 == 0");
+        // wide layers: the hidden-split cluster kernel whenever the batch is a whole number of 256-row clusters
+        // (same arithmetic, element for element, as the per-workgroup kernel it replaces)
+        const bool cl_ok = e->use_cluster && !e->lstm_wcl.empty() && e->cl_flags != nullptr && N % 256 == 0 &&
+                           mibc_launch_lstm_layer_cl(e->stream, e->C, cur, nxt, e->lstm_wcl[l], e->lstm_bcl[l],
+                                                     e->lstm_zero, e->cl_flags, e->cl_err, T, N, reverse,
+                                                     e->in_tmask) == 0;
+        if (cl_ok) {
+            e->cl_used = true;
+        } else if (e->in_tmask != nullptr) {
+            if (mibc_launch_lstm_layer_masked(e->stream, e->C, cur, nxt, e->C >= 512 ? e->lstm_w[l] : e->lstm_w16[l],
+                                              e->lstm_bn[l], T, N, reverse, e->in_tmask) != 0)
+                return fail(e, MIBC_NOT_SUPPORTED, "variable chunks need an LSTM model and N % 64 == 0");
         } else if (mibc_launch_lstm_layer(e->stream, e->C, cur, nxt, e->lstm_w[l], e->lstm_w16[l], e->lstm_bn[l], T, N,
                                           reverse) != 0)
             return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
@@ -510,7 +568,22 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
         nxt = t;
     }
     e->lstm_out = cur;
+    if (e->cl_used)   // hand-off time-outs of the cluster kernel surface at the next stream synchronisation
+        HIP_OK(e, hipMemcpyAsync(e->cl_err_host, e->cl_err, 4, hipMemcpyDeviceToHost, e->stream));
     HIP_OK(e, hipGetLastError());
+    return MIBC_OK;
+}
+
+// after a stream synchronisation: did a cluster hand-off of the LSTM kernel time out?
+static int check_cluster_error(mibc_engine *e) {
+    if (e->cl_err_host && e->cl_err_host[0] != 0) {
+        const unsigned w = e->cl_err_host[0];
+        e->cl_err_host[0] = 0;
+        (void)hipMemsetAsync(e->cl_err, 0, 16, e->stream);
+        return fail(e, MIBC_ERR_HIP, "LSTM cluster kernel: hand-off between workgroups timed out (cluster " +
+                                             std::to_string((w >> 16) & 0x7fff) + ", step " + std::to_string(w & 0xffff) +
+                                             "); results of this call are invalid");
+    }
     return MIBC_OK;
 }
 
@@ -680,7 +753,7 @@ extern "C" int mibc_call(mibc_engine *e, const uint16_t *in_host, int N, int T_i
     if (rc != MIBC_OK) return rc;
     HIP_OK(e, hipMemcpyAsync(out_host, e->out3, (size_t)3 * N * T, hipMemcpyDeviceToHost, e->stream));
     HIP_OK(e, hipStreamSynchronize(e->stream));
-    return MIBC_OK;
+    return check_cluster_error(e);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -719,7 +792,7 @@ extern "C" int mibc_call_i16(mibc_engine *e, const int16_t *in_host, const float
     if (rc != MIBC_OK) return rc;
     HIP_OK(e, hipMemcpyAsync(out_host, e->out3, (size_t)3 * N * T, hipMemcpyDeviceToHost, e->stream));
     HIP_OK(e, hipStreamSynchronize(e->stream));
-    return MIBC_OK;
+    return check_cluster_error(e);
 }
 
 // Per-read shift / scale of the QUANTILE (strategy 0; params = quantile_a, quantile_b, shift_multiplier,
@@ -907,7 +980,7 @@ extern "C" int mibc_call_var(mibc_engine *e, const void *in_host, const float *s
     if (rc != MIBC_OK) return rc;
     HIP_OK(e, hipMemcpyAsync(out_host, e->out3, (size_t)3 * N * T, hipMemcpyDeviceToHost, e->stream));
     HIP_OK(e, hipStreamSynchronize(e->stream));
-    return MIBC_OK;
+    return check_cluster_error(e);
 }
 
 extern "C" int mibc_get_stage_ms(mibc_engine *e, mibc_stage_ms *out) {

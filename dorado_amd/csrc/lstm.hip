@@ -53,13 +53,17 @@ __device__ __forceinline__ void acc_init(float16_t (&acc)[4][RT], const float *b
     }
 }
 
-// lane-local gate math for one hidden tile: D row = hidden unit, D col = batch row
-template <int RT>
+// lane-local gate math for one hidden tile: D row = hidden unit, D col = batch row.
+// MASKED (variable-chunk mode): bit (rowbit0 + rt*32 + l31) of vm = "this batch row is inside a chunk at this
+// step"; outside, h and c are forced to 0 = the fresh initial state of the neighbouring chunk.
+template <int RT, bool MASKED = false>
 __device__ __forceinline__ void gates(const float16_t (&acc)[4][RT], float16_t (&cst)[RT], half_t *hnext,
-                                      int LD, int j, int l31, int lhi) {
+                                      int LD, int j, int l31, int lhi, unsigned long long vm = ~0ull,
+                                      int rowbit0 = 0) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         half_t *hdst = hnext + (rt * 32 + l31) * LD + j * 32 + 4 * lhi;
+        const bool rowon = !MASKED || ((vm >> (rowbit0 + rt * 32 + l31)) & 1ull);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             half4_t hv;
@@ -70,9 +74,14 @@ __device__ __forceinline__ void gates(const float16_t (&acc)[4][RT], float16_t (
                 const float fg = fast_sigmoid(acc[1][rt][r]);
                 const float gg = fast_tanh(acc[2][rt][r]);
                 const float og = fast_sigmoid(acc[3][rt][r]);
-                const float c = fmaf(fg, cst[rt][r], ig * gg);
+                float c = fmaf(fg, cst[rt][r], ig * gg);
+                float hval = og * fast_tanh(c);
+                if (MASKED && !rowon) {
+                    c = 0.0f;
+                    hval = 0.0f;
+                }
                 cst[rt][r] = c;
-                hv[e] = (half_t)(og * fast_tanh(c));
+                hv[e] = (half_t)hval;
             }
             *(half4_t *)(hdst + 8 * q) = hv;
         }
@@ -206,10 +215,11 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_xl_kernel(
 // ---------------------------------------------------------------------------------------------
 // xg: x_t fragments straight from global/L2 (any C); NB = 32*RT rows, NW waves
 // ---------------------------------------------------------------------------------------------
-template <int C, int RT, int NW, int PF>
+template <int C, int RT, int NW, int PF, bool MASKED = false>
 __global__ __launch_bounds__(64 * NW, 1) void lstm_layer_xg_kernel(
         const half_t *__restrict__ Xin, half_t *__restrict__ Xout, const half_t *__restrict__ Wf,
-        const float *__restrict__ biasn, int T, int N, int reverse) {
+        const float *__restrict__ biasn, int T, int N, int reverse,
+        const unsigned long long *__restrict__ tmask = nullptr /* MASKED: [T][N/64], see x8 */) {
     constexpr int NB = 32 * RT;
     constexpr int NT = 64 * NW;
     constexpr int HT = C / 32 / NW;
@@ -266,6 +276,8 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_layer_xg_kernel(
         const half_t *xp_step_next = Xin + ((size_t)tn * N + n0 + l31) * C + 8 * lhi;
         const half_t *hprev = hbuf[step & 1];
         half_t *hnext = hbuf[(step + 1) & 1];
+        unsigned long long vm = ~0ull;
+        if (MASKED) vm = tmask[(size_t)t * (N / 64) + (n0 >> 6)];
 
 #pragma unroll
         for (int jj = 0; jj < HT; ++jj) {
@@ -311,7 +323,7 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_layer_xg_kernel(
                     kpre = (kpre + 1 == KTOT) ? 0 : kpre + 1;
                 }
             }
-            gates<RT>(acc, cst[jj], hnext, LD, j, l31, lhi);
+            gates<RT, MASKED>(acc, cst[jj], hnext, LD, j, l31, lhi, vm, n0 & 63);
         }
         __syncthreads();
         half_t *orow = Xout + ((size_t)t * N + n0) * C;
@@ -648,11 +660,27 @@ extern "C" int mibc_lstm_rows_per_wg(int C) {
     return 0;
 }
 
-// Variable-chunk mode: x8 kernels only (C = 128 / 256 / 384); returns 1 for other widths.
+// Variable-chunk mode: masked x8 kernels (C = 128 / 256 / 384) and masked xg kernels (C = 512 / 768 / 1024 —
+// the widths for which the reference enables variable chunk sizes, api/runner_creation.cpp:24-44).
 extern "C" int mibc_launch_lstm_layer_masked(hipStream_t s, int C, const half_t *Xin, half_t *Xout,
                                              const half_t *Wf16, const float *biasn, int T, int N, int reverse,
                                              const unsigned long long *tmask) {
-    if (Wf16 == nullptr || tmask == nullptr || N % 64 != 0) return 1;
+    if (tmask == nullptr || N % 64 != 0) return 1;
+    if (C >= 512) {
+        // Wf16 carries the 32-unit-tile layout (lstm_w) for these widths
+        if (Wf16 == nullptr) return 1;
+        const int nb = mibc_lstm_rows_per_wg(C);
+        dim3 grid(N / nb);
+#define XGM(CC, RT, NW) hipLaunchKernelGGL((lstm_layer_xg_kernel<CC, RT, NW, 4, true>), grid, dim3(64 * NW), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse, tmask)
+        switch (C) {
+            case 512: XGM(512, 2, 4); return 0;
+            case 768: XGM(768, 1, 8); return 0;
+            case 1024: XGM(1024, 1, 8); return 0;
+            default: return 1;
+        }
+#undef XGM
+    }
+    if (Wf16 == nullptr) return 1;
     dim3 g8(N / 64);
     switch (C) {
         case 128: hipLaunchKernelGGL((lstm_layer_x8_kernel<128, 4, true>), g8, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse, tmask); return 0;

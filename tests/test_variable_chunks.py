@@ -142,11 +142,58 @@ def test_variable_chunk_argument_errors():
             eng.forward_var(X, bad)
     eng.forward_var(X, [(0, 0, 600), (0, 612, 300)])           # exactly 2 steps apart is fine
     eng.close()
-    c512 = config.tiny(512, 5)
-    e2 = capi.Engine(c512, synth.make_weights(c512, seed=1))
+    ctx = config.tiny_tx()                                     # transformer models: not supported, loudly
+    e2 = capi.Engine(ctx, synth.make_weights(ctx, seed=1))
     with pytest.raises(capi.MibcNotSupported):
-        e2.forward_var(np.zeros((64, 1200), np.float16), [(0, 0, 600)])
+        e2.forward_var(np.zeros((4, 1536), np.float16), [(0, 0, 768)])
     e2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [512, 768, 1024])
+def test_packed_chunks_wide_layers(C):
+    """The widths for which the reference enables variable chunk sizes (api/runner_creation.cpp:24-44: 256 ... 1024
+    in steps of 128) beyond the x8 kernels: masked lstm_layer_xg_kernel (N = 64 rows) and the masked cluster
+    kernel (N = 256 rows).  Every packed chunk == the chunk called alone (bit-identical scores), decoder exact on
+    the engine's own scores, and the two kernels agree bit for bit on the same packing."""
+    cfg = config.tiny(C, 3)
+    cfg.lstm_layers = 5
+    ws = synth.make_weights(cfg, seed=60 + C)
+    stride, t_in, N = cfg.stride, 1200, 64
+    rng = np.random.default_rng(C)
+    lengths = [int(v) * stride for v in rng.integers(12, 190, 80)] + [t_in, stride * 2, stride * 199]
+    chunks, order = _pack(lengths, t_in, stride, N)
+    sigs = [synth.make_signal(1, L, seed=700 + i)[0] for i, L in enumerate(lengths)]
+    sigs = [sigs[i] for i in order]
+    X = np.full((N, t_in), 3.0, np.float16)               # garbage in the gaps must not matter
+    for (r, s0, L), x in zip(chunks, sigs):
+        X[r, s0:s0 + L] = x
+    eng = capi.Engine(cfg, ws)
+    S = eng.forward_var(X, chunks)
+    calls = eng.call_var(X, chunks)
+    for i, ((r, s0, L), x) in enumerate(zip(chunks, sigs)):
+        t0, tc = s0 // stride, L // stride
+        dec_in = np.clip(S[r, t0:t0 + tc][None].astype(np.float32), -5.0, 5.0)
+        want = O.decode(dec_in, q_shift=cfg.qbias, q_scale=cfg.qscale, det=1)[0]
+        assert calls[i][0] == want[0] and (calls[i][2] == want[2]).all()
+    for i in (0, len(chunks) // 3, len(chunks) // 2, len(chunks) - 1):
+        r, s0, L = chunks[i]
+        Xa = np.zeros((N, t_in), np.float16)
+        Xa[0, :L] = sigs[i]
+        Sa = eng.forward_var(Xa, [(0, 0, L)])
+        assert (Sa[0, :L // stride].view(np.uint16) == S[r, s0 // stride:(s0 + L) // stride].view(np.uint16)).all()
+        # vs the f32 oracle on the chunk alone (stated network tolerance)
+        ref = O.lstm_crf_forward(cfg, ws, sigs[i].astype(np.float32)[None, None, :])[0]
+        d = np.clip(Sa[0, :L // stride].astype(np.float32), -5, 5) - np.clip(ref, -5, 5)
+        assert np.abs(d).max() <= 0.15 and float(np.sqrt((d ** 2).mean())) <= 0.012
+    # the same packing in a 256-row batch runs on the masked CLUSTER kernel: bit-identical scores
+    X4 = np.full((256, t_in), -2.0, np.float16)
+    X4[:N] = X
+    S4 = eng.forward_var(X4, chunks)
+    for (r, s0, L) in chunks:
+        a, b = s0 // stride, (s0 + L) // stride
+        assert (S4[r, a:b].view(np.uint16) == S[r, a:b].view(np.uint16)).all()
+    eng.close()
 
 
 @pytest.mark.gpu
