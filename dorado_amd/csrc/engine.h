@@ -67,8 +67,9 @@ extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, h
 extern "C" int mibc_lstm_rows_per_wg(int C);
 // lstm_cluster.hip: hidden-split cluster kernel (C = 512 / 768 / 1024, N a multiple of 256); 1 = shape not covered
 extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin, half_t *Xout, const half_t *Wt,
-                                         const float *biascl, const half_t *zeros, unsigned *flags, unsigned *err,
-                                         int T, int N, int reverse, const unsigned long long *tmask);
+                                         const float *biascl, const half_t *zeros, float *cbuf, unsigned *flags,
+                                         unsigned *err, int T, int N, int reverse,
+                                         const unsigned long long *tmask);
 extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
                                       float beam_cut, float stay, float clampv, float q_shift, float q_scale,
                                       float *bwd, uint32_t *trace, uint16_t *path_state, int8_t *out3,
@@ -102,6 +103,7 @@ struct mibc_engine {
     std::vector<float *> lstm_bcl;   // [C/128][2][2][4][32]
     half_t *lstm_zero = nullptr;     // [256][C] zeros (h_{-1})
     unsigned *cl_flags = nullptr;    // [N_res/256][C/128][16] completed-step counters (zeroed per launch)
+    float *cl_cstate = nullptr;      // [N_res][C] f32 cell state of the layer in flight (workspace)
     unsigned *cl_err = nullptr;      // device [4]: sticky hand-off time-out word
     unsigned *cl_err_host = nullptr; // pinned copy, checked after every stream synchronisation
     bool cl_used = false;

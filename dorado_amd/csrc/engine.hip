@@ -312,10 +312,11 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
 static void free_ws(mibc_engine *e) {
     if (e->is_tx) tx_free_ws(e);
     void *ptrs[] = {e->in_stage, e->a2p, e->xa, e->xb, e->scores, e->mid, e->a1_tap, e->bwd,
-                    e->prob_tap, e->trace, e->path_state, e->out3, e->ss_stage, e->cl_flags};
+                    e->prob_tap, e->trace, e->path_state, e->out3, e->ss_stage, e->cl_flags, e->cl_cstate};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     e->cl_flags = nullptr;
+    e->cl_cstate = nullptr;
     e->in_stage = e->a2p = e->xa = e->xb = e->scores = e->mid = e->a1_tap = nullptr;
     e->bwd = e->prob_tap = nullptr;
     e->trace = nullptr;
@@ -435,8 +436,10 @@ extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
         HIP_OK(e, hipMemsetAsync(e->a2p, 0, (N * e->Tpitch + 64) * 16 * 2, e->stream));
         if (alloc((void **)&e->xa, T * N * e->C * 2)) return MIBC_ERR_MEM;
         if (alloc((void **)&e->xb, T * N * e->C * 2)) return MIBC_ERR_MEM;
-        if (!e->lstm_wcl.empty() && N >= 256)
+        if (!e->lstm_wcl.empty() && N >= 256) {
             if (alloc((void **)&e->cl_flags, (N / 256) * (size_t)(e->C / 128) * 16 * sizeof(unsigned))) return MIBC_ERR_MEM;
+            if (alloc((void **)&e->cl_cstate, (N / 256) * 256 * (size_t)e->C * sizeof(float))) return MIBC_ERR_MEM;
+        }
     }
     if (alloc((void **)&e->scores, Nd * T * e->K * 2)) return MIBC_ERR_MEM;
     if (e->d.out_features > 0)
@@ -551,7 +554,7 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
         // (same arithmetic, element for element, as the per-workgroup kernel it replaces)
         const bool cl_ok = e->use_cluster && !e->lstm_wcl.empty() && e->cl_flags != nullptr && N % 256 == 0 &&
                            mibc_launch_lstm_layer_cl(e->stream, e->C, cur, nxt, e->lstm_wcl[l], e->lstm_bcl[l],
-                                                     e->lstm_zero, e->cl_flags, e->cl_err, T, N, reverse,
+                                                     e->lstm_zero, e->cl_cstate, e->cl_flags, e->cl_err, T, N, reverse,
                                                      e->in_tmask) == 0;
         if (cl_ok) {
             e->cl_used = true;

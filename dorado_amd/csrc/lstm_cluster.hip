@@ -29,6 +29,8 @@
 // rest of the launch (results are garbage, the kernel still terminates) and the host reports it.
 #include "common.h"
 
+#include <utility>
+
 #define CL_ROWS 256
 #define CL_BK 32
 #define CL_NST 4
@@ -47,28 +49,43 @@
 
 typedef __attribute__((address_space(1))) unsigned int gu32;
 
-__device__ __forceinline__ void cl_dma16(const half_t *g, half_t *l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) — a guaranteed full unroll
+template <typename F, int... I>
+__device__ __forceinline__ void cl_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
 }
-__device__ __forceinline__ void cl_dma16_sc1(const half_t *g, half_t *l) {   // agent-scope (L1 bypass) load
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)l, 16, 0, 16);
+template <int N, typename F>
+__device__ __forceinline__ void cl_static_for(F &&f) {
+    cl_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
-__device__ __forceinline__ void cl_dma4_sc1(const unsigned *g, unsigned *l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)l, 4, 0, 16);
+
+// LDS destinations are passed as byte addresses inside the workgroup's LDS allocation (wave-uniform)
+typedef __attribute__((address_space(3))) void *lds_vptr;
+#define LDSP(T) __attribute__((address_space(3))) T *
+typedef const __attribute__((address_space(1))) half_t *ghalf_p;   // global-address-space pointer (no generic selects)
+__device__ __forceinline__ void cl_dma16(ghalf_p g, unsigned lds_addr) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (lds_vptr)(size_t)lds_addr, 16, 0, 0);
+}
+__device__ __forceinline__ void cl_dma16_sc1(ghalf_p g, unsigned lds_addr) {   // agent-scope (L1 bypass) load
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (lds_vptr)(size_t)lds_addr, 16, 0, 16);
+}
+__device__ __forceinline__ void cl_dma4_sc1(const unsigned *g, unsigned lds_addr) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (lds_vptr)(size_t)lds_addr, 4, 0, 16);
 }
 
 // One launch = one layer.  grid = KCL * (clusters resident at once); a workgroup loops over the row
 // groups (clusters of 256 rows) rg = first, first + stride, ... so that N may exceed one residency.
-template <int C, bool MASKED>
+// DBG (debug build only; results are wrong when non-zero): timing ablations — 1 no gate math, 2 no DMA after the
+// first step, 4 no MFMA, 8 no hand-off wait / publish, 16 no fragment reads, 32 / 64 weight / activation slabs
+// always fetched from the same (cache-resident) address.
+template <int C, bool MASKED, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
         const half_t *__restrict__ Xin,     // [T][N][C]
         half_t *__restrict__ Xout,          // [T][N][C]
         const half_t *__restrict__ Wt,      // [KCL][2][KS][256][32]: swizzled LDS images of the weight slabs
         const float *__restrict__ biascl,   // [KCL][2][2][4][32]  (b_ih + b_hh)
         const half_t *__restrict__ zeros,   // [256][C] zeros (h_{-1})
+        float *__restrict__ cbuf,           // [N][C] f32 cell state, private layout (see seg_gates); no init needed
         unsigned *__restrict__ flags,       // [nclusters][KCL][16]: completed steps of member j (zeroed per launch)
         unsigned *__restrict__ err,         // [4]: sticky error word, first failing (cluster, step)
         int T, int N, int reverse, int cpx /* clusters per XCD slot group, 0 = linear map */,
@@ -78,11 +95,14 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
     constexpr int KSX = C / CL_BK;         // x-part slabs per pass
     constexpr int KS = 2 * KSX;            // slabs per pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    half_t *stage = (half_t *)smem;
-    half_t *patch_all = (half_t *)(smem + CL_OFF_PATCH);
-    float *bias_s = (float *)(smem + CL_OFF_BIAS);
-    unsigned *flagz = (unsigned *)(smem + CL_OFF_FLAGZ);
-    volatile unsigned *syncw = (volatile unsigned *)(smem + CL_OFF_SYNC);
+    // every LDS access goes through explicit LDS-address-space pointers (no generic pointers, no aperture tests)
+    LDSP(unsigned char) smem3 = (LDSP(unsigned char))smem;
+    LDSP(half_t) stage = (LDSP(half_t))smem3;
+    LDSP(half_t) patch_all = (LDSP(half_t))(smem3 + CL_OFF_PATCH);
+    LDSP(float) bias_s = (LDSP(float))(smem3 + CL_OFF_BIAS);
+    LDSP(unsigned) flagz = (LDSP(unsigned))(smem3 + CL_OFF_FLAGZ);
+    LDSP(volatile unsigned) syncw = (LDSP(volatile unsigned))(smem3 + CL_OFF_SYNC);
+    const unsigned lds0 = (unsigned)(size_t)smem3;   // byte address of the allocation (DMA destinations)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -118,101 +138,108 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
     const half_t *wsrc = Wt + (size_t)j * 2 * KS * CL_WTILE + (size_t)(wave * 2) * 512 + lane * 8;
 
     for (int i = tid; i < 2 * 2 * 4 * 32; i += 512) bias_s[i] = biascl[(size_t)j * 2 * 2 * 4 * 32 + i];
-    half_t *patch = patch_all + wave * CL_PATCH;
+    LDSP(half_t) patch = patch_all + wave * CL_PATCH;
     bool dead = false;
+
+    const bool grpB = wave >= 4;
+    const int sw = (l31 >> 2) & 3;              // (row >> 2) & 3 for every fragment row of this lane
+    const int c0 = ((0 + lhi) ^ sw) << 3, c1 = ((2 + lhi) ^ sw) << 3;
+    // fragment read bases of this lane inside a stage (halfs)
+    const int woff = (hg * 128 + l31) * CL_BK, xoff = CL_WTILE + (rgw * 64 + l31) * CL_BK;
+    const unsigned long long wslice = (unsigned long long)(Wt + (size_t)j * 2 * KS * CL_WTILE);   // uniform
+    const unsigned wlane = (unsigned)(((wave * 2) * 512 + lane * 8) * 2);                              // bytes
+    const unsigned aoffb[2] = {aoff[0] * 2u, aoff[1] * 2u};                                             // bytes
+    const unsigned dma_lds = lds0 + (unsigned)(wave * 2) * 1024u;   // + slot * 64 KiB/2 ... + tile + q * 1 KiB
 
     for (int cl = cl0; cl < nclusters; cl += resident_clusters) {
         const int n0 = cl * CL_ROWS;
         unsigned *myflag = flags + ((size_t)cl * KCL + j) * 16;
         const unsigned *clflags = flags + (size_t)cl * KCL * 16;
 
-        float16_t cst[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) cst[a][b][r] = 0.0f;
+        // Per pass the 2C/32 slabs are FULLY UNROLLED: ring slots, weight-slab offsets and activation-column
+        // offsets are compile-time constants relative to a handful of per-pass scalars, so a slab costs ~a dozen
+        // scalar instructions (eight waves share the CU's scalar issue: a per-slab address state machine of ~150
+        // scalar instructions alone took as long as the slab's MFMAs).
+        // (Addresses are integers: selects between pointers into different allocations trip an address-space
+        // inference bug of this hipcc: "Illegal instruction ... V_CMP_NE_U32 0, $src_shared_base".)
+        const long long dstep = (reverse ? -1LL : 1LL) * (long long)N * C * 2;           // bytes per time step
+        const int t_first = reverse ? (T - 1) : 0;
+        unsigned long long x_cur = (unsigned long long)Xin + 2ull * (((size_t)t_first * N + n0) * C);
+        unsigned long long h_cur = (unsigned long long)zeros;                              // h_{-1} = 0
+        const unsigned long long o_first = (unsigned long long)Xout + 2ull * (((size_t)t_first * N + n0) * C);
 
-        // ---- slab stream state of the ISSUE side (runs 3 slabs ahead of the compute side) ----
-        int is_step = 0, is_u = 0;      // next slab to issue: step, u = pass * KS + ks
-        int ring_w = 0;                 // ring slot it goes to
-        auto issue_next = [&]() {
-            if (is_step >= T) return;
-            const int t = reverse ? (T - 1 - is_step) : is_step;
-            const int p = is_u / KS, ks = is_u % KS;
-            half_t *Ws = stage + ring_w * CL_STAGE, *As = Ws + CL_WTILE;
-            const half_t *wb = wsrc + (size_t)(p * KS + ks) * CL_WTILE;
-            cl_dma16(wb, Ws + (wave * 2) * 512);
-            cl_dma16(wb + 512, Ws + (wave * 2 + 1) * 512);
-            if (ks < KSX) {
-                const half_t *xb = Xin + ((size_t)t * N + n0) * C + ks * CL_BK;
-                cl_dma16(xb + aoff[0], As + (wave * 2) * 512);
-                cl_dma16(xb + aoff[1], As + (wave * 2 + 1) * 512);
-            } else {
-                const int tp = reverse ? (t + 1) : (t - 1);
-                const half_t *hb = (is_step == 0) ? zeros : (Xout + ((size_t)tp * N + n0) * C);
-                hb += (ks - KSX) * CL_BK;
-                cl_dma16_sc1(hb + aoff[0], As + (wave * 2) * 512);
-                cl_dma16_sc1(hb + aoff[1], As + (wave * 2 + 1) * 512);
-            }
-            ring_w = (ring_w + 1) & (CL_NST - 1);
-            if (++is_u == 2 * KS) {
-                is_u = 0;
-                ++is_step;
-            }
+        // DMA of one slab into ring slot `slot`: weights from byte offset w_off of this member's slice,
+        // activations from a_base (row 0 of the cluster, first column of the slab).  Both activation halves
+        // (x_t and the exchanged h_{t-1}) use agent-scope (sc1) loads: no L1 reuse to lose, and the hand-off needs it.
+        // Every address is (uniform 64-bit base in SGPRs) + (this lane's constant 32-bit byte offset): the bases are
+        // made opaque per slab — with 64 unrolled slabs the optimiser otherwise hoists 64 x 4 loop-invariant per-lane
+        // 64-bit addresses out of the time loop and spills them.
+        auto issue = [&](int slot, unsigned w_off, unsigned long long a_base, bool on) __attribute__((always_inline)) {
+            if ((DBG & 2) && !on) return;
+            const unsigned l = dma_lds + (unsigned)slot * (CL_STAGE * 2);
+            if (DBG & 32) w_off = 0;                       // ablation: weight slab always L2-resident
+            if (DBG & 64) a_base = (unsigned long long)Xin;   // ablation: activation slab always L2-resident
+            unsigned long long wb = wslice + w_off;
+            asm volatile("" : "+s"(wb));
+            asm volatile("" : "+s"(a_base));
+            ghalf_p wp = (ghalf_p)(wb + wlane);
+            cl_dma16(wp, l);
+            cl_dma16(wp + 512, l + 1024);
+            cl_dma16_sc1((ghalf_p)(a_base + aoffb[0]), l + CL_WTILE * 2);
+            cl_dma16_sc1((ghalf_p)(a_base + aoffb[1]), l + CL_WTILE * 2 + 1024);
         };
-        __syncthreads();   // bias_s visible; previous row group's LDS reads are done
-        issue_next();
-        issue_next();
-        issue_next();
-        int ring_r = 0;
 
+        __syncthreads();   // bias_s visible; previous row group's LDS reads are done
+        issue(0, 0u, x_cur, true);                       // slabs 0 and 1 of (step 0, pass 0): 2 slabs ahead
+        issue(1, 2u * CL_WTILE, x_cur + 2ull * CL_BK, true);
+
+        // ---- two wave groups in anti-phase ----
+        // Waves w and w + 4 share a SIMD.  Group A = waves 0-3, group B = waves 4-7; per slab every wave runs a LOAD
+        // segment L (issue the DMAs of slab g + 2, read the first k16 step's fragments of slab g) and a MATRIX
+        // segment M (16 MFMAs, the second step's fragments fetched in a rolling fashion behind the MFMAs that free
+        // their registers), with a workgroup barrier in front of each:  B1 L(g) B2 M(g)  B1 L(g+1) B2 M(g+1) ...
+        // Both groups run the SAME instruction stream; group B executes one extra barrier up front (group A one at
+        // the end), which shifts B by one barrier instance: A.B1(g) pairs with B.B2(g-1), A.B2(g) with B.B1(g) —
+        // on every SIMD one wave feeds the matrix pipe while its partner occupies the LDS / DMA / scalar issue.
+        // Slab g must have landed in LDS — every wave's part — before the instance after which the first wave reads
+        // it, A.B1(g) == B.B2(g-1): with 4 DMAs per lane and slab and 2 slabs of look-ahead, A waits vmcnt(4) before
+        // its B1(g), B waits vmcnt(4) before its B2(g-1) (younger: one slab).  Extra younger operations (h stores,
+        // flag fetch) only make a wait stricter.  The DMAs of slab g + 2 reuse the ring slot of slab g - 2, last
+        // read in M(g-2), which both groups have finished before the instance A.B1(g).
+        float16_t acc[4][2];
+        half8_t wf[4], xa[2];
+        float4_t cpre[2][4];
+        if (grpB) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // own part of slab 0 (group A reads it after this instance)
+            __builtin_amdgcn_s_barrier();
+        }
+#pragma nounroll
         for (int step = 0; step < T; ++step) {
             const int t = reverse ? (T - 1 - step) : step;
             const bool last_step = (step == T - 1);
             unsigned long long vm = ~0ull;
             if (MASKED) vm = tmask[(size_t)t * (N / 64) + (n0 >> 6) + rgw];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                float16_t acc[4][2];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float *bp = bias_s + ((p * 2 + hg) * 4 + g) * 32 + 4 * lhi;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4_t v = *(const float4_t *)(bp + 8 * q);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            acc[g][0][q * 4 + e] = v[e];
-                            acc[g][1][q * 4 + e] = v[e];
-                        }
-                    }
-                }
+            const unsigned long long x_next = last_step ? x_cur : (unsigned long long)((long long)x_cur + dstep);
 #pragma nounroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const int u = p * KS + ks;
-                    // slab (step, u) has landed when only the two younger slabs (8 DMAs per lane) are still in
-                    // flight; extra younger operations (h stores, flag fetch) only make this wait stricter
-                    const bool tail = last_step && (u >= 2 * KS - 2);
-                    if (p == 0 && ks == 2 && step > 0) {
-                        // publish h_{step-1}: the sc1 stores of both passes were issued >= 2 slabs ago
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    } else if (!tail) {
-                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    } else {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    __builtin_amdgcn_s_barrier();
-                    if (p == 0 && step > 0) {
-                        if (ks == 2) {
-                            if (tid == 0 && !dead)
-                                __hip_atomic_store((gu32 *)myflag, (unsigned)step, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-                        } else if (ks == KSX - 6) {
-                            if (wave == 0) cl_dma4_sc1(clflags + (lane < KCL ? lane : 0) * 16, flagz);
-                        } else if (ks == KSX - 3 && !dead) {
-                            // h_{step-1} of every member must be visible before the first h slab is fetched
+            for (int p = 0; p < 2; ++p) {
+                const unsigned w_pass = (unsigned)p * (KS * CL_WTILE * 2);                 // bytes
+                // the pass after this one (for the two look-ahead slabs at the end): pass 1 of this step, or pass 0
+                // of the next step; past the end of the layer the last slabs are fetched again (nobody reads them)
+                const unsigned w_n = (p == 0) ? (unsigned)(KS * CL_WTILE * 2) : 0u;
+                const unsigned long long x_n = (p == 0) ? x_cur : x_next;
+                const bool ev = (p == 0) && (step > 0) && !(DBG & 8);
+                const bool dma_on = (step == 0);   // DBG & 2: DMAs only during the first step
+
+                // Hand-off events (workgroup-wide, attached to ONE barrier instance: A's B1 of the slab, B's B2 of the
+                // slab before).  ks == 3: every wave drained its h stores ahead of this instance -> publish
+                // h_{step-1}.  ks == KSX - 2: h_{step-1} of every member must be visible before the first h slab
+                // (slab KSX) is fetched.
+                auto events = [&](int ks) __attribute__((always_inline)) {
+                    if (ks == 3) {
+                        if (ev && tid == 0 && !dead)
+                            __hip_atomic_store((gu32 *)myflag, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else if (ks == KSX - 2) {
+                        if (ev && !dead) {
                             bool ok = true;
 #pragma unroll
                             for (int m = 0; m < KCL; ++m) ok = ok && (flagz[m] >= (unsigned)step);
@@ -232,77 +259,195 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
                                 __syncthreads();
                                 if (syncw[0] == 2u) {
                                     dead = true;
-                                    if (tid == 0) {
-                                        atomicCAS(err, 0u, 0x80000000u | ((unsigned)cl << 16) | (unsigned)step);
-                                    }
+                                    if (tid == 0) atomicCAS(err, 0u, 0x80000000u | ((unsigned)cl << 16) | (unsigned)step);
                                 }
                                 __syncthreads();
                             }
                         }
                     }
-                    issue_next();
-                    const half_t *Ws = stage + ring_r * CL_STAGE, *As = Ws + CL_WTILE;
-                    ring_r = (ring_r + 1) & (CL_NST - 1);
+                };
+
+                cl_static_for<KS>([&](auto ks_c) __attribute__((always_inline)) {
+                    constexpr int ks = decltype(ks_c)::value;
+                    constexpr int slot = ks & 3;
+                    // ---------------- B1(g) ----------------
+                    if (!grpB) {
+                        if (ks == 3 && ev) {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        } else {
+                            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        }
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (!grpB) events(ks);
+                    // ---------------- L(g): fragments of the first k16 step, DMAs of slab g + 2 ----------------
+                    {
+                        if (wave == 0 && ks == KSX - 4 && ev)
+                            cl_dma4_sc1(clflags + (lane < KCL ? lane : 0) * 16, lds0 + CL_OFF_FLAGZ);
+                        LDSP(const half_t) sp = stage + slot * CL_STAGE;
+                        if (DBG & 16) {
 #pragma unroll
-                    for (int k16 = 0; k16 < 2; ++k16) {
-                        half8_t wf[4], xf[2];
+                            for (int g = 0; g < 4; ++g) wf[g] = (half8_t)((half_t)(0.001f * (g + 1)));
+                            xa[0] = (half8_t)((half_t)0.002f);
+                            xa[1] = (half8_t)((half_t)0.003f);
+                        } else {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) wf[g] = *(LDSP(const half8_t))(sp + woff + g * 32 * CL_BK + c0);
+                            xa[0] = *(LDSP(const half8_t))(sp + xoff + c0);
+                            xa[1] = *(LDSP(const half8_t))(sp + xoff + 32 * CL_BK + c0);
+                        }
+                        constexpr int LA = 2;
+                        const int kt = ks + LA;
+                        if (kt < KSX) {
+                            issue(kt & 3, w_pass + (unsigned)kt * (CL_WTILE * 2), x_cur + (unsigned)kt * (CL_BK * 2), dma_on);
+                        } else if (kt < KS) {
+                            issue(kt & 3, w_pass + (unsigned)kt * (CL_WTILE * 2), h_cur + (unsigned)(kt - KSX) * (CL_BK * 2), dma_on);
+                        } else {
+                            issue(kt & 3, w_n + (unsigned)(kt - KS) * (CL_WTILE * 2), x_n + (unsigned)(kt - KS) * (CL_BK * 2),
+                                  dma_on && p == 0);
+                        }
+                    }
+                    // ---------------- B2(g) ----------------
+                    if (grpB) {
+                        if (ks + 1 == 3 && ev) {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        } else {
+                            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        }
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (grpB && ks + 1 < KS) events(ks + 1);
+                    // ---------------- M(g) ----------------
+                    {
+                        if (ks == 0) {   // first slab of a pass: accumulators start from the bias
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                LDSP(const float) bp = bias_s + ((p * 2 + hg) * 4 + g) * 32 + 4 * lhi;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const float4_t v = *(LDSP(const float4_t))(bp + 8 * q);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        acc[g][0][q * 4 + e] = v[e];
+                                        acc[g][1][q * 4 + e] = v[e];
+                                    }
+                                }
+                            }
+                        }
+                        LDSP(const half_t) sp = stage + slot * CL_STAGE;
+                        half8_t xb[2];
+                        if (DBG & 16) {
+                            xb[0] = (half8_t)((half_t)0.004f);
+                            xb[1] = (half8_t)((half_t)0.005f);
+                        }
+                        if (ks == KS - 1) {
+                            // cell state of this pass (private scratch, see below): the latency hides under the MFMAs
+                            if (step == 0) {   // zero initial state (nn/LSTMStack.cpp:29-41: no h0 / c0 given)
+#pragma unroll
+                                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) cpre[rt][q] = (float4_t)(0.0f);
+                            } else {
+#pragma unroll
+                                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q)
+                                        cpre[rt][q] = *((const float4_t *)(cbuf + ((((((size_t)cl * KCL + j) * 2 + p) * 8 + wave) * 2 + rt) * 4 + q) * 256) + lane);
+                            }
+                        }
+                        __builtin_amdgcn_s_setprio(1);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const int row = hg * 128 + g * 32 + l31;
-                            wf[g] = *(const half8_t *)(Ws + row * CL_BK + (((2 * k16 + lhi) ^ ((row >> 2) & 3)) << 3));
-                        }
-#pragma unroll
-                        for (int rt = 0; rt < 2; ++rt) {
-                            const int row = rgw * 64 + rt * 32 + l31;
-                            xf[rt] = *(const half8_t *)(As + row * CL_BK + (((2 * k16 + lhi) ^ ((row >> 2) & 3)) << 3));
-                        }
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-#pragma unroll
-                            for (int rt = 0; rt < 2; ++rt) acc[g][rt] = mfma32x32x16(wf[g], xf[rt], acc[g][rt]);
-                    }
-                }
-                // ---- gates of this pass: D row = hidden (r&3) + 8 (r>>2) + 4 lhi, D col = batch row l31 ----
-                const int hcol = j * 128 + p * 64 + hg * 32;
-                const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
-                        (void *)(Xout + ((size_t)t * N + n0 + rgw * 64) * C + hcol), 0, 64 * C * 2, 0x00020000);
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    const bool rowon = !MASKED || ((vm >> (rt * 32 + l31)) & 1ull);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        half4_t hv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int r = q * 4 + e;
-                            const float ig = fast_sigmoid(acc[0][rt][r]);
-                            const float fg = fast_sigmoid(acc[1][rt][r]);
-                            const float gg = fast_tanh(acc[2][rt][r]);
-                            const float og = fast_sigmoid(acc[3][rt][r]);
-                            float c = fmaf(fg, cst[p][rt][r], ig * gg);
-                            float hval = og * fast_tanh(c);
-                            if (MASKED && !rowon) {
-                                c = 0.0f;
-                                hval = 0.0f;
+                            if (!(DBG & 4)) {
+                                acc[g][0] = mfma32x32x16(wf[g], xa[0], acc[g][0]);
+                                acc[g][1] = mfma32x32x16(wf[g], xa[1], acc[g][1]);
+                            } else {
+                                asm volatile("" ::"v"(wf[g]), "v"(xa[0]), "v"(xa[1]));
                             }
-                            cst[p][rt][r] = c;
-                            hv[e] = (half_t)hval;
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (!(DBG & 16)) {
+                                wf[g] = *(LDSP(const half8_t))(sp + woff + g * 32 * CL_BK + c1);
+                                if (g == 0) {
+                                    xb[0] = *(LDSP(const half8_t))(sp + xoff + c1);
+                                    xb[1] = *(LDSP(const half8_t))(sp + xoff + 32 * CL_BK + c1);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
                         }
-                        *(half4_t *)(patch + l31 * CL_PATCH_LD + 8 * q + 4 * lhi) = hv;
-                    }
-                    __builtin_amdgcn_wave_barrier();   // same wave: LDS operations execute in order
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int prow = (lane >> 2) + 16 * i, seg = lane & 3;
-                        const half8_t v = *(const half8_t *)(patch + prow * CL_PATCH_LD + seg * 8);
-                        __builtin_amdgcn_raw_buffer_store_b128(
-                                __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v), ors,
-                                ((rt * 32 + prow) * C + seg * 8) * 2, 0, 16 /* sc1: write-through */);
+                        for (int g = 0; g < 4; ++g) {
+                            if (!(DBG & 4)) {
+                                acc[g][0] = mfma32x32x16(wf[g], xb[0], acc[g][0]);
+                                acc[g][1] = mfma32x32x16(wf[g], xb[1], acc[g][1]);
+                            } else {
+                                asm volatile("" ::"v"(wf[g]), "v"(xb[0]), "v"(xb[1]));
+                            }
+                        }
+                        __builtin_amdgcn_s_setprio(0);
+                        if (ks == KS - 1) {
+                            // ---- gates of this pass: D row = hidden (r&3) + 8 (r>>2) + 4 lhi, D col = batch row l31.
+                            // Cell state: fp32, in a private scratch buffer instead of registers (64 registers per
+                            // lane buy the fragment double-buffering of the anti-phase schedule).  Layout
+                            // [cluster][member][pass][wave][rt][q][lane][4]: every access is one coalesced 1 KiB wave
+                            // transaction; 32 KiB per workgroup and pass.
+                            const int hcol = j * 128 + p * 64 + hg * 32;
+                            const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+                                    (void *)(Xout + ((size_t)t * N + n0 + rgw * 64) * C + hcol), 0, 64 * C * 2, 0x00020000);
+#pragma unroll
+                            for (int rt = 0; rt < 2; ++rt) {
+                                const bool rowon = !MASKED || ((vm >> (rt * 32 + l31)) & 1ull);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    half4_t hv;
+                                    float4_t cn;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const int r = q * 4 + e;
+                                        float c, hval;
+                                        if (DBG & 1) {
+                                            c = cpre[rt][q][e];
+                                            hval = 1e-3f * (acc[0][rt][r] + acc[1][rt][r] + acc[2][rt][r] + acc[3][rt][r]);
+                                        } else {
+                                            const float ig = fast_sigmoid(acc[0][rt][r]);
+                                            const float fg = fast_sigmoid(acc[1][rt][r]);
+                                            const float gg = fast_tanh(acc[2][rt][r]);
+                                            const float og = fast_sigmoid(acc[3][rt][r]);
+                                            c = fmaf(fg, cpre[rt][q][e], ig * gg);
+                                            hval = og * fast_tanh(c);
+                                        }
+                                        if (MASKED && !rowon) {
+                                            c = 0.0f;
+                                            hval = 0.0f;
+                                        }
+                                        cn[e] = c;
+                                        hv[e] = (half_t)hval;
+                                    }
+                                    *((float4_t *)(cbuf + ((((((size_t)cl * KCL + j) * 2 + p) * 8 + wave) * 2 + rt) * 4 + q) * 256) + lane) = cn;
+                                    *(LDSP(half4_t))(patch + l31 * CL_PATCH_LD + 8 * q + 4 * lhi) = hv;
+                                }
+                                __builtin_amdgcn_wave_barrier();   // same wave: LDS operations execute in order
+#pragma unroll
+                                for (int i = 0; i < 2; ++i) {
+                                    const int prow = (lane >> 2) + 16 * i, seg = lane & 3;
+                                    const half8_t v = *(LDSP(const half8_t))(patch + prow * CL_PATCH_LD + seg * 8);
+                                    __builtin_amdgcn_raw_buffer_store_b128(
+                                            __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v), ors,
+                                            ((rt * 32 + prow) * C + seg * 8) * 2, 0, 16 /* sc1: write-through */);
+                                }
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                        }
                     }
-                    __builtin_amdgcn_wave_barrier();
-                }
+                });
             }
+            // next step: x advances, h_{step} is this step's output rows
+            h_cur = (step == 0) ? o_first : (unsigned long long)((long long)h_cur + dstep);
+            x_cur = x_next;
         }
+        if (!grpB) __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -312,9 +457,11 @@ extern "C" size_t mibc_lstm_cl_lds_bytes(void) { return CL_LDS_BYTES; }
 
 // Returns 0 if launched, 1 if the shape is not covered (caller falls back to the per-workgroup kernels).
 extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin, half_t *Xout, const half_t *Wt,
-                                         const float *biascl, const half_t *zeros, unsigned *flags, unsigned *err,
-                                         int T, int N, int reverse, const unsigned long long *tmask) {
-    if (Wt == nullptr || biascl == nullptr || zeros == nullptr || flags == nullptr || err == nullptr) return 1;
+                                         const float *biascl, const half_t *zeros, float *cbuf, unsigned *flags,
+                                         unsigned *err, int T, int N, int reverse,
+                                         const unsigned long long *tmask) {
+    if (Wt == nullptr || biascl == nullptr || zeros == nullptr || cbuf == nullptr || flags == nullptr || err == nullptr)
+        return 1;
     if ((C != 512 && C != 768 && C != 1024) || N < CL_ROWS || N % CL_ROWS != 0) return 1;
     const int KCL = C / 128;
     const int nclusters = N / CL_ROWS;
@@ -343,8 +490,23 @@ extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin
             once = true;                                                                                    \
         }                                                                                                   \
         hipLaunchKernelGGL((lstm_layer_cl_kernel<CC, M_>), grid, dim3(512), CL_LDS_BYTES, s, Xin, Xout, Wt, \
-                           biascl, zeros, flags, err, T, N, reverse, cpx, resident, tmask);                 \
+                           biascl, zeros, cbuf, flags, err, T, N, reverse, cpx, resident, tmask);           \
     } while (0)
+#ifdef MIBC_DEBUG_KERNELS
+    static const int dbg = MIBC_ENV_INT("MIBC_CL_DBG", 0);
+    if (dbg && C == 1024 && tmask == nullptr) {
+#define CL_DBG(D_)                                                                                          \
+    case D_: {                                                                                              \
+        (void)hipFuncSetAttribute((const void *)lstm_layer_cl_kernel<1024, false, D_>,                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, CL_LDS_BYTES);                \
+        hipLaunchKernelGGL((lstm_layer_cl_kernel<1024, false, D_>), grid, dim3(512), CL_LDS_BYTES, s, Xin,  \
+                           Xout, Wt, biascl, zeros, cbuf, flags, err, T, N, reverse, cpx, resident, tmask); \
+        return 0;                                                                                           \
+    }
+        switch (dbg) { CL_DBG(1) CL_DBG(2) CL_DBG(4) CL_DBG(8) CL_DBG(16) CL_DBG(18) CL_DBG(22) CL_DBG(27) CL_DBG(32) CL_DBG(64) CL_DBG(96) default: break; }
+#undef CL_DBG
+    }
+#endif
     if (tmask != nullptr) {
         switch (C) {
             case 512: CL_LAUNCH(512, true); return 0;

@@ -17,7 +17,10 @@ ap.add_argument("--batch", type=int, default=16384)
 ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--model", default="hac")
 ap.add_argument("--tin", type=int, default=0)
+ap.add_argument("--lib", default="", help="'dbg' = dorado_amd/libmibc_dbg.so (make -C dorado_amd/csrc debug): MIBC_* switches")
 a = ap.parse_args()
+if a.lib == "dbg":
+    capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), "libmibc_dbg.so")
 cfg = {"hac": config.hac_v43, "sup": config.sup_v43, "sup5": config.sup_v50, "fast": config.fast_v43}.get(a.model, lambda: config.tiny(128, 4))()
 t_in = a.tin or cfg.chunk_size
 eng = capi.Engine(cfg, synth.make_weights(cfg, seed=42))
