@@ -1104,3 +1104,93 @@ extern "C" int mibc_debug_gemm(int M, int N, int K, int dbg, int iters, float *m
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+
+// Test entry (not part of the public ABI): runs one GEMM shape through gemm256_kernel and through gemm_dma_kernel on
+// the same pseudo-random operands and reports how many output halfs differ (contract: none — same arithmetic) and
+// both run times.  epi: 0 plain (act, optional bias), 1 rotary + transposed V (N = 3 * d_model, T = rope_T), 2 SwiGLU.
+extern "C" int mibc_debug_gemm_compare(int M, int N, int K, int epi, int act, int use_bias, int rope_T, int iters,
+                                       long long *ndiff, float *maxdiff, float *ms_256, float *ms_128) {
+    auto lcg = [](uint32_t &s) {
+        s = s * 1664525u + 1013904223u;
+        return (float)((s >> 9) & 0x7fff) / 16384.0f - 1.0f;   // [-1, 1)
+    };
+    uint32_t seed = 12345u + (uint32_t)(M + 3 * N + 7 * K + epi);
+    std::vector<half_t> hA((size_t)M * K), hB((size_t)N * K);
+    for (auto &v : hA) v = (half_t)lcg(seed);
+    for (auto &v : hB) v = (half_t)(lcg(seed) * 0.08f);
+    std::vector<float> hbias((size_t)N), hrope((size_t)(rope_T > 0 ? rope_T : 1) * 64);
+    for (auto &v : hbias) v = lcg(seed);
+    for (size_t i = 0; i < hrope.size() / 2; ++i) {
+        const float ang = 3.0f * lcg(seed);
+        hrope[2 * i] = cosf(ang);
+        hrope[2 * i + 1] = sinf(ang);
+    }
+    half_t *A = nullptr, *B = nullptr, *C1 = nullptr, *C2 = nullptr, *V1 = nullptr, *V2 = nullptr;
+    float *bias = nullptr, *rope = nullptr;
+    const size_t ocols = (epi == 2) ? (size_t)N / 2 : (size_t)N;
+    const size_t obytes = (size_t)M * ocols * 2, vbytes = (size_t)M * (N / 3) * 2;
+    if (hipMalloc((void **)&A, hA.size() * 2) != hipSuccess || hipMalloc((void **)&B, hB.size() * 2) != hipSuccess ||
+        hipMalloc((void **)&C1, obytes) != hipSuccess || hipMalloc((void **)&C2, obytes) != hipSuccess ||
+        hipMalloc((void **)&bias, hbias.size() * 4) != hipSuccess || hipMalloc((void **)&rope, hrope.size() * 4) != hipSuccess ||
+        hipMalloc((void **)&V1, vbytes) != hipSuccess || hipMalloc((void **)&V2, vbytes) != hipSuccess)
+        return -1;
+    (void)hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(B, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(bias, hbias.data(), hbias.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(rope, hrope.data(), hrope.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemset(C1, 0, obytes);
+    (void)hipMemset(C2, 0, obytes);
+    (void)hipMemset(V1, 0, vbytes);
+    (void)hipMemset(V2, 0, vbytes);
+    GemmArgs g{};
+    g.A = A; g.B = B; g.bias = use_bias ? bias : nullptr; g.M = M; g.Ncols = N; g.K = K;
+    g.a_div = 1 << 30; g.a_inner = K; g.o_div = 1 << 30; g.o_inner = (long)ocols; g.act = act; g.epi_mode = epi;
+    if (epi == 1) { g.rope = rope; g.rope_T = rope_T; g.rope_cols = 2 * (N / 3); }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float ms[2] = {0, 0};
+    for (int which = 0; which < 2; ++which) {
+        g.out = which ? C2 : C1;
+        g.vT = (epi == 1) ? (which ? V2 : V1) : nullptr;
+        g.dbg = which ? 0x100 : 0;
+        if (mibc_launch_gemm_tn(nullptr, &g) != 0) return -2;
+        (void)hipEventRecord(e0, nullptr);
+        for (int i = 0; i < iters; ++i) mibc_launch_gemm_tn(nullptr, &g);
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms[which], e0, e1);
+        ms[which] /= (float)(iters > 0 ? iters : 1);
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return -3;
+    std::vector<half_t> o1(obytes / 2), o2(obytes / 2), v1(vbytes / 2), v2(vbytes / 2);
+    (void)hipMemcpy(o1.data(), C1, obytes, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(o2.data(), C2, obytes, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(v1.data(), V1, vbytes, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(v2.data(), V2, vbytes, hipMemcpyDeviceToHost);
+    long long nd = 0;
+    float md = 0.0f, amax = 0.0f;
+    auto cmp = [&](const std::vector<half_t> &x, const std::vector<half_t> &y) {
+        for (size_t i = 0; i < x.size(); ++i) {
+            uint16_t a, b;
+            memcpy(&a, &x[i], 2);
+            memcpy(&b, &y[i], 2);
+            if (a != b) {
+                ++nd;
+                const float d = fabsf((float)x[i] - (float)y[i]);
+                if (!(d <= md)) md = d;
+            }
+            amax = fmaxf(amax, fabsf((float)y[i]));
+        }
+    };
+    cmp(o1, o2);
+    if (epi == 1) cmp(v1, v2);
+    if (amax == 0.0f) nd = -1;   // nothing was written: the comparison is void
+    *ndiff = nd;
+    *maxdiff = md;
+    *ms_256 = ms[0];
+    *ms_128 = ms[1];
+    for (void *q : {(void *)A, (void *)B, (void *)C1, (void *)C2, (void *)V1, (void *)V2, (void *)bias, (void *)rope}) (void)hipFree(q);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+}

@@ -185,8 +185,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p) {
                 for (int e = 0; e < 8; ++e) {
                     const float2 cs = tab[e];
                     const float a = (float)v[e], b = (float)w[e];
-                    // evens' = cos*e - sin*o ; odds' = sin*e + cos*o   (nn/TxModules.cpp:241-244)
-                    v[e] = (half_t)(lo ? (cs.x * a - cs.y * b) : (cs.y * b + cs.x * a));
+                    // evens' = cos*e - sin*o ; odds' = sin*e + cos*o   (nn/TxModules.cpp:241-244); explicit fma forms
+                    // (shared with gemm256.hip) so that both kernels round identically
+                    v[e] = (half_t)(lo ? fmaf(cs.x, a, -(cs.y * b)) : fmaf(cs.y, b, cs.x * a));
                 }
             }
             *(half8_t *)dst = v;
@@ -392,8 +393,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmArgs p) {
                 for (int e = 0; e < 8; ++e) {
                     const float2 cs = tab[e];
                     const float a = (float)v[e], b = (float)w[e];
-                    // evens' = cos*e - sin*o ; odds' = sin*e + cos*o   (nn/TxModules.cpp:241-244)
-                    v[e] = (half_t)(lo ? (cs.x * a - cs.y * b) : (cs.y * b + cs.x * a));
+                    // evens' = cos*e - sin*o ; odds' = sin*e + cos*o   (nn/TxModules.cpp:241-244); explicit fma forms
+                    // (shared with gemm256.hip) so that both kernels round identically
+                    v[e] = (half_t)(lo ? fmaf(cs.x, a, -(cs.y * b)) : fmaf(cs.y, b, cs.x * a));
                 }
             }
             *(half8_t *)dst = v;
@@ -401,10 +403,15 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmArgs p) {
     }
 }
 
+extern "C" int mibc_launch_gemm256(hipStream_t s, const GemmArgs *a);
+
 extern "C" int mibc_launch_gemm_tn(hipStream_t s, const GemmArgs *a) {
     if (a->K % G_BK != 0 || a->Ncols % G_BN != 0 || a->M <= 0) {
         return 1;
     }
+    // large row counts with K = 512 / 1024 / 2048: the persistent 256 x 256 tile kernel (gemm256.hip; same
+    // arithmetic, bit-identical results).  dbg bit 8 (microbenchmark) keeps the 128 x 128 kernel.
+    if (a->dbg == 0 && mibc_launch_gemm256(s, a) == 0) return 0;
     const int ncol = a->Ncols / G_BN;
     const int nrow = (a->M + G_BM - 1) / G_BM;
     dim3 grid(((nrow + 7) / 8) * 8 * ncol);

@@ -31,7 +31,7 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 CASES = {
     "hac": (config.hac_v43, 64, 42, 0xBA5E0, 4),
     "sup43": (config.sup_v43, 32, 42, 0xBA5E1, 4),
-    "sup5": (config.sup_v50, 2, 42, 0xBA5E2, 48),
+    "sup5": (config.sup_v50, 8, 42, 0xBA5E2, 16),
 }
 
 
