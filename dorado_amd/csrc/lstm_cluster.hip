@@ -209,6 +209,82 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
         float16_t acc[4][2];
         half8_t wf[4], xa[2];
         float4_t cpre[2][4];
+        // ---- gates of one pass (gp, time index gt): D row = hidden (r&3) + 8 (r>>2) + 4 lhi, D col = batch row l31.
+        // Cell state: fp32, in a private scratch buffer instead of registers (64 registers per lane buy the fragment
+        // double-buffering of the anti-phase schedule).  Layout [cluster][member][pass][wave][rt][q][lane][4]: every
+        // access is one coalesced 1 KiB wave transaction; 32 KiB per workgroup and pass.
+        auto gates = [&](int gp, int gt, bool gfirst, unsigned long long gvm) __attribute__((always_inline)) {
+            if (gfirst) {   // zero initial state (nn/LSTMStack.cpp:29-41: no h0 / c0 given)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cpre[rt][q] = (float4_t)(0.0f);
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        cpre[rt][q] = *((const float4_t *)(cbuf + ((((((size_t)cl * KCL + j) * 2 + gp) * 8 + wave) * 2 + rt) * 4 + q) * 256) + lane);
+            }
+
+// ---- gates of this pass: D row = hidden (r&3) + 8 (r>>2) + 4 lhi, D col = batch row l31.
+            // Cell state: fp32, in a private scratch buffer instead of registers (64 registers per
+            // lane buy the fragment double-buffering of the anti-phase schedule).  Layout
+            // [cluster][member][pass][wave][rt][q][lane][4]: every access is one coalesced 1 KiB wave
+            // transaction; 32 KiB per workgroup and pass.
+            const int hcol = j * 128 + gp * 64 + hg * 32;
+            const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)(Xout + ((size_t)gt * N + n0 + rgw * 64) * C + hcol), 0, 64 * C * 2, 0x00020000);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const bool rowon = !MASKED || ((gvm >> (rt * 32 + l31)) & 1ull);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    half4_t hv;
+                    float4_t cn;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = q * 4 + e;
+                        float c, hval;
+                        if (DBG & 1) {
+                            c = cpre[rt][q][e];
+                            hval = 1e-3f * (acc[0][rt][r] + acc[1][rt][r] + acc[2][rt][r] + acc[3][rt][r]);
+                        } else {
+                            const float ig = fast_sigmoid(acc[0][rt][r]);
+                            const float fg = fast_sigmoid(acc[1][rt][r]);
+                            const float gg = fast_tanh(acc[2][rt][r]);
+                            const float og = fast_sigmoid(acc[3][rt][r]);
+                            c = fmaf(fg, cpre[rt][q][e], ig * gg);
+                            hval = og * fast_tanh(c);
+                        }
+                        if (MASKED && !rowon) {
+                            c = 0.0f;
+                            hval = 0.0f;
+                        }
+                        cn[e] = c;
+                        hv[e] = (half_t)hval;
+                    }
+                    *((float4_t *)(cbuf + ((((((size_t)cl * KCL + j) * 2 + gp) * 8 + wave) * 2 + rt) * 4 + q) * 256) + lane) = cn;
+                    *(LDSP(half4_t))(patch + l31 * CL_PATCH_LD + 8 * q + 4 * lhi) = hv;
+                }
+                __builtin_amdgcn_wave_barrier();   // same wave: LDS operations execute in order
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int prow = (lane >> 2) + 16 * i, seg = lane & 3;
+                    const half8_t v = *(LDSP(const half8_t))(patch + prow * CL_PATCH_LD + seg * 8);
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                            __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v), ors,
+                            ((rt * 32 + prow) * C + seg * 8) * 2, 0, 16 /* sc1: write-through */);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        
+        };
+        // pass whose gates group A still owes (it runs them behind L(0) of the NEXT pass, i.e. beside group B's last
+        // M + gates of that pass, which come half a slab later by construction, instead of before them)
+        int g_p = 0, g_t = 0;
+        bool g_first = true, g_pending = false;
+        unsigned long long g_vm = ~0ull;
         if (grpB) {
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // own part of slab 0 (group A reads it after this instance)
             __builtin_amdgcn_s_barrier();
@@ -307,6 +383,7 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
                             issue(kt & 3, w_n + (unsigned)(kt - KS) * (CL_WTILE * 2), x_n + (unsigned)(kt - KS) * (CL_BK * 2),
                                   dma_on && p == 0);
                         }
+                        if (ks == 0 && !grpB && g_pending) gates(g_p, g_t, g_first, g_vm);
                     }
                     // ---------------- B2(g) ----------------
                     if (grpB) {
@@ -342,21 +419,6 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
                             xb[0] = (half8_t)((half_t)0.004f);
                             xb[1] = (half8_t)((half_t)0.005f);
                         }
-                        if (ks == KS - 1) {
-                            // cell state of this pass (private scratch, see below): the latency hides under the MFMAs
-                            if (step == 0) {   // zero initial state (nn/LSTMStack.cpp:29-41: no h0 / c0 given)
-#pragma unroll
-                                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q) cpre[rt][q] = (float4_t)(0.0f);
-                            } else {
-#pragma unroll
-                                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q)
-                                        cpre[rt][q] = *((const float4_t *)(cbuf + ((((((size_t)cl * KCL + j) * 2 + p) * 8 + wave) * 2 + rt) * 4 + q) * 256) + lane);
-                            }
-                        }
                         __builtin_amdgcn_s_setprio(1);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -387,67 +449,24 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
                             }
                         }
                         __builtin_amdgcn_s_setprio(0);
-                        if (ks == KS - 1) {
-                            // ---- gates of this pass: D row = hidden (r&3) + 8 (r>>2) + 4 lhi, D col = batch row l31.
-                            // Cell state: fp32, in a private scratch buffer instead of registers (64 registers per
-                            // lane buy the fragment double-buffering of the anti-phase schedule).  Layout
-                            // [cluster][member][pass][wave][rt][q][lane][4]: every access is one coalesced 1 KiB wave
-                            // transaction; 32 KiB per workgroup and pass.
-                            const int hcol = j * 128 + p * 64 + hg * 32;
-                            const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
-                                    (void *)(Xout + ((size_t)t * N + n0 + rgw * 64) * C + hcol), 0, 64 * C * 2, 0x00020000);
-#pragma unroll
-                            for (int rt = 0; rt < 2; ++rt) {
-                                const bool rowon = !MASKED || ((vm >> (rt * 32 + l31)) & 1ull);
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    half4_t hv;
-                                    float4_t cn;
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        const int r = q * 4 + e;
-                                        float c, hval;
-                                        if (DBG & 1) {
-                                            c = cpre[rt][q][e];
-                                            hval = 1e-3f * (acc[0][rt][r] + acc[1][rt][r] + acc[2][rt][r] + acc[3][rt][r]);
-                                        } else {
-                                            const float ig = fast_sigmoid(acc[0][rt][r]);
-                                            const float fg = fast_sigmoid(acc[1][rt][r]);
-                                            const float gg = fast_tanh(acc[2][rt][r]);
-                                            const float og = fast_sigmoid(acc[3][rt][r]);
-                                            c = fmaf(fg, cpre[rt][q][e], ig * gg);
-                                            hval = og * fast_tanh(c);
-                                        }
-                                        if (MASKED && !rowon) {
-                                            c = 0.0f;
-                                            hval = 0.0f;
-                                        }
-                                        cn[e] = c;
-                                        hv[e] = (half_t)hval;
-                                    }
-                                    *((float4_t *)(cbuf + ((((((size_t)cl * KCL + j) * 2 + p) * 8 + wave) * 2 + rt) * 4 + q) * 256) + lane) = cn;
-                                    *(LDSP(half4_t))(patch + l31 * CL_PATCH_LD + 8 * q + 4 * lhi) = hv;
-                                }
-                                __builtin_amdgcn_wave_barrier();   // same wave: LDS operations execute in order
-#pragma unroll
-                                for (int i = 0; i < 2; ++i) {
-                                    const int prow = (lane >> 2) + 16 * i, seg = lane & 3;
-                                    const half8_t v = *(LDSP(const half8_t))(patch + prow * CL_PATCH_LD + seg * 8);
-                                    __builtin_amdgcn_raw_buffer_store_b128(
-                                            __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v), ors,
-                                            ((rt * 32 + prow) * C + seg * 8) * 2, 0, 16 /* sc1: write-through */);
-                                }
-                                __builtin_amdgcn_wave_barrier();
-                            }
-                        }
+                        // group B: gates right behind its last MFMAs of the pass
+                        if (ks == KS - 1 && grpB) gates(p, t, step == 0, vm);
                     }
                 });
+                g_p = p;
+                g_t = t;
+                g_first = (step == 0);
+                g_vm = vm;
+                g_pending = true;
             }
             // next step: x advances, h_{step} is this step's output rows
             h_cur = (step == 0) ? o_first : (unsigned long long)((long long)h_cur + dstep);
             x_cur = x_next;
         }
-        if (!grpB) __builtin_amdgcn_s_barrier();
+        if (!grpB) {
+            gates(g_p, g_t, g_first, g_vm);   // group A's last pass
+            __builtin_amdgcn_s_barrier();
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
