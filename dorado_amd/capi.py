@@ -50,6 +50,7 @@ EXPORTS = [
     "mibc_sync", "mibc_time_forward", "mibc_get_stage_ms", "mibc_set_profile", "mibc_debug_tap",
     "mibc_forward_i16", "mibc_call_device_i16", "mibc_call_i16", "mibc_scaler_stats", "mibc_scale_reads",
     "mibc_svb16_decode", "mibc_forward_var", "mibc_call_device_var", "mibc_call_var",
+    "mibc_call_async", "mibc_call_wait", "mibc_call_poll",
 ]
 
 SCALE_QUANTILE = 0
@@ -124,6 +125,10 @@ def lib():
                                            C.POINTER(DecodeOptsC), C.c_void_p]
         L.mibc_call_var.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.POINTER(DecodeOptsC), C.c_void_p]
+        L.mibc_call_async.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.POINTER(DecodeOptsC), C.c_void_p]
+        L.mibc_call_wait.argtypes = [C.c_void_p, C.c_int]
+        L.mibc_call_poll.argtypes = [C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -288,6 +293,41 @@ class Engine:
         self._check(lib().mibc_call(self._h, x.ctypes.data, n, t_in, C.byref(self.opts),
                                     out.ctypes.data), "mibc_call")
         return unpack_planes(out)
+
+    def call_two_slots(self, batches):
+        """Several host batches through the two-phase entry points (mibc_call_async / mibc_call_wait), two in
+        flight, pinned buffers.  Returns the decoded chunks per batch."""
+        L = lib()
+        xs = [np.ascontiguousarray(b, np.float16) for b in batches]
+        n, t_in = xs[0].shape
+        t = self.output_steps(t_in)
+        self.reserve(n, t_in)
+        pin_in = [L.mibc_host_alloc(n * t_in * 2) for _ in range(2)]
+        pin_out = [L.mibc_host_alloc(3 * n * t) for _ in range(2)]
+        res = [None] * len(xs)
+        try:
+            def submit(i):
+                s = i & 1
+                C.memmove(pin_in[s], xs[i].ctypes.data, xs[i].nbytes)
+                self._check(L.mibc_call_async(self._h, s, pin_in[s], None, n, t_in, C.byref(self.opts), pin_out[s]),
+                            "mibc_call_async")
+
+            def collect(i):
+                s = i & 1
+                self._check(L.mibc_call_wait(self._h, s), "mibc_call_wait")
+                out = np.frombuffer((C.c_int8 * (3 * n * t)).from_address(pin_out[s]), np.int8).reshape(3, n, t).copy()
+                res[i] = unpack_planes(out)
+
+            for i in range(len(xs)):
+                if i >= 2:
+                    collect(i - 2)
+                submit(i)
+            for i in range(max(0, len(xs) - 2), len(xs)):
+                collect(i)
+        finally:
+            for p in pin_in + pin_out:
+                L.mibc_host_free(p)
+        return res
 
     # -- f1: ScalerNode on the device (raw int16 in)
     def call_i16(self, x_i16: np.ndarray, shift_scale: np.ndarray):

@@ -132,6 +132,17 @@ struct mibc_engine {
     uint16_t *path_state = nullptr;
     int8_t *out3 = nullptr;
     size_t ws_bytes = 0;
+    // two-phase calls (mibc_call_async / mibc_call_wait): per-slot device staging + copy streams, so that the
+    // H2D copy of batch i+1 and the D2H copy of batch i-1 run beside the kernels of batch i
+    struct AsyncSlot {
+        half_t *in = nullptr;
+        float *ss = nullptr;
+        int8_t *out3 = nullptr;
+        hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
+        size_t in_bytes = 0, out_bytes = 0;
+        int n = 0;
+    } aslot[2];
+    hipStream_t s_in = nullptr, s_out = nullptr;
     // last call
     half_t *lstm_out = nullptr;
     int last_N = 0, last_T = 0, last_T_in = 0;

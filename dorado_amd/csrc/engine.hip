@@ -343,6 +343,16 @@ extern "C" void mibc_destroy(mibc_engine *e) {
     for (auto p : e->lstm_w16)
         if (p) (void)hipFree(p);
     for (auto p : e->lstm_bn) (void)hipFree(p);
+    for (auto &a : e->aslot) {
+        if (a.in) (void)hipFree(a.in);
+        if (a.ss) (void)hipFree(a.ss);
+        if (a.out3) (void)hipFree(a.out3);
+        if (a.ev_in) (void)hipEventDestroy(a.ev_in);
+        if (a.ev_done) (void)hipEventDestroy(a.ev_done);
+        if (a.ev_out) (void)hipEventDestroy(a.ev_out);
+    }
+    if (e->s_in) (void)hipStreamDestroy(e->s_in);
+    if (e->s_out) (void)hipStreamDestroy(e->s_out);
     for (auto p : e->lstm_wcl) (void)hipFree(p);
     for (auto p : e->lstm_bcl) (void)hipFree(p);
     if (e->lstm_zero) (void)hipFree(e->lstm_zero);
@@ -756,6 +766,75 @@ extern "C" int mibc_call(mibc_engine *e, const uint16_t *in_host, int N, int T_i
     if (rc != MIBC_OK) return rc;
     HIP_OK(e, hipMemcpyAsync(out_host, e->out3, (size_t)3 * N * T, hipMemcpyDeviceToHost, e->stream));
     HIP_OK(e, hipStreamSynchronize(e->stream));
+    return check_cluster_error(e);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two-phase calls: copies on their own streams, ordered with the engine's stream by events.
+// ---------------------------------------------------------------------------------------------
+static int async_prepare(mibc_engine *e, int slot, int N, int T_in) {
+    if (!e->s_in) {
+        HIP_OK(e, hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
+        HIP_OK(e, hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
+    }
+    auto &a = e->aslot[slot];
+    if (!a.ev_in) {
+        HIP_OK(e, hipEventCreateWithFlags(&a.ev_in, hipEventDisableTiming));
+        HIP_OK(e, hipEventCreateWithFlags(&a.ev_done, hipEventDisableTiming));
+        HIP_OK(e, hipEventCreateWithFlags(&a.ev_out, hipEventDisableTiming));
+    }
+    const size_t T = (size_t)mibc_output_steps(e, T_in);
+    const size_t inb = (size_t)N * T_in * 2, outb = (size_t)3 * N * T;
+    if (a.in_bytes < inb || a.out_bytes < outb) {
+        HIP_OK(e, hipStreamSynchronize(e->stream));
+        if (a.in) (void)hipFree(a.in);
+        if (a.ss) (void)hipFree(a.ss);
+        if (a.out3) (void)hipFree(a.out3);
+        a.in = nullptr; a.ss = nullptr; a.out3 = nullptr; a.in_bytes = a.out_bytes = 0;
+        HIP_OK(e, hipMalloc((void **)&a.in, inb));
+        HIP_OK(e, hipMalloc((void **)&a.ss, (size_t)N * 2 * sizeof(float)));
+        HIP_OK(e, hipMalloc((void **)&a.out3, outb));
+        a.in_bytes = inb;
+        a.out_bytes = outb;
+    }
+    return MIBC_OK;
+}
+
+extern "C" int mibc_call_async(mibc_engine *e, int slot, const void *in_host, const float *shift_scale_host, int N,
+                               int T_in, const mibc_decode_opts *o, int8_t *out_host) {
+    if (!e || !in_host || !out_host || !o || slot < 0 || slot > 1) return MIBC_ERR_ARG;
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    rc = async_prepare(e, slot, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    auto &a = e->aslot[slot];
+    const int T = mibc_output_steps(e, T_in);
+    HIP_OK(e, hipMemcpyAsync(a.in, in_host, (size_t)N * T_in * 2, hipMemcpyHostToDevice, e->s_in));
+    if (shift_scale_host)
+        HIP_OK(e, hipMemcpyAsync(a.ss, shift_scale_host, (size_t)N * 2 * sizeof(float), hipMemcpyHostToDevice, e->s_in));
+    HIP_OK(e, hipEventRecord(a.ev_in, e->s_in));
+    HIP_OK(e, hipStreamWaitEvent(e->stream, a.ev_in, 0));
+    rc = shift_scale_host ? mibc_call_device_i16(e, (const int16_t *)a.in, a.ss, N, T_in, o, a.out3)
+                          : mibc_call_device(e, (const uint16_t *)a.in, N, T_in, o, a.out3);
+    if (rc != MIBC_OK) return rc;
+    HIP_OK(e, hipEventRecord(a.ev_done, e->stream));
+    HIP_OK(e, hipStreamWaitEvent(e->s_out, a.ev_done, 0));
+    HIP_OK(e, hipMemcpyAsync(out_host, a.out3, (size_t)3 * N * T, hipMemcpyDeviceToHost, e->s_out));
+    HIP_OK(e, hipEventRecord(a.ev_out, e->s_out));
+    a.n = N;
+    return MIBC_OK;
+}
+
+extern "C" int mibc_call_poll(mibc_engine *e, int slot) {
+    if (!e || slot < 0 || slot > 1 || !e->aslot[slot].ev_out) return 1;
+    return hipEventQuery(e->aslot[slot].ev_out) == hipErrorNotReady ? 0 : 1;
+}
+
+extern "C" int mibc_call_wait(mibc_engine *e, int slot) {
+    if (!e || slot < 0 || slot > 1) return MIBC_ERR_ARG;
+    if (!e->aslot[slot].ev_out) return fail(e, MIBC_ERR_ARG, "mibc_call_wait: nothing was submitted on this slot");
+    HIP_OK(e, hipSetDevice(e->device));
+    HIP_OK(e, hipEventSynchronize(e->aslot[slot].ev_out));
     return check_cluster_error(e);
 }
 

@@ -314,41 +314,98 @@ std::vector<std::pair<float, float>> HipCaller::scaler_stats(
 }
 
 void HipCaller::gpu_thread_fn() {
-    while (true) {
+    // Two batches in flight (the reference gets the same overlap from its runners' own streams,
+    // CudaCaller.cpp:645-719): a task is submitted to the engine as soon as one of the two slots is free — its H2D
+    // copy runs beside the kernels of the batch in front of it, and the D2H copy + the runner's string slicing of
+    // a finished batch run beside the kernels of the next one.  Completion is reported in submission order.
+    struct InFlight {
         std::shared_ptr<NNTask> task;
-        {
-            std::unique_lock<std::mutex> lk(m_mutex);
-            m_cv.wait(lk, [&] { return m_terminate.load() || !m_queue.empty(); });
-            if (m_queue.empty()) return;  // terminate and drained
-            task = m_queue.back();
-            m_queue.pop_back();
-        }
-        const auto t0 = std::chrono::steady_clock::now();
-        // the engine decodes all batch rows (stale rows included), the node uses the first n
-        // (CudaCaller.cpp:269-270, BasecallerNode.cpp:185-189)
+        int slot;
         int rc;
-        {
-            std::lock_guard<std::mutex> elk(m_engine_mutex);
-            auto run = [&]() {
-                if (task->var)
-                    return mibc_call_var(m_engine, task->in, nullptr, m_batch_size, m_chunk_size, task->var->data(),
-                                         int(task->var->size()), &m_opts, task->out);
-                return task->ss ? mibc_call_i16(m_engine, reinterpret_cast<const int16_t *>(task->in), task->ss,
-                                                m_batch_size, m_chunk_size, &m_opts, task->out)
-                                : mibc_call(m_engine, task->in, m_batch_size, m_chunk_size, &m_opts, task->out);
-            };
-            rc = run();
-            if (rc != MIBC_OK) rc = run();  // retry once (:698-704)
-        }
+        std::chrono::steady_clock::time_point t0;
+    };
+    std::deque<InFlight> inflight;
+    bool slot_busy[2] = {false, false};
+    auto finish = [&](InFlight &f, int rc) {
         m_model_decode_us += std::chrono::duration_cast<std::chrono::microseconds>(
-                                     std::chrono::steady_clock::now() - t0).count();
+                                     std::chrono::steady_clock::now() - f.t0).count();
         ++m_batches;
         {
-            std::lock_guard<std::mutex> lk(task->mut);
-            task->rc = rc;
-            task->done = true;
+            std::lock_guard<std::mutex> lk(f.task->mut);
+            f.task->rc = rc;
+            f.task->done = true;
         }
-        task->cv.notify_one();
+        f.task->cv.notify_one();
+    };
+    auto run_sync = [&](NNTask &t) {   // whole call on the engine's stream (variable chunks; retries)
+        std::lock_guard<std::mutex> elk(m_engine_mutex);
+        if (t.var)
+            return mibc_call_var(m_engine, t.in, nullptr, m_batch_size, m_chunk_size, t.var->data(), int(t.var->size()),
+                                 &m_opts, t.out);
+        return t.ss ? mibc_call_i16(m_engine, reinterpret_cast<const int16_t *>(t.in), t.ss, m_batch_size, m_chunk_size,
+                                    &m_opts, t.out)
+                    : mibc_call(m_engine, t.in, m_batch_size, m_chunk_size, &m_opts, t.out);
+    };
+    while (true) {
+        // 1. take new tasks while a slot is free
+        {
+            std::unique_lock<std::mutex> lk(m_mutex);
+            if (inflight.empty()) m_cv.wait(lk, [&] { return m_terminate.load() || !m_queue.empty(); });
+            if (m_queue.empty() && inflight.empty()) return;   // terminate and drained
+            while (!m_queue.empty() && (!slot_busy[0] || !slot_busy[1])) {
+                std::shared_ptr<NNTask> task = m_queue.back();
+                if (task->var && !inflight.empty()) break;       // synchronous path: drain first
+                m_queue.pop_back();
+                lk.unlock();
+                InFlight f{task, -1, MIBC_OK, std::chrono::steady_clock::now()};
+                // the engine decodes all batch rows (stale rows included), the node uses the first n
+                // (CudaCaller.cpp:269-270, BasecallerNode.cpp:185-189)
+                if (task->var) {
+                    int rc = run_sync(*task);
+                    if (rc != MIBC_OK) rc = run_sync(*task);     // retry once (:698-704)
+                    finish(f, rc);
+                } else {
+                    f.slot = slot_busy[0] ? 1 : 0;
+                    {
+                        std::lock_guard<std::mutex> elk(m_engine_mutex);
+                        f.rc = mibc_call_async(m_engine, f.slot, task->in, task->ss, m_batch_size, m_chunk_size, &m_opts,
+                                               task->out);
+                    }
+                    slot_busy[f.slot] = true;
+                    inflight.push_back(std::move(f));
+                }
+                lk.lock();
+            }
+        }
+        if (inflight.empty()) continue;
+        // 2. oldest batch: done?  (poll, so that a task arriving meanwhile still gets its copy started)
+        InFlight &f = inflight.front();
+        bool ready = (f.rc != MIBC_OK);
+        if (!ready) {
+            std::lock_guard<std::mutex> elk(m_engine_mutex);
+            ready = mibc_call_poll(m_engine, f.slot) != 0;
+        }
+        if (!ready) {
+            std::unique_lock<std::mutex> lk(m_mutex);
+            const bool can_take = !slot_busy[0] || !slot_busy[1];
+            m_cv.wait_for(lk, std::chrono::microseconds(100), [&] { return can_take && !m_queue.empty(); });
+            continue;
+        }
+        int rc = f.rc;
+        if (rc == MIBC_OK) {
+            std::lock_guard<std::mutex> elk(m_engine_mutex);
+            rc = mibc_call_wait(m_engine, f.slot);
+        }
+        if (rc != MIBC_OK) {   // retry once, synchronously (:698-704) — after the other slot has drained
+            if (inflight.size() > 1) {
+                std::lock_guard<std::mutex> elk(m_engine_mutex);
+                (void)mibc_call_wait(m_engine, inflight[1].slot);
+            }
+            rc = run_sync(*f.task);
+        }
+        slot_busy[f.slot] = false;
+        finish(f, rc);
+        inflight.pop_front();
     }
 }
 
@@ -574,6 +631,15 @@ std::vector<CalledRead> SimplexBasecaller::basecall(const std::vector<std::vecto
     return basecall_views(v);
 }
 
+size_t SimplexBasecaller::basecall_repeated(const uint16_t *data, size_t n_distinct, size_t read_len, size_t n_reads) {
+    std::vector<ReadView> v;
+    v.reserve(n_reads);
+    for (size_t i = 0; i < n_reads; ++i) v.push_back({data + (i % n_distinct) * read_len, read_len, false, 0.0f, 1.0f});
+    size_t bases = 0;
+    for (const auto &r : basecall_views(v)) bases += r.seq.size();
+    return bases;
+}
+
 std::vector<CalledRead> SimplexBasecaller::basecall_raw(const std::vector<RawRead> &reads) {
     std::vector<ReadView> v;
     for (const auto &r : reads)
@@ -599,6 +665,20 @@ std::vector<CalledRead> SimplexBasecaller::basecall_views(const std::vector<Read
         }
     }
     std::mutex qmut;
+    // a read is stitched by the worker that delivers its last chunk (the reference's stitch threads run beside the
+    // basecalling workers too: BasecallerNode.cpp:205-287, 535-548), not in a serial pass at the end
+    std::vector<std::atomic<int>> remaining(reads.size());
+    for (size_t r = 0; r < reads.size(); ++r) remaining[r].store(int(chunks[r].size()));
+    auto stitch_read = [&](size_t r) {
+        std::vector<const Chunk *> cc;
+        for (auto &c : chunks[r]) cc.push_back(&c);
+        StitchedRead st = stitch_chunks(cc, reads[r].n, m_stride);
+        out[r].seq = std::move(st.seq);
+        out[r].qstring = std::move(st.qstring);
+        out[r].moves = std::move(st.moves);
+        std::vector<Chunk>().swap(chunks[r]);
+        m_samples_processed += int64_t(reads[r].n);
+    };
     auto worker = [&](ModelRunnerBase *runner, std::atomic<bool> &failed) {
         const size_t batch = runner->batch_size();
         std::vector<uint16_t> padded(chunk_size);
@@ -637,19 +717,11 @@ std::vector<CalledRead> SimplexBasecaller::basecall_views(const std::vector<Read
                 c.seq = std::move(decoded[k].sequence);
                 c.qstring = std::move(decoded[k].qstring);
                 c.moves = std::move(decoded[k].moves);
+                if (remaining[mine[k].read].fetch_sub(1) == 1) stitch_read(mine[k].read);
             }
         }
     };
     run_workers(m_runners, worker);
-    for (size_t r = 0; r < reads.size(); ++r) {
-        std::vector<const Chunk *> cc;
-        for (auto &c : chunks[r]) cc.push_back(&c);
-        StitchedRead s = stitch_chunks(cc, reads[r].n, m_stride);
-        out[r].seq = std::move(s.seq);
-        out[r].qstring = std::move(s.qstring);
-        out[r].moves = std::move(s.moves);
-        m_samples_processed += int64_t(reads[r].n);
-    }
     return out;
 }
 
@@ -870,6 +942,32 @@ int mibch_basecall_raw_reads(const mibc_model_desc *desc, const float *const *we
         auto called = node->basecall_raw(reads);
         write_outputs(called, *node, {seq_out, qstr_out, seq_len_out, moves_out, moves_len_out, offsets_out,
                                       n_offsets_out, stats4});
+        return 0;
+    } catch (const std::exception &e) {
+        g_herr = e.what();
+        return -1;
+    }
+}
+
+// Throughput of the whole host path (bench.py --through-host): create_basecall_runners + SimplexBasecaller on
+// synthetic f16 reads held in host memory: chunking, pinned batch assembly, H2D, network + decode, D2H, string
+// slicing and stitching, `num_runners` runners per device with two batches in flight.  n_warm reads are called first
+// (untimed), then n_reads are timed.  out4 = {samples/s, seconds, batches, bases}.
+int mibch_bench_through_host(const mibc_model_desc *desc, const float *const *weights, int n_weights,
+                             const char *device_string, int num_runners, int chunk_size, int overlap, int batch_size,
+                             const mibc_decode_opts *opts, const uint16_t *signals, int n_distinct, int64_t read_len,
+                             int64_t n_warm, int64_t n_reads, double *out4) {
+    try {
+        auto node = make_node(desc, weights, n_weights, device_string, num_runners, chunk_size, overlap, batch_size, opts);
+        if (n_warm > 0) (void)node->basecall_repeated(signals, size_t(n_distinct), size_t(read_len), size_t(n_warm));
+        const double b0 = node->sample_stats()["batches_called"];
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t bases = node->basecall_repeated(signals, size_t(n_distinct), size_t(read_len), size_t(n_reads));
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        out4[0] = double(n_reads) * double(read_len) / sec;
+        out4[1] = sec;
+        out4[2] = node->sample_stats()["batches_called"] - b0;
+        out4[3] = double(bases);
         return 0;
     } catch (const std::exception &e) {
         g_herr = e.what();

@@ -256,6 +256,9 @@ public:
     // generate_variable_chunks, each chunk is topped up to a stride multiple by repeating its head, chunks of any
     // length share batch rows (2-step gaps) and go through mibc_call_var.  f16 reads.
     std::vector<CalledRead> basecall_variable(const std::vector<std::vector<uint16_t>> &reads_f16);
+    // Measurement helper: n_reads reads of read_len samples each, read i = data + (i % n_distinct) * read_len (f16);
+    // same path as basecall(); returns the total number of called bases.
+    size_t basecall_repeated(const uint16_t *data, size_t n_distinct, size_t read_len, size_t n_reads);
     NamedStats sample_stats() const;
 
 private:

@@ -129,6 +129,26 @@ def basecall_reads(cfg: ModelConfig, weights, reads_f16, device="hip:0", num_run
                  "batches_called": stats[2], "partial_batches_called": stats[3]}
 
 
+def bench_through_host(cfg: ModelConfig, weights, reads_f16, n_warm, n_reads, device="hip:0", num_runners=2,
+                       batch_size=0, beam_width=32):
+    """Throughput of the C++ host path (SimplexBasecaller, `num_runners` runners, two batches in flight) on synthetic
+    reads: reads_f16 [n_distinct, read_len] f16 are cycled n_reads times.  Returns dict(samples_per_s, seconds,
+    batches, bases)."""
+    L = lib()
+    d = cfg.to_desc()
+    ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+    arr = (C.POINTER(C.c_float) * len(ws))(*[w.ctypes.data_as(C.POINTER(C.c_float)) for w in ws])
+    opts = capi.DecodeOptsC(beam_width, 100.0, 2.0, cfg.qbias, cfg.qscale)
+    sig = np.ascontiguousarray(reads_f16, np.float16)
+    out = (C.c_double * 4)()
+    rc = L.mibch_bench_through_host(C.byref(d), arr, len(ws), device.encode(), num_runners, cfg.chunk_size, cfg.overlap,
+                                    batch_size, C.byref(opts), sig.ctypes.data_as(C.c_void_p), int(sig.shape[0]),
+                                    C.c_int64(sig.shape[1]), C.c_int64(n_warm), C.c_int64(n_reads), out)
+    if rc != 0:
+        raise capi.MibcError(L.mibch_last_error().decode())
+    return {"samples_per_s": out[0], "seconds": out[1], "batches": out[2], "bases": out[3]}
+
+
 # ---------------------------------------------------------------- ScalerNode host half (SURVEY.md 8f-1)
 def pa_read_scaling(standardise, mean, stdev, scaling, offset, open_pore_level=float("nan"),
                     flow_cell_product_code=""):

@@ -117,6 +117,16 @@ int mibc_call(mibc_engine *e, const uint16_t *in_host, int N, int T_in,
               int8_t *out_host); /* H2D + forward + decode + D2H, synchronous
                                     (CudaCaller::call_chunks, CudaCaller.cpp:224-271) */
 int mibc_sync(mibc_engine *e);
+/* Two-phase form of mibc_call (the overlap CudaCaller gets from its runners' own streams, CudaCaller.cpp:645-719 +
+ * decode/CUDADecoder.h:13-15): mibc_call_async enqueues H2D (copy stream) -> network + decode (engine stream) ->
+ * D2H (second copy stream) for `slot` (0 or 1) and returns; mibc_call_wait blocks until that slot's output has
+ * arrived in out_host.  Two slots in flight: the copies of one batch run beside the kernels of the other.  A slot
+ * must be waited for before it is submitted again; in_host / out_host must be pinned (mibc_host_alloc) and stay
+ * valid until the wait returns.  shift_scale_host: NULL (in_host holds scaled f16) or float [N][2] (raw int16). */
+int mibc_call_async(mibc_engine *e, int slot, const void *in_host, const float *shift_scale_host, int N, int T_in,
+                    const mibc_decode_opts *opts, int8_t *out_host);
+int mibc_call_wait(mibc_engine *e, int slot);
+int mibc_call_poll(mibc_engine *e, int slot); /* 1 = finished (then call mibc_call_wait), 0 = still running */
 
 /* ---- signal scaling in front of the path (the device side of ScalerNode,
  *      dorado/read_pipeline/nodes/ScalerNode.cpp:144-269) ----

@@ -254,6 +254,21 @@ def test_transformer_model_vs_oracle(name):
     eng.close()
 
 
+def test_two_phase_calls_equal_synchronous_calls():
+    """mibc_call_async / mibc_call_wait with two batches in flight (copies on their own streams beside the other
+    batch's kernels) == mibc_call, batch by batch, byte for byte."""
+    cfg = _cfg(128, 4, 5)
+    ws = synth.make_weights(cfg, seed=45)
+    eng = capi.Engine(cfg, ws)
+    batches = [synth.make_signal(64, 1206, seed=500 + i) for i in range(5)]
+    got = eng.call_two_slots(batches)
+    for b, g in zip(batches, got):
+        want = eng.call(b)
+        for (s1, q1, m1), (s2, q2, m2) in zip(g, want):
+            assert s1 == s2 and q1 == q2 and (m1 == m2).all()
+    eng.close()
+
+
 def test_unsupported_shapes_fail_loudly():
     cfg = _cfg(64, 3, 5)  # C=64 has no kernel
     with pytest.raises(capi.MibcNotSupported):
