@@ -577,23 +577,82 @@ NamedStats HipModelRunner::sample_stats() const {
     return s;
 }
 
+int model_stride(const mibc_model_desc &d) {
+    int stride = 1;
+    for (int i = 0; i < d.n_convs; ++i) stride *= d.conv_stride[i];
+    if (d.tx_d_model > 0 && d.up_scale_factor > 1) stride /= d.up_scale_factor;
+    return stride;
+}
+
+int chunk_size_granularity(const mibc_model_desc &d) {
+    const bool tx = d.tx_d_model > 0;
+    const int stride_inner = model_stride(d) * (tx && d.up_scale_factor > 1 ? d.up_scale_factor : 1);
+    return stride_inner * (tx ? 16 : 1);
+}
+
+std::vector<int> simplex_chunk_sizes(const mibc_model_desc &d, int requested_chunk_size, int overlap) {
+    const int gran = chunk_size_granularity(d);
+    const int min_chunk = (overlap + 1 + gran - 1) / gran * gran;   // utils::pad_to(overlap + 1, granularity)
+    auto norm = [&](int x) { return std::max(min_chunk, (x / gran) * gran); };
+    std::set<int> sizes{norm(requested_chunk_size)};
+    for (float fraction : {0.5f}) sizes.insert(norm(int(float(requested_chunk_size) * fraction)));
+    return std::vector<int>(sizes.rbegin(), sizes.rend());
+}
+
+size_t get_chunk_queue_idx(const std::vector<size_t> &chunk_sizes, size_t read_raw_size) {
+    size_t best_idx = 0;
+    for (size_t i = 1; i < chunk_sizes.size(); ++i) {
+        const size_t best_size = chunk_sizes[best_idx], this_size = chunk_sizes[i];
+        if ((best_size < read_raw_size && best_size < this_size) || (read_raw_size < this_size && this_size < best_size))
+            best_idx = i;
+    }
+    return best_idx;
+}
+
 std::vector<std::vector<RunnerPtr>> create_basecall_runners(const mibc_model_desc &desc,
                                                             const float *const *weights, int n_weights,
                                                             const std::string &device_string, int num_runners,
-                                                            int chunk_size, int batch_size,
+                                                            const std::vector<int> &chunk_sizes, int batch_size,
                                                             const mibc_decode_opts &opts) {
     std::vector<int> ids;
     std::string err;
     if (!try_parse_device_ids(device_string, size_t(mibc_device_count()), ids, err)) throw std::runtime_error(err);
     if (ids.empty()) throw std::runtime_error("no GPU device in '" + device_string + "' (the HIP engine has no CPU fallback)");
+    if (chunk_sizes.empty()) throw std::invalid_argument("create_basecall_runners: no chunk size");
+    // callers of different devices are built concurrently (api/runner_creation.cpp:95-113: one pool thread per device)
+    std::vector<std::vector<std::shared_ptr<HipCaller>>> callers(ids.size());
+    std::vector<std::thread> pool;
+    std::exception_ptr first;
+    std::mutex emut;
+    for (size_t di = 0; di < ids.size(); ++di)
+        pool.emplace_back([&, di] {
+            try {
+                for (int cs : chunk_sizes)
+                    callers[di].push_back(std::make_shared<HipCaller>(desc, weights, n_weights, ids[di], cs, batch_size, opts));
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(emut);
+                if (!first) first = std::current_exception();
+            }
+        });
+    for (auto &t : pool) t.join();
+    if (first) std::rethrow_exception(first);
     std::vector<std::vector<RunnerPtr>> out;
-    for (int id : ids) {
-        auto caller = std::make_shared<HipCaller>(desc, weights, n_weights, id, chunk_size, batch_size, opts);
+    for (size_t di = 0; di < ids.size(); ++di) {
         std::vector<RunnerPtr> rs;
-        for (int r = 0; r < num_runners; ++r) rs.push_back(std::make_unique<HipModelRunner>(caller));
+        for (int r = 0; r < num_runners; ++r)
+            for (auto &caller : callers[di]) rs.push_back(std::make_unique<HipModelRunner>(caller));
         out.push_back(std::move(rs));
     }
     return out;
+}
+
+std::vector<std::vector<RunnerPtr>> create_basecall_runners(const mibc_model_desc &desc,
+                                                            const float *const *weights, int n_weights,
+                                                            const std::string &device_string, int num_runners,
+                                                            int chunk_size, int batch_size,
+                                                            const mibc_decode_opts &opts) {
+    return create_basecall_runners(desc, weights, n_weights, device_string, num_runners, std::vector<int>{chunk_size},
+                                   batch_size, opts);
 }
 
 // ------------------------------------------------------------------ SimplexBasecaller
@@ -623,7 +682,14 @@ void run_workers(std::vector<RunnerPtr> &runners, Worker &&worker) {
 }  // namespace
 
 SimplexBasecaller::SimplexBasecaller(std::vector<RunnerPtr> runners, int overlap, int model_stride)
-        : m_runners(std::move(runners)), m_overlap(overlap), m_stride(model_stride) {}
+        : m_runners(std::move(runners)), m_overlap(overlap), m_stride(model_stride) {
+    // the runner list is [devices][runners][chunk_sizes]: the chunk sizes repeat, so collect until the first one
+    // shows up again (BasecallerNode.cpp:494-501)
+    for (auto &r : m_runners) {
+        if (!m_chunk_sizes.empty() && r->chunk_size() == m_chunk_sizes[0]) break;
+        m_chunk_sizes.push_back(r->chunk_size());
+    }
+}
 
 std::vector<CalledRead> SimplexBasecaller::basecall(const std::vector<std::vector<uint16_t>> &reads) {
     std::vector<ReadView> v;
@@ -651,17 +717,20 @@ std::vector<CalledRead> SimplexBasecaller::basecall_views(const std::vector<Read
     struct Work {
         size_t read, idx, offset;
     };
-    const size_t chunk_size = m_runners.at(0)->chunk_size();
+    const size_t nq = m_chunk_sizes.size();
     std::vector<CalledRead> out(reads.size());
     std::vector<std::vector<Chunk>> chunks(reads.size());
-    std::deque<Work> queue;
+    std::vector<std::deque<Work>> queues(nq);   // one chunk queue per chunk size (BasecallerNode.cpp:515-522)
     for (size_t r = 0; r < reads.size(); ++r) {
-        out[r].chunk_offsets = generate_chunks(reads[r].n, chunk_size, size_t(m_stride), size_t(m_overlap));
+        // a read goes to the queue with the smallest chunk size that fits it whole, else the largest (:81-94, :125)
+        const size_t qi = get_chunk_queue_idx(m_chunk_sizes, reads[r].n);
+        const size_t cs = m_chunk_sizes[qi];
+        out[r].chunk_offsets = generate_chunks(reads[r].n, cs, size_t(m_stride), size_t(m_overlap));
         chunks[r].resize(out[r].chunk_offsets.size());
         for (size_t i = 0; i < out[r].chunk_offsets.size(); ++i) {
             chunks[r][i].input_offset = out[r].chunk_offsets[i];
-            chunks[r][i].raw_chunk_size = chunk_size;
-            queue.push_back({r, i, out[r].chunk_offsets[i]});
+            chunks[r][i].raw_chunk_size = cs;
+            queues[qi].push_back({r, i, out[r].chunk_offsets[i]});
         }
     }
     std::mutex qmut;
@@ -681,6 +750,12 @@ std::vector<CalledRead> SimplexBasecaller::basecall_views(const std::vector<Read
     };
     auto worker = [&](ModelRunnerBase *runner, std::atomic<bool> &failed) {
         const size_t batch = runner->batch_size();
+        const size_t chunk_size = runner->chunk_size();
+        // a worker serves the queue of its runner's chunk size (BasecallerNode.cpp:300-301: worker_id % num queues,
+        // which is the same thing for a [devices][runners][chunk_sizes] runner list)
+        size_t qi = 0;
+        while (qi + 1 < nq && m_chunk_sizes[qi] != chunk_size) ++qi;
+        std::deque<Work> &queue = queues[qi];
         std::vector<uint16_t> padded(chunk_size);
         while (!failed.load()) {
             std::vector<Work> mine;
@@ -817,15 +892,6 @@ NamedStats SimplexBasecaller::sample_stats() const {  // BasecallerNode.cpp:597-
 using namespace dorado_amd::host;
 static thread_local std::string g_herr;
 
-// Samples per output step: the product of the conv strides, divided by the upsample factor of the
-// transformer models (config/BasecallModelConfig.cpp:447-454: sup@v5 = 1*1*3*2*2 / 2 = 6).
-static int model_stride_of(const mibc_model_desc &d) {
-    int stride = 1;
-    for (int i = 0; i < d.n_convs; ++i) stride *= d.conv_stride[i];
-    if (d.tx_d_model > 0 && d.up_scale_factor > 1) stride /= d.up_scale_factor;
-    return stride;
-}
-
 namespace {
 struct ReadOutputs {
     char *seq_out, *qstr_out;
@@ -856,13 +922,16 @@ void write_outputs(const std::vector<CalledRead> &called, SimplexBasecaller &nod
 }
 std::unique_ptr<SimplexBasecaller> make_node(const mibc_model_desc *desc, const float *const *weights, int n_weights,
                                              const char *device_string, int num_runners, int chunk_size, int overlap,
-                                             int batch_size, const mibc_decode_opts *opts) {
-    auto per_dev = create_basecall_runners(*desc, weights, n_weights, device_string, num_runners, chunk_size,
-                                           batch_size, *opts);
+                                             int batch_size, const mibc_decode_opts *opts, bool extra_chunk_sizes = false) {
+    // extra_chunk_sizes: the reference's high-throughput simplex set {chunk, 0.5 x chunk} (CudaCaller.cpp:388-413)
+    const std::vector<int> sizes = extra_chunk_sizes ? simplex_chunk_sizes(*desc, chunk_size, overlap)
+                                                     : std::vector<int>{chunk_size};
+    auto per_dev = create_basecall_runners(*desc, weights, n_weights, device_string, num_runners, sizes, batch_size,
+                                           *opts);
     std::vector<RunnerPtr> flat;
     for (auto &d : per_dev)
         for (auto &r : d) flat.push_back(std::move(r));
-    return std::make_unique<SimplexBasecaller>(std::move(flat), overlap, model_stride_of(*desc));
+    return std::make_unique<SimplexBasecaller>(std::move(flat), overlap, model_stride(*desc));
 }
 }  // namespace
 
@@ -974,6 +1043,46 @@ int mibch_bench_through_host(const mibc_model_desc *desc, const float *const *we
         return -1;
     }
 }
+
+// mibch_basecall_reads with the reference's extra 0.5x chunk-size queue; sizes_out (up to 4) gets the chunk sizes.
+int mibch_basecall_reads_two_queues(const mibc_model_desc *desc, const float *const *weights, int n_weights,
+                                    const char *device_string, int num_runners, int chunk_size, int overlap,
+                                    int batch_size, const mibc_decode_opts *opts, const uint16_t *signals,
+                                    const int64_t *read_len, int n_reads, char *seq_out, char *qstr_out,
+                                    int64_t *seq_len_out, uint8_t *moves_out, int64_t *moves_len_out,
+                                    int64_t *offsets_out, int64_t *n_offsets_out, double *stats4, int *sizes_out) {
+    try {
+        auto node = make_node(desc, weights, n_weights, device_string, num_runners, chunk_size, overlap, batch_size, opts,
+                              true);
+        const auto sizes = simplex_chunk_sizes(*desc, chunk_size, overlap);
+        for (size_t i = 0; i < 4; ++i) sizes_out[i] = i < sizes.size() ? sizes[i] : 0;
+        std::vector<std::vector<uint16_t>> reads(static_cast<size_t>(n_reads));
+        size_t pos = 0;
+        for (int r = 0; r < n_reads; ++r) {
+            reads[size_t(r)].assign(signals + pos, signals + pos + read_len[r]);
+            pos += size_t(read_len[r]);
+        }
+        auto called = node->basecall(reads);
+        write_outputs(called, *node, {seq_out, qstr_out, seq_len_out, moves_out, moves_len_out, offsets_out,
+                                      n_offsets_out, stats4});
+        return 0;
+    } catch (const std::exception &e) {
+        g_herr = e.what();
+        return -1;
+    }
+}
+
+// CPU-only helpers for the tests
+int mibch_simplex_chunk_sizes(const mibc_model_desc *desc, int requested, int overlap, int *out, int max) {
+    const auto v = simplex_chunk_sizes(*desc, requested, overlap);
+    for (size_t i = 0; i < v.size() && int(i) < max; ++i) out[i] = v[i];
+    return int(v.size());
+}
+int mibch_get_chunk_queue_idx(const uint64_t *sizes, int n, uint64_t read_raw_size) {
+    std::vector<size_t> v(sizes, sizes + n);
+    return int(get_chunk_queue_idx(v, size_t(read_raw_size)));
+}
+int mibch_model_stride(const mibc_model_desc *desc) { return model_stride(*desc); }
 
 long mibch_generate_variable_chunks(uint64_t num_samples, uint64_t chunk_size, uint64_t stride, uint64_t overlap,
                                     uint64_t *out_pairs, long max_out) {

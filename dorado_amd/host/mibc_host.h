@@ -224,8 +224,29 @@ private:
     std::atomic<int64_t> m_batches{0};
 };
 
-// [device][runner]; one caller per device, num_runners runners sharing it
-// (api/runner_creation.cpp:85-124; utils/include/utils/parameters.h:11 num_runners = 2).
+// Samples per output step: product of the conv strides, divided by the upsample factor of the transformer models
+// (config/BasecallModelConfig.cpp:447-454); chunk granularity = stride_inner * 16 for transformer models
+// (config/include/config/BasecallModelConfig.h:152-159).
+int model_stride(const mibc_model_desc &desc);
+int chunk_size_granularity(const mibc_model_desc &desc);
+// The batch dimensions CudaCaller builds for high-throughput simplex calling (CudaCaller.cpp:382-413): the
+// requested chunk size and 0.5x of it, each rounded down to the chunk granularity and kept above the overlap;
+// largest first, duplicates removed.
+std::vector<int> simplex_chunk_sizes(const mibc_model_desc &desc, int requested_chunk_size, int overlap);
+// BasecallerNode::get_chunk_queue_idx (BasecallerNode.cpp:81-94): the queue with the smallest chunk size that
+// fits the whole read, else the one with the largest chunk size.
+size_t get_chunk_queue_idx(const std::vector<size_t> &chunk_sizes, size_t read_raw_size);
+
+// [device][runner][chunk_size] (inner vector: runner-major, chunk sizes in the order given) — the order
+// api::create_basecall_runners returns and BasecallerNode relies on (api/runner_creation.cpp:115-123,
+// BasecallerNode.cpp:494-501).  One caller (engine + workspace) per device and chunk size, num_runners runners
+// sharing each (utils/include/utils/parameters.h:11 num_runners = 2).  batch_size 0 = automatic, sized against the
+// device memory that is still free when the caller is created.
+std::vector<std::vector<RunnerPtr>> create_basecall_runners(
+        const mibc_model_desc &desc, const float *const *weights, int n_weights,
+        const std::string &device_string, int num_runners, const std::vector<int> &chunk_sizes, int batch_size,
+        const mibc_decode_opts &opts);
+// single chunk size
 std::vector<std::vector<RunnerPtr>> create_basecall_runners(
         const mibc_model_desc &desc, const float *const *weights, int n_weights,
         const std::string &device_string, int num_runners, int chunk_size, int batch_size,
@@ -270,6 +291,7 @@ private:
     };
     std::vector<CalledRead> basecall_views(const std::vector<ReadView> &reads);
     std::vector<RunnerPtr> m_runners;
+    std::vector<size_t> m_chunk_sizes;   // one chunk queue per size (BasecallerNode.cpp:494-501, 515-522)
     int m_overlap, m_stride;
     std::atomic<int64_t> m_samples_processed{0}, m_samples_incl_padding{0}, m_batches{0},
             m_partial_batches{0};

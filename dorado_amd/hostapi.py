@@ -90,9 +90,29 @@ def generate_variable_chunks(num_samples, chunk_size, stride, overlap):
     return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
 
 
+def simplex_chunk_sizes(cfg: ModelConfig, requested_chunk_size, overlap):
+    """CudaCaller.cpp:382-413: {chunk, 0.5 x chunk} normalised to the chunk granularity, largest first."""
+    out = (C.c_int * 8)()
+    d = cfg.to_desc()
+    n = lib().mibch_simplex_chunk_sizes(C.byref(d), int(requested_chunk_size), int(overlap), out, 8)
+    return [int(out[i]) for i in range(n)]
+
+
+def get_chunk_queue_idx(chunk_sizes, read_raw_size):
+    """BasecallerNode::get_chunk_queue_idx (BasecallerNode.cpp:81-94)."""
+    arr = (C.c_uint64 * len(chunk_sizes))(*[int(v) for v in chunk_sizes])
+    return int(lib().mibch_get_chunk_queue_idx(arr, len(chunk_sizes), C.c_uint64(int(read_raw_size))))
+
+
+def model_stride(cfg: ModelConfig):
+    d = cfg.to_desc()
+    return int(lib().mibch_model_stride(C.byref(d)))
+
+
 def basecall_reads(cfg: ModelConfig, weights, reads_f16, device="hip:0", num_runners=2, batch_size=64,
-                   beam_width=32, variable_chunks=False):
-    """reads_f16: list of 1-D f16 arrays.  Returns (list of (seq, qstr, moves, chunk_offsets), stats)."""
+                   beam_width=32, variable_chunks=False, two_queues=False):
+    """reads_f16: list of 1-D f16 arrays.  Returns (list of (seq, qstr, moves, chunk_offsets), stats).
+    two_queues: the reference's extra 0.5x chunk-size queue ([device][runner][chunk_size] runners)."""
     L = lib()
     d = cfg.to_desc()
     ws = [np.ascontiguousarray(w, np.float32) for w in weights]
@@ -107,16 +127,20 @@ def basecall_reads(cfg: ModelConfig, weights, reads_f16, device="hip:0", num_run
     mv = np.zeros(tot_steps + 8, np.uint8)
     sl = np.zeros(n, np.int64)
     ml = np.zeros(n, np.int64)
-    max_off = int(sum(l // (cfg.chunk_size - cfg.overlap) + 3 for l in lens))
+    max_off = int(sum(l // max(1, cfg.chunk_size // 2 - cfg.overlap) + 3 for l in lens))
     offs = np.zeros(max_off, np.int64)
     noff = np.zeros(n, np.int64)
     stats = (C.c_double * 4)()
     fn = L.mibch_basecall_reads_variable if variable_chunks else L.mibch_basecall_reads
-    rc = fn(C.byref(d), arr, len(ws), device.encode(), num_runners, cfg.chunk_size,
-                                cfg.overlap, batch_size, C.byref(opts), sig.ctypes.data_as(C.c_void_p),
-                                lens.ctypes.data_as(_i64p), n, seq, qs, sl.ctypes.data_as(_i64p),
-                                mv.ctypes.data_as(_u8p), ml.ctypes.data_as(_i64p),
-                                offs.ctypes.data_as(_i64p), noff.ctypes.data_as(_i64p), stats)
+    args = [C.byref(d), arr, len(ws), device.encode(), num_runners, cfg.chunk_size,
+            cfg.overlap, batch_size, C.byref(opts), sig.ctypes.data_as(C.c_void_p),
+            lens.ctypes.data_as(_i64p), n, seq, qs, sl.ctypes.data_as(_i64p),
+            mv.ctypes.data_as(_u8p), ml.ctypes.data_as(_i64p),
+            offs.ctypes.data_as(_i64p), noff.ctypes.data_as(_i64p), stats]
+    if two_queues:
+        fn = L.mibch_basecall_reads_two_queues
+        args.append((C.c_int * 4)())
+    rc = fn(*args)
     if rc != 0:
         raise capi.MibcError(L.mibch_last_error().decode())
     out = []

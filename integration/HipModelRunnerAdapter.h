@@ -1,0 +1,146 @@
+// integration/HipModelRunnerAdapter.h — the reference-side binding of the MI355X engine.
+//
+// This is the one file a Dorado maintainer adds next to dorado/basecall/CudaModelRunner.h: it derives from the
+// reference's own dorado::basecall::ModelRunnerBase (basecall/include/basecall/ModelRunnerBase.h:20-38) and
+// forwards to dorado_amd::host::HipModelRunner (dorado_amd/host/mibc_host.h -> libmibc_host.so -> libmibc.so).
+// It is COMPILED against the reference's real headers by oracle/Makefile.ref (target adapter) and exercised
+// through ModelRunnerBase::accept_chunk(at::Tensor) / call_chunks by tests/test_adapter.py — not documentation.
+//
+//   accept_chunk(at::Tensor)  the only libtorch type that crosses the boundary: the [1, T_in] f16 slice
+//                             BasecallerNode hands over (BasecallerNode.cpp:397-444) -> raw pointer + length
+//   create_hip_basecall_runners  the branch api::create_basecall_runners gains beside its "cuda" branch
+//                             (api/runner_creation.cpp:85-124): same [devices][runners][chunk_sizes] order,
+//                             same {chunk, 0.5 x chunk} batch dimensions for PipelineType::simplex
+#pragma once
+#include "basecall/ModelRunnerBase.h"
+#include "config/BasecallModelConfig.h"
+#include "mibc_host.h"   // this repo: dorado_amd/host
+
+#include <ATen/ATen.h>
+
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace dorado::basecall {
+
+// config::BasecallModelConfig -> the plain C descriptor of include/mibc.h
+inline mibc_model_desc mibc_desc_from_config(const config::BasecallModelConfig &c) {
+    mibc_model_desc d{};
+    d.n_convs = int(c.convs.size());
+    if (d.n_convs > 8) throw std::runtime_error("mibc: more than 8 convolution layers");
+    for (int i = 0; i < d.n_convs; ++i) {
+        d.conv_insize[i] = c.convs[size_t(i)].insize;
+        d.conv_size[i] = c.convs[size_t(i)].size;
+        d.conv_winlen[i] = c.convs[size_t(i)].winlen;
+        d.conv_stride[i] = c.convs[size_t(i)].stride;
+        d.conv_act[i] = int(c.convs[size_t(i)].activation);   // MIBC_ACT_* == config::Activation order
+    }
+    d.lstm_size = c.lstm_size;
+    d.lstm_layers = c.lstm_layers;
+    d.state_len = c.state_len;
+    d.outsize = c.outsize;
+    d.bias = c.bias ? 1 : 0;
+    d.clamp = c.clamp ? 1 : 0;
+    d.scale = c.scale;
+    d.out_features = c.out_features.value_or(-1);
+    d.num_features = c.num_features;
+    if (c.tx.has_value()) {
+        const auto &t = *c.tx;
+        d.tx_d_model = t.tx.d_model;
+        d.tx_nhead = t.tx.nhead;
+        d.tx_depth = t.tx.depth;
+        d.tx_dim_ff = t.tx.dim_feedforward;
+        d.tx_win_upper = t.tx.attn_window.first;
+        d.tx_win_lower = t.tx.attn_window.second;
+        d.tx_max_seq_len = t.tx.max_seq_len;
+        d.tx_deepnorm_alpha = t.tx.deepnorm_alpha;
+        d.tx_theta = t.tx.theta;
+        d.up_size = t.upsample.size;
+        d.up_scale_factor = t.upsample.scale_factor;
+        d.crf_scale = t.crf.scale;
+        d.crf_blank_score = t.crf.blank_score;
+        d.crf_expand_blanks = t.crf.expand_blanks ? 1 : 0;
+        d.state_len = t.crf.state_len;
+        d.outsize = t.crf.outsize();
+    }
+    return d;
+}
+
+class HipModelRunnerAdapter final : public ModelRunnerBase {
+public:
+    HipModelRunnerAdapter(std::unique_ptr<dorado_amd::host::ModelRunnerBase> impl, const config::BasecallModelConfig &cfg,
+                          bool low_latency)
+            : m_impl(std::move(impl)), m_cfg(cfg), m_low_latency(low_latency) {}
+
+    void accept_chunk(int chunk_idx, const at::Tensor &chunk) override {
+        // [1, T_in] (or [T_in]) f16 view of the read's signal, possibly shorter than chunk_size for variable chunks
+        const at::Tensor c = chunk.to(at::kHalf).contiguous();
+        m_impl->accept_chunk(chunk_idx, reinterpret_cast<const uint16_t *>(c.data_ptr()), size_t(c.numel()));
+    }
+    std::vector<decode::DecodedChunk> call_chunks(int num_chunks) override {
+        auto r = m_impl->call_chunks(num_chunks);
+        std::vector<decode::DecodedChunk> out(r.size());
+        for (size_t i = 0; i < r.size(); ++i)
+            out[i] = {std::move(r[i].sequence), std::move(r[i].qstring), std::move(r[i].moves)};
+        return out;
+    }
+    const config::BasecallModelConfig &config() const override { return m_cfg; }
+    size_t chunk_size() const override { return m_impl->chunk_size(); }
+    size_t batch_size() const override { return m_impl->batch_size(); }
+    // ModelRunnerBase.h:29.  The packed-rows form of variable chunk sizes needs the node to place several chunks in
+    // one batch row (HipModelRunner::batch_row + call_chunks_var); through THIS interface — one chunk per
+    // accept_chunk index — chunks are fixed-size, so the node must use generate_chunks: report false.
+    bool variable_chunk_sizes() const override { return false; }
+    std::pair<int, int> batch_timeouts_ms() const override {
+        // CudaCaller.cpp:126-138: low latency 350 ms / 350 ms, else 300 s first chunk / 30 s last chunk
+        return m_low_latency ? std::pair<int, int>{350, 350} : m_impl->batch_timeouts_ms();
+    }
+    bool is_low_latency() const override { return m_low_latency; }   // ModelRunnerBase.h:34
+    void terminate() override { m_impl->terminate(); }
+    void restart() override { m_impl->restart(); }
+    std::string get_name() const override { return m_impl->get_name(); }
+    stats::NamedStats sample_stats() const override {
+        stats::NamedStats s;
+        for (const auto &kv : m_impl->sample_stats()) s[kv.first] = kv.second;
+        return s;
+    }
+
+private:
+    std::unique_ptr<dorado_amd::host::ModelRunnerBase> m_impl;
+    const config::BasecallModelConfig &m_cfg;
+    bool m_low_latency;
+};
+
+// The "hip:" branch of api::create_basecall_runners (api/runner_creation.cpp:85-124).  weights: host f32 tensors in
+// module.parameters() order (what basecall::load_crf_model_weights returns, crf_utils.cpp:26-150).
+// Returns the runners in [devices][runners][chunk_sizes] order and the number of devices.
+inline std::pair<std::vector<RunnerPtr>, size_t> create_hip_basecall_runners(const BasecallerCreationParams &params,
+                                                                            const std::vector<at::Tensor> &weights,
+                                                                            size_t num_gpu_runners) {
+    const config::BasecallModelConfig &cfg = params.model_config;
+    const mibc_model_desc desc = mibc_desc_from_config(cfg);
+    std::vector<at::Tensor> keep;
+    std::vector<const float *> wp;
+    for (const auto &w : weights) {
+        keep.push_back(w.to(at::kCPU).to(at::kFloat).contiguous());
+        wp.push_back(keep.back().data_ptr<float>());
+    }
+    const mibc_decode_opts opts{32, 100.0f, 2.0f, cfg.qbias, cfg.qscale};   // DecodedChunk.h:15-23, ModelRunner.cpp:17-18
+    const int chunk = int(cfg.basecaller.chunk_size()), overlap = int(cfg.basecaller.overlap());
+    // batch dimensions: {chunk, 0.5 x chunk} for high-throughput simplex, one size otherwise (CudaCaller.cpp:388-413)
+    const std::vector<int> sizes = (params.pipeline_type == PipelineType::simplex)
+                                           ? dorado_amd::host::simplex_chunk_sizes(desc, chunk, overlap)
+                                           : std::vector<int>{chunk};
+    auto per_device = dorado_amd::host::create_basecall_runners(desc, wp.data(), int(wp.size()), params.device,
+                                                                int(num_gpu_runners), sizes,
+                                                                int(cfg.basecaller.batch_size()), opts);
+    std::vector<RunnerPtr> runners;
+    const bool low_latency = params.pipeline_type == PipelineType::simplex_low_latency;
+    for (auto &dev : per_device)
+        for (auto &r : dev) runners.push_back(std::make_unique<HipModelRunnerAdapter>(std::move(r), cfg, low_latency));
+    return {std::move(runners), per_device.size()};
+}
+
+}  // namespace dorado::basecall

@@ -324,6 +324,45 @@ def test_host_layer_whole_reads_vs_oracle_pipeline():
     eng.close()
 
 
+def test_host_layer_two_chunk_size_queues():
+    """[device][runner][chunk_size] runners with the reference's extra 0.5x chunk queue (CudaCaller.cpp:388-413,
+    runner_creation.cpp:115-123, BasecallerNode.cpp:81-94,494-501): every read is chunked with the size of the queue
+    it is routed to; stitched reads == oracle stitch of the engine's per-chunk calls at that size."""
+    cfg = _cfg(128, 4, 5)
+    cfg.chunk_size, cfg.overlap = 1200, 120
+    cfg.normalise_basecaller_params()
+    ws = synth.make_weights(cfg, seed=31)
+    sizes = hostapi.simplex_chunk_sizes(cfg, cfg.chunk_size, cfg.overlap)
+    assert sizes == [1200, 600]
+    lens = [300, 600, 601, 1200, 1201, 2500, 3333, 5000, 799, 4096, 61, 599]
+    reads = [synth.make_signal(1, L, seed=100 + i)[0] for i, L in enumerate(lens)]
+    got, stats = hostapi.basecall_reads(cfg, ws, reads, device="hip:0", num_runners=2, batch_size=64, two_queues=True)
+    assert stats["samples_processed"] == sum(lens)
+    engs = {}
+    for r, sig in enumerate(reads):
+        cs = sizes[hostapi.get_chunk_queue_idx(sizes, len(sig))]
+        assert cs == (600 if len(sig) < 600 else 1200)   # strict comparison, as the reference's
+        offs = O.generate_chunks(len(sig), cs, cfg.stride, cfg.overlap)
+        assert got[r][3] == offs
+        rows = []
+        for o in offs:
+            sl = sig[o:o + cs]
+            if len(sl) != cs:
+                n, ov = divmod(cs, len(sl))
+                sl = np.concatenate([np.tile(sl, n), sl[:ov]])
+            rows.append(sl)
+        x = np.zeros((64, cs), np.float16)
+        x[:len(rows)] = np.stack(rows)
+        if cs not in engs:
+            engs[cs] = capi.Engine(cfg, ws)
+        calls = engs[cs].call(x)[:len(rows)]
+        st = O.stitch_chunks(offs, [cs] * len(offs), [c[2] for c in calls], [c[0] for c in calls],
+                             [c[1] for c in calls], len(sig), cfg.stride)
+        assert got[r][0] == st[0] and got[r][1] == st[1] and (got[r][2] == st[2]).all()
+    for e in engs.values():
+        e.close()
+
+
 def test_host_layer_whole_reads_transformer_stride():
     """Transformer models emit one step per conv_stride / up_scale_factor samples (sup@v5: 12 / 2 = 6,
     config/BasecallModelConfig.cpp:447-454); the host layer must chunk by the model's chunk granularity and

@@ -199,3 +199,24 @@ def test_scaler_host_trim_known_answers():
     assert hostapi.dna_trim_start(True, sig) == 10                      # standardised models: constant
     assert hostapi.dna_trim_start(False, sig) == 90
     assert hostapi.dna_trim_start(True, sig[:8]) == 0                   # trim would swallow the read
+
+
+def test_simplex_chunk_sizes_and_queue_routing():
+    """CudaCaller.cpp:382-413 batch dimensions and BasecallerNode.cpp:81-94 routing (restated; known answers worked
+    from the reference code: hac 9996 -> {9996, 4998}; sup@v5 12288 -> {12288, 6144} with granularity 12*16)."""
+    from dorado_amd import config
+    hac, s5 = config.hac_v43(), config.sup_v50()
+    assert hostapi.model_stride(hac) == 6 and hostapi.model_stride(s5) == 6
+    assert hostapi.simplex_chunk_sizes(hac, 9996, 498) == [9996, 4998]
+    assert hostapi.simplex_chunk_sizes(hac, 10000, 498) == [9996, 4998]       # x / 6 * 6
+    assert hostapi.simplex_chunk_sizes(s5, 12288, 600) == [12288, 6144]
+    assert hostapi.simplex_chunk_sizes(s5, 12000, 600) == [11904, 5952]       # granularity 192
+    assert hostapi.simplex_chunk_sizes(hac, 600, 498) == [600, 504]           # never below pad_to(overlap + 1)
+    assert hostapi.simplex_chunk_sizes(hac, 504, 498) == [504]                # duplicates collapse
+    q = hostapi.get_chunk_queue_idx
+    sizes = [9996, 4998]
+    # smallest size STRICTLY larger than the read (the reference compares with <), else the largest
+    assert q(sizes, 100) == 1 and q(sizes, 4997) == 1 and q(sizes, 4998) == 0 and q(sizes, 4999) == 0
+    assert q(sizes, 9996) == 0 and q(sizes, 50000) == 0                           # else the largest
+    assert q([4998, 9996], 50000) == 1 and q([4998, 9996], 10) == 0
+    assert q([9996], 5) == 0
