@@ -151,7 +151,7 @@ HipCaller::HipCaller(const mibc_model_desc &desc, const float *const *weights, i
     if (rc != MIBC_OK) throw std::runtime_error(std::string("mibc_create: ") + mibc_last_error(nullptr));
     const int g = mibc_batch_granularity(m_engine);
     if (batch_size <= 0) {
-        // Auto batch size (the role of CudaCaller::determine_batch_dims, CudaCaller.cpp:323-569, whose timing sweep
+        // Auto batch size (0: the known knee; -1: the reference's timing sweep, see below) (the role of CudaCaller::determine_batch_dims, CudaCaller.cpp:323-569, whose timing sweep
         // looks for the knee of a GPU that batches across SMs).  On this engine the LSTM runs one 64-chunk workgroup
         // per CU for the whole chunk, so the knee is known: one workgroup on every CU (256 * granularity), bounded by
         // what fits in 80 % of the free device memory (mibc_query_memory = the memory model of :323-369).
@@ -166,6 +166,31 @@ HipCaller::HipCaller(const mibc_model_desc &desc, const float *const *weights, i
         long cap = budget > 0 ? long(budget / double(per_chunk)) : 0;
         long want = (desc.tx_d_model > 0) ? 1024 : 256L * g;
         long n = std::min(want, cap / g * g);
+        if (batch_size < 0) {
+            // Timing-based selection, the reference's procedure (CudaCaller.cpp:552-627): time the network alone on
+            // a short chunk (288 output steps, :497-503) for a ladder of batch sizes up to the memory cap, min of the
+            // timed runs, and take the SMALLEST batch whose time per chunk is within `penalty` of the best.
+            const int stride = dorado_amd::host::model_stride(desc);
+            const int gran = chunk_size_granularity(desc);
+            const int t_bench = std::max(gran, (288 * stride) / gran * gran);
+            const long top = std::max<long>(g, std::min<long>(std::max(want, 2 * want), cap / g * g));
+            std::vector<long> ladder;
+            for (long b = top; b >= g && ladder.size() < 6; b = (b / 2) / g * g) ladder.push_back(b);
+            double best = 1e30;
+            std::vector<std::pair<long, double>> timed;
+            for (long b : ladder) {
+                float ms = 0;
+                if (mibc_time_forward(m_engine, int(b), t_bench, &ms) != MIBC_OK) continue;
+                timed.push_back({b, double(ms) / double(b)});
+                best = std::min(best, timed.back().second);
+                m_batch_timings.push_back({int(b), double(ms) / double(b)});
+            }
+            const double penalty = 0.05;
+            n = want;
+            for (auto &tb : timed)
+                if (tb.second <= best * (1.0 + penalty)) n = tb.first;   // ladder is descending: ends at the smallest
+            n = std::min(n, cap / g * g);
+        }
         batch_size = int(std::max<long>(g, n));
     }
     m_batch_size = (batch_size + g - 1) / g * g;
@@ -1065,6 +1090,27 @@ int mibch_basecall_reads_two_queues(const mibc_model_desc *desc, const float *co
         auto called = node->basecall(reads);
         write_outputs(called, *node, {seq_out, qstr_out, seq_len_out, moves_out, moves_len_out, offsets_out,
                                       n_offsets_out, stats4});
+        return 0;
+    } catch (const std::exception &e) {
+        g_herr = e.what();
+        return -1;
+    }
+}
+
+// Batch size a HipCaller picks: mode 0 = the known knee, -1 = the reference's timing sweep (CudaCaller.cpp:552-627).
+// timings_out: up to max_t (batch, ms per chunk) pairs of the sweep.
+int mibch_auto_batch_size(const mibc_model_desc *desc, const float *const *weights, int n_weights, int device,
+                          int chunk_size, int mode, const mibc_decode_opts *opts, int *chosen, double *timings_out,
+                          int max_t, int *n_t) {
+    try {
+        HipCaller c(*desc, weights, n_weights, device, chunk_size, mode, *opts);
+        *chosen = c.batch_size();
+        const auto &t = c.batch_timings();
+        *n_t = int(t.size());
+        for (size_t i = 0; i < t.size() && int(i) < max_t; ++i) {
+            timings_out[2 * i] = double(t[i].first);
+            timings_out[2 * i + 1] = t[i].second;
+        }
         return 0;
     } catch (const std::exception &e) {
         g_herr = e.what();

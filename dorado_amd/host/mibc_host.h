@@ -162,6 +162,8 @@ public:
     std::pair<int, int> batch_timeouts_ms() const { return {300000, 30000}; }  // CudaCaller.cpp:126-132
     NamedStats sample_stats() const;
     std::string get_name() const { return "HipCaller_hip:" + std::to_string(m_device); }
+    // (batch size, ms per chunk) pairs of the timing sweep (batch_size = -1 at construction); empty otherwise
+    const std::vector<std::pair<int, double>> &batch_timings() const { return m_batch_timings; }
 
 private:
     struct NNTask {
@@ -190,6 +192,7 @@ private:
     std::atomic<bool> m_terminate{false};
     std::atomic<int64_t> m_batches{0};
     std::atomic<int64_t> m_model_decode_us{0};
+    std::vector<std::pair<int, double>> m_batch_timings;
 };
 
 class HipModelRunner final : public ModelRunnerBase {

@@ -104,6 +104,22 @@ def get_chunk_queue_idx(chunk_sizes, read_raw_size):
     return int(lib().mibch_get_chunk_queue_idx(arr, len(chunk_sizes), C.c_uint64(int(read_raw_size))))
 
 
+def auto_batch_size(cfg: ModelConfig, weights, mode=0, device=0):
+    """Batch size HipCaller chooses for cfg.chunk_size: mode 0 = known knee (one LSTM workgroup / cluster slot per CU,
+    bounded by memory), mode -1 = the reference's timing sweep.  Returns (batch, [(batch, ms_per_chunk), ...])."""
+    d = cfg.to_desc()
+    ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+    arr = (C.POINTER(C.c_float) * len(ws))(*[w.ctypes.data_as(C.POINTER(C.c_float)) for w in ws])
+    opts = capi.DecodeOptsC(32, 100.0, 2.0, cfg.qbias, cfg.qscale)
+    chosen, nt = C.c_int(), C.c_int()
+    tim = (C.c_double * 32)()
+    rc = lib().mibch_auto_batch_size(C.byref(d), arr, len(ws), device, cfg.chunk_size, mode, C.byref(opts),
+                                     C.byref(chosen), tim, 16, C.byref(nt))
+    if rc != 0:
+        raise capi.MibcError(lib().mibch_last_error().decode())
+    return chosen.value, [(int(tim[2 * i]), float(tim[2 * i + 1])) for i in range(min(nt.value, 16))]
+
+
 def model_stride(cfg: ModelConfig):
     d = cfg.to_desc()
     return int(lib().mibch_model_stride(C.byref(d)))

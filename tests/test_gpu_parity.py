@@ -571,6 +571,24 @@ def test_stage_time_ratios_guard():
     assert st["lstm"] < 450.0, st
 
 
+def test_timing_based_batch_size_selection():
+    """batch_size = -1: the reference's procedure (CudaCaller.cpp:552-627) — time the network on 288-step chunks for a
+    ladder of batch sizes under the memory cap, pick the smallest within 5 % of the best time per chunk."""
+    cfg = _cfg(128, 4, 5)
+    cfg.chunk_size, cfg.overlap = 1200, 120
+    cfg.normalise_basecaller_params()
+    ws = synth.make_weights(cfg, seed=31)
+    chosen, timings = hostapi.auto_batch_size(cfg, ws, mode=-1)
+    knee, none = hostapi.auto_batch_size(cfg, ws, mode=0)
+    print("timing sweep:", timings, "->", chosen, "; formula:", knee)
+    assert none == [] and knee == 256 * 64
+    assert len(timings) >= 3 and [b for b, _ in timings] == sorted([b for b, _ in timings], reverse=True)
+    assert chosen % 64 == 0 and chosen in [b for b, _ in timings]
+    best = min(t for _, t in timings)
+    assert dict(timings)[chosen] <= best * 1.05 + 1e-12
+    assert all(dict(timings)[b] > best * 1.05 for b in [b for b, _ in timings] if b < chosen)
+
+
 def test_host_layer_auto_batch_size():
     """batch_size = 0 -> the caller sizes the batch itself (one LSTM workgroup per CU, bounded by
     mibc_query_memory against mibc_device_memory); calls are independent of the batch size."""
