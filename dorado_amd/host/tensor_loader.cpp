@@ -1,6 +1,7 @@
 // dorado_amd/host/tensor_loader.cpp — see tensor_loader.h.
 #include "tensor_loader.h"
 
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -36,37 +37,49 @@ std::map<std::string, ZipEntry> zip_entries(const std::vector<uint8_t> &f, const
         if (i == 0 || f.size() - i > 66000) break;
     }
     if (eocd == std::string::npos) die(path, "not a zip archive (no end-of-central-directory record)");
+    if (eocd + 22 > f.size()) die(path, "truncated end-of-central-directory record");
     uint64_t n = rd16(&f[eocd + 10]), cd_off = rd32(&f[eocd + 16]);
     if (cd_off == 0xffffffffu || n == 0xffffu) {   // zip64
         if (eocd < 20 || rd32(&f[eocd - 20]) != 0x07064b50u) die(path, "zip64 locator missing");
         const uint64_t e64 = rd64(&f[eocd - 20 + 8]);
-        if (e64 + 56 > f.size() || rd32(&f[e64]) != 0x06064b50u) die(path, "bad zip64 end record");
+        if (e64 > f.size() || f.size() - e64 < 56 || rd32(&f[e64]) != 0x06064b50u) die(path, "bad zip64 end record");
         n = rd64(&f[e64 + 32]);
         cd_off = rd64(&f[e64 + 48]);
     }
     std::map<std::string, ZipEntry> out;
+    if (cd_off > f.size() || n > f.size() / 46) die(path, "corrupt central directory");
     size_t p = cd_off;
     for (uint64_t i = 0; i < n; ++i) {
-        if (p + 46 > f.size() || rd32(&f[p]) != 0x02014b50u) die(path, "corrupt central directory");
+        if (p > f.size() || f.size() - p < 46 || rd32(&f[p]) != 0x02014b50u) die(path, "corrupt central directory");
         const uint16_t method = rd16(&f[p + 10]);
         uint64_t csize = rd32(&f[p + 20]), usize = rd32(&f[p + 24]), lho = rd32(&f[p + 42]);
         const uint16_t nlen = rd16(&f[p + 28]), xlen = rd16(&f[p + 30]), clen = rd16(&f[p + 32]);
+        if (f.size() - p - 46 < size_t(nlen) + xlen + clen) die(path, "corrupt central directory (names run past the end)");
         const std::string name(reinterpret_cast<const char *>(&f[p + 46]), nlen);
         size_t x = p + 46 + nlen;
         const size_t xend = x + xlen;
         while (x + 4 <= xend) {
             const uint16_t id = rd16(&f[x]), sz = rd16(&f[x + 2]);
+            if (x + 4 + sz > xend) die(path, "corrupt extra field of '" + name + "'");
             if (id == 0x0001) {
                 size_t q = x + 4;
-                if (usize == 0xffffffffu) { usize = rd64(&f[q]); q += 8; }
-                if (csize == 0xffffffffu) { csize = rd64(&f[q]); q += 8; }
-                if (lho == 0xffffffffu) { lho = rd64(&f[q]); q += 8; }
+                const size_t qend = x + 4 + sz;
+                auto take64 = [&](uint64_t &v) {
+                    if (q + 8 > qend) die(path, "short zip64 extra field of '" + name + "'");
+                    v = rd64(&f[q]);
+                    q += 8;
+                };
+                if (usize == 0xffffffffu) take64(usize);
+                if (csize == 0xffffffffu) take64(csize);
+                if (lho == 0xffffffffu) take64(lho);
             }
             x += 4 + sz;
         }
-        if (lho + 30 > f.size() || rd32(&f[lho]) != 0x04034b50u) die(path, "corrupt local header of '" + name + "'");
+        if (lho > f.size() || f.size() - lho < 30 || rd32(&f[lho]) != 0x04034b50u)
+            die(path, "corrupt local header of '" + name + "'");
         const size_t data = lho + 30 + rd16(&f[lho + 26]) + rd16(&f[lho + 28]);
-        if (data + (method == 0 ? usize : csize) > f.size()) die(path, "entry '" + name + "' runs past the end of the file");
+        const uint64_t stored_size = method == 0 ? usize : csize;
+        if (data > f.size() || stored_size > f.size() - data) die(path, "entry '" + name + "' runs past the end of the file");
         out[name] = {data, size_t(method == 0 ? usize : csize), method == 0};
         p = xend + clen;
     }
@@ -105,10 +118,15 @@ struct Unpickler {
         stack.pop_back();
         return v;
     }
+    const P &top() {
+        if (stack.empty()) die(path, "pickle stack underflow");
+        return stack.back();
+    }
     std::vector<P> pop_mark() {
         if (marks.empty()) die(path, "pickle MARK missing");
         const size_t m = marks.back();
         marks.pop_back();
+        if (m > stack.size()) die(path, "pickle MARK beyond the stack");
         std::vector<P> v(stack.begin() + long(m), stack.end());
         stack.resize(m);
         return v;
@@ -200,8 +218,8 @@ struct Unpickler {
                     stack.push_back(g);
                     break;
                 }
-                case 'q': need(1); memo[*p++] = stack.back(); break;               // BINPUT
-                case 'r': need(4); memo[rd32(p)] = stack.back(); p += 4; break;    // LONG_BINPUT
+                case 'q': need(1); memo[*p++] = top(); break;                      // BINPUT
+                case 'r': need(4); memo[rd32(p)] = top(); p += 4; break;           // LONG_BINPUT
                 case 'h': { need(1); auto it = memo.find(*p++); if (it == memo.end()) die(path, "bad BINGET"); stack.push_back(it->second); break; }
                 case 'j': { need(4); auto it = memo.find(rd32(p)); p += 4; if (it == memo.end()) die(path, "bad LONG_BINGET"); stack.push_back(it->second); break; }
                 case 't': { P t = mk(Obj::TUPLE); t->items = pop_mark(); stack.push_back(t); break; }          // TUPLE
@@ -238,7 +256,7 @@ struct Unpickler {
                 case 'R': { P args = pop(), fn = pop(); stack.push_back(reduce(fn, args)); break; }            // REDUCE
                 case 'Q': {                                                        // BINPERSID: ('storage', StorageClass, key, device, numel)
                     P pid = pop();
-                    if (pid->kind != Obj::TUPLE || pid->items.size() < 5 || pid->items[0]->s != "storage" ||
+                    if (pid->kind != Obj::TUPLE || pid->items.size() < 5 || pid->items[0]->kind != Obj::STR || pid->items[0]->s != "storage" ||
                         pid->items[1]->kind != Obj::GLOBAL || pid->items[2]->kind != Obj::STR || pid->items[4]->kind != Obj::INT)
                         die(path, "unsupported persistent id");
                     P st = mk(Obj::STORAGE);
@@ -359,6 +377,7 @@ std::vector<LoadedTensor> load_tensor_file(const std::string &path) {
     for (const auto &kv : attrs) {
         if (kv.second->kind != Obj::TENSOR) continue;   // e.g. "training": False
         const Obj &t = *kv.second;
+        if (t.items.empty() || t.items[0]->kind != Obj::STORAGE || t.items[0]->items.empty()) die(path, "tensor without storage");
         const Obj &st = *t.items[0];
         const DInfo di = storage_dtype(st.s, path);
         const auto it = entries.find(root + "data/" + st.items[0]->s);
@@ -369,14 +388,28 @@ std::vector<LoadedTensor> load_tensor_file(const std::string &path) {
         lt.dtype = di.t;
         lt.shape = t.shape;
         if (t.stride.size() != t.shape.size()) die(path, "shape / stride rank mismatch");
-        const size_t n = lt.numel(), es = di.size;
-        // bounds: largest linear index touched
-        int64_t maxidx = t.offset;
+        const size_t es = di.size;
+        // bounds, overflow-checked: rank, element count (a stride-0 view may not blow the output up beyond the
+        // archive's own size class), largest linear index touched
+        if (t.shape.size() > 16) die(path, "tensor rank above 16");
+        const uint64_t storage_elems = it->second.size / es;
+        uint64_t n64 = 1, maxidx = 0;
+        if (t.offset < 0) die(path, "negative storage offset");
+        maxidx = uint64_t(t.offset);
         for (size_t d = 0; d < t.shape.size(); ++d) {
             if (t.shape[d] < 0 || t.stride[d] < 0) die(path, "negative shape / stride");
-            if (t.shape[d] > 0) maxidx += (t.shape[d] - 1) * t.stride[d];
+            const uint64_t sd = uint64_t(t.shape[d]), st_d = uint64_t(t.stride[d]);
+            if (sd != 0 && n64 > (uint64_t(1) << 40) / sd) die(path, "tensor '" + lt.name + "' is implausibly large");
+            n64 *= sd;
+            if (sd > 1) {
+                if (st_d != 0 && (sd - 1) > (uint64_t(1) << 62) / st_d) die(path, "tensor '" + lt.name + "' reaches outside its storage");
+                maxidx += (sd - 1) * st_d;
+                if (maxidx >= (uint64_t(1) << 62)) die(path, "tensor '" + lt.name + "' reaches outside its storage");
+            }
         }
-        if (n > 0 && (t.offset < 0 || size_t(maxidx + 1) * es > it->second.size)) die(path, "tensor '" + lt.name + "' reaches outside its storage");
+        const size_t n = size_t(n64);
+        if (n > 0 && maxidx >= storage_elems) die(path, "tensor '" + lt.name + "' reaches outside its storage");
+        if (n > 0 && n64 > 64 * std::max<uint64_t>(storage_elems, 1)) die(path, "tensor '" + lt.name + "' expands its storage more than 64x");
         lt.data.resize(n * es);
         const uint8_t *src = &f[it->second.offset];
         // contiguous fast path

@@ -66,12 +66,23 @@ def zstd_frame_content_size(buf: bytes) -> int:
     size = (1 if single else 0, 2, 4, 8)[fcs_flag]
     if size == 0:
         raise Pod5Error("zstd frame without content size")
+    if len(buf) < pos + size:
+        raise Pod5Error("truncated zstd frame header")
     v = int.from_bytes(buf[pos:pos + size], "little")
     return v + 256 if size == 2 else v
 
 
-def zstd_inflate(buf: bytes) -> bytes:
+def svb16_max_bytes(samples: int) -> int:
+    """Largest StreamVByte-16 stream `samples` values can occupy: one control bit per value + 2 data bytes."""
+    return (samples + 7) // 8 + 2 * samples
+
+
+def zstd_inflate(buf: bytes, max_size: int | None = None) -> bytes:
+    """Inflate one zstd frame.  max_size: upper bound the caller knows for the content (a signal row: the svb16 worst
+    case of its `samples` column) — the size field of a corrupt / hostile frame is not trusted with an allocation."""
     n = zstd_frame_content_size(buf)
+    if max_size is not None and n > max_size:
+        raise Pod5Error(f"zstd: frame claims {n} bytes, the row can hold at most {max_size}")
     L = _zstd_lib()
     if L:
         out = C.create_string_buffer(n)
@@ -81,13 +92,18 @@ def zstd_inflate(buf: bytes) -> bytes:
         return out.raw
     import pyarrow as pa
 
-    return pa.decompress(buf, decompressed_size=n, codec="zstd", asbytes=True)
+    try:
+        return pa.decompress(buf, decompressed_size=n, codec="zstd", asbytes=True)
+    except Exception as e:  # pyarrow raises ArrowIOError / OSError on corrupt frames
+        raise Pod5Error(f"zstd: corrupt signal row ({e})") from None
 
 
 # ---------------------------------------------------------------- footer (minimal flatbuffer reader)
 def _fb_table_fields(buf, pos):
     """(vtable field offsets, table pos) of the flatbuffer table at `pos`."""
     vt = pos - struct.unpack_from("<i", buf, pos)[0]
+    if vt < 0:
+        raise IndexError("vtable before the buffer")
     vt_len = struct.unpack_from("<H", buf, vt)[0]
     n = (vt_len - 4) // 2
     return [struct.unpack_from("<H", buf, vt + 4 + 2 * i)[0] for i in range(n)], pos
@@ -99,12 +115,22 @@ def _fb_string(buf, table_pos, off):
     p = table_pos + off
     p += struct.unpack_from("<I", buf, p)[0]
     ln = struct.unpack_from("<I", buf, p)[0]
+    if p + 4 + ln > len(buf):
+        raise IndexError("string runs past the footer")
     return bytes(buf[p + 4:p + 4 + ln]).decode()
 
 
 def parse_footer(buf: bytes):
-    """-> dict(file_identifier, software, pod5_version, contents=[(offset, length, format, content_type)])."""
-    if buf[:8] != SIGNATURE or buf[-8:] != SIGNATURE:
+    """-> dict(file_identifier, software, pod5_version, contents=[(offset, length, format, content_type)]).
+    Offsets inside the flatbuffer are not trusted: anything that points outside the footer is a Pod5Error."""
+    try:
+        return _parse_footer(buf)
+    except (struct.error, IndexError, UnicodeDecodeError, OverflowError, MemoryError) as e:
+        raise Pod5Error(f"corrupt POD5 footer ({type(e).__name__}: {e})") from None
+
+
+def _parse_footer(buf: bytes):
+    if len(buf) < 72 or buf[:8] != SIGNATURE or buf[-8:] != SIGNATURE:
         raise Pod5Error("bad POD5 signature")
     flen = struct.unpack_from("<q", buf, len(buf) - 32)[0]
     end = len(buf) - 32
@@ -121,6 +147,8 @@ def parse_footer(buf: bytes):
         p = tp + fields[3]
         p += struct.unpack_from("<I", fb, p)[0]
         cnt = struct.unpack_from("<I", fb, p)[0]
+        if cnt > len(fb) // 4:
+            raise Pod5Error("corrupt POD5 footer (embedded-file count)")
         for i in range(cnt):
             ep = p + 4 + 4 * i
             ep += struct.unpack_from("<I", fb, ep)[0]
@@ -235,8 +263,9 @@ class Pod5File:
 
     def inflated_rows(self, rows):
         """zstd stage of the given signal-table rows -> (list of svb16 streams, samples per row)."""
-        streams = [zstd_inflate(self._sig_bytes[int(r)].as_py()) for r in rows]
-        return streams, [int(self._sig_samples[int(r)]) for r in rows]
+        ns = [int(self._sig_samples[int(r)]) for r in rows]
+        streams = [zstd_inflate(self._sig_bytes[int(r)].as_py(), svb16_max_bytes(n)) for r, n in zip(rows, ns)]
+        return streams, ns
 
     def load_signals(self, reads, engine):
         """Fill read.raw (int16) for every read: zstd on the host, svb16 + zig-zag + delta on the device

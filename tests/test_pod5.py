@@ -100,6 +100,33 @@ def test_zstd_frame_header():
     assert n == len(pod5.zstd_inflate(raw)) == 53704
     with pytest.raises(pod5.Pod5Error):
         pod5.zstd_frame_content_size(b"\x00" * 16)
+    # a frame that claims 2^64-1 bytes is refused against the row's own bound, before any allocation
+    hostile = b"\x28\xb5\x2f\xfd" + bytes([0xC0]) + b"\x00" + b"\xff" * 8 + b"\x00" * 8
+    assert pod5.zstd_frame_content_size(hostile) == 2 ** 64 - 1
+    with pytest.raises(pod5.Pod5Error, match="at most"):
+        pod5.zstd_inflate(hostile, pod5.svb16_max_bytes(47062))
+    assert len(pod5.zstd_inflate(raw, pod5.svb16_max_bytes(int(f.signal_table.column("samples")[0].as_py())))) == n
+    with pytest.raises(pod5.Pod5Error):
+        pod5.zstd_inflate(raw[:40] + bytes(len(raw) - 40))            # corrupt payload -> Pod5Error, not a crash
+
+
+def test_corrupt_footer_is_a_pod5_error():
+    buf = bytearray(open(os.path.join(P5, "single_na24385.pod5"), "rb").read())
+    good = pod5.parse_footer(bytes(buf))
+    assert len(good["contents"]) == 3
+    flen = int.from_bytes(buf[len(buf) - 32:len(buf) - 24], "little")
+    start = len(buf) - 32 - flen
+    rng = np.random.default_rng(3)
+    n_err = 0
+    for trial in range(300):
+        b = bytearray(buf)
+        for _ in range(1 + trial % 3):
+            b[start + int(rng.integers(0, flen))] = int(rng.integers(0, 256))
+        try:
+            pod5.parse_footer(bytes(b))
+        except pod5.Pod5Error:
+            n_err += 1
+    assert n_err > 20
 
 
 # ---------------------------------------------------------------- GPU

@@ -85,6 +85,64 @@ def test_errors_are_loud(tmp_path):
         hostapi.load_tensor_file(tmp_path / "deflated.tensor")
 
 
+def test_malformed_archives_never_crash(tmp_path):
+    """File-format parser hygiene: byte flips, truncations and hostile pickles (empty-stack BINPUT, stride-0
+    blow-up, offsets beyond the file) either load or raise ValueError — never touch memory out of bounds."""
+    _save_tensor(tmp_path / "ok.tensor", torch.arange(64, dtype=torch.float16).reshape(4, 16))
+    raw = bytearray((tmp_path / "ok.tensor").read_bytes())
+    rng = np.random.default_rng(7)
+    bad = tmp_path / "bad.tensor"
+    outcomes = {"ok": 0, "err": 0}
+    eocd = raw.rfind(b"PK\x05\x06")
+    cd = int.from_bytes(raw[eocd + 16:eocd + 20], "little")
+    pk = raw.find(b"data.pkl") + len("data.pkl")
+    regions = [(cd, len(raw)), (pk, pk + 400), (0, len(raw))]
+    for trial in range(600):
+        b = bytearray(raw)
+        lo, hi = regions[trial % 3]
+        for _ in range(1 + trial % 4):
+            b[int(rng.integers(lo, min(hi, len(b))))] = int(rng.integers(0, 256))
+        if trial % 10 == 9:
+            b = b[:int(rng.integers(1, len(b)))]
+        bad.write_bytes(bytes(b))
+        try:
+            hostapi.load_tensor_file(bad)
+            outcomes["ok"] += 1
+        except ValueError:
+            outcomes["err"] += 1
+    assert outcomes["err"] > 100 and outcomes["ok"] > 0, outcomes
+
+    def archive(pickle_bytes, storage=b"\x00" * 128):
+        with zipfile.ZipFile(bad, "w", zipfile.ZIP_STORED) as z:
+            z.writestr("m/data.pkl", pickle_bytes)
+            z.writestr("m/data/0", storage)
+
+    archive(b"\x80\x02q\x00.")                       # BINPUT on an empty stack
+    with pytest.raises(ValueError, match="underflow"):
+        hostapi.load_tensor_file(bad)
+    archive(b"\x80\x02b.")                            # BUILD on an empty stack
+    with pytest.raises(ValueError, match="underflow"):
+        hostapi.load_tensor_file(bad)
+
+    def rebuild(shape, stride, offset=0):
+        def tup(v):
+            return b"(" + b"".join(b"J" + int(x).to_bytes(4, "little", signed=True) for x in v) + b"t"
+        return (b"\x80\x02ctorch._utils\n_rebuild_tensor_v2\n((X\x07\x00\x00\x00storagectorch\nFloatStorage\n"
+                b"X\x01\x00\x00\x000X\x03\x00\x00\x00cpuK\x20tQJ" + int(offset).to_bytes(4, "little", signed=True)
+                + tup(shape) + tup(stride) + b"\x89tR.")
+
+    archive(rebuild((4, 8), (8, 1)))
+    (_, a), = hostapi.load_tensor_file(bad)
+    assert a.shape == (4, 8)
+    for shape, stride, off in [((2 ** 31 - 1, 2 ** 31 - 1), (0, 0), 0),      # stride-0 view: numel overflow / giant resize
+                               ((4, 8), (8, 1), 1),                          # one element past the storage
+                               ((4, 8), (2 ** 31 - 1, 2 ** 31 - 1), 0),      # index overflow
+                               ((100000,), (0,), 0)]:                        # 100000x expansion of a 32-element storage
+        archive(rebuild(shape, stride, off))
+        with pytest.raises(ValueError):
+            hostapi.load_tensor_file(bad)
+
+
 def test_model_tensor_names_follow_the_reference():
     """basecall/crf_utils.cpp:26-88 for hac@v4.3.0 (3 convs, 5 LSTMs, no bias, no decomposition) and
     :90-150 for sup@v5.0.0 (5 convs, 18 encoder layers)."""
