@@ -70,6 +70,13 @@ extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin
                                          const float *biascl, const half_t *zeros, float *cbuf, unsigned *flags,
                                          unsigned *err, int T, int N, int reverse,
                                          const unsigned long long *tmask);
+// lstm_ws.hip: weight-stationary cluster kernel (C = 384, N a multiple of 16, >= WS_RMIN row tiles per cluster)
+extern "C" size_t mibc_lstm_ws_lds_bytes(int C);
+extern "C" size_t mibc_lstm_ws_cstate_bytes(int C, int N);
+extern "C" size_t mibc_lstm_ws_flag_bytes(int C, int N);
+extern "C" int mibc_launch_lstm_layer_ws(hipStream_t s, int C, const half_t *Xin, half_t *Xout, const half_t *Wf16,
+                                         const float *biasn, const half_t *zeros, float *cbuf, unsigned *flags,
+                                         unsigned *err, int T, int N, int reverse);
 extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
                                       float beam_cut, float stay, float clampv, float q_shift, float q_scale,
                                       float *bwd, uint32_t *trace, uint16_t *path_state, int8_t *out3,
@@ -107,6 +114,8 @@ struct mibc_engine {
     unsigned *cl_err = nullptr;      // device [4]: sticky hand-off time-out word
     unsigned *cl_err_host = nullptr; // pinned copy, checked after every stream synchronisation
     bool cl_used = false;
+    bool ws_ok = false;              // lstm_ws.hip covers this width
+    int ws_min_rows = 2048;          // smallest batch that takes the weight-stationary kernel
     int use_cluster = 1;             // debug build: MIBC_LSTM_CLUSTER=0 forces the per-workgroup kernels
     half_t *head_w1 = nullptr, *head_w2 = nullptr;
     float *head_b1 = nullptr;

@@ -257,7 +257,8 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
             e->lstm_bcl.push_back(dbcl);
         }
     }
-    if (!e->lstm_wcl.empty()) {
+    e->ws_ok = (mibc_lstm_ws_lds_bytes(C) != 0);   // weight-stationary cluster kernel (lstm_ws.hip): C = 384
+    if (!e->lstm_wcl.empty() || e->ws_ok) {
         HIP_OK(e, hipMalloc((void **)&e->lstm_zero, (size_t)256 * C * 2));
         HIP_OK(e, hipMemset(e->lstm_zero, 0, (size_t)256 * C * 2));
         HIP_OK(e, hipMalloc((void **)&e->cl_err, 16));
@@ -299,6 +300,7 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
     }
     e->use_ws = MIBC_ENV_INT("MIBC_WSGEMM", 1);
     e->use_cluster = MIBC_ENV_INT("MIBC_LSTM_CLUSTER", 1);
+    e->ws_min_rows = MIBC_ENV_INT("MIBC_WS_MIN_ROWS", 2048);
     const char *tp = getenv("MIBC_TAPS");
     e->taps = tp ? atoi(tp) : 0;
     // weight uploads are null-stream copies from pageable memory: hipMemcpy may return once the data sits
@@ -450,6 +452,12 @@ extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
             if (alloc((void **)&e->cl_flags, (N / 256) * (size_t)(e->C / 128) * 16 * sizeof(unsigned))) return MIBC_ERR_MEM;
             if (alloc((void **)&e->cl_cstate, (N / 256) * 256 * (size_t)e->C * sizeof(float))) return MIBC_ERR_MEM;
         }
+        if (e->ws_ok && mibc_lstm_ws_cstate_bytes(e->C, (int)(N / 16 * 16)) != 0) {
+            // sized for the largest batch; smaller batches use fewer / shorter clusters of the same buffers
+            if (alloc((void **)&e->cl_flags, mibc_lstm_ws_flag_bytes(e->C, (int)(N / 16 * 16)) + 4096)) return MIBC_ERR_MEM;
+            if (alloc((void **)&e->cl_cstate, mibc_lstm_ws_cstate_bytes(e->C, (int)(N / 16 * 16)) + (size_t)256 * 6 * 4096))
+                return MIBC_ERR_MEM;
+        }
     }
     if (alloc((void **)&e->scores, Nd * T * e->K * 2)) return MIBC_ERR_MEM;
     if (e->d.out_features > 0)
@@ -566,7 +574,12 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
                            mibc_launch_lstm_layer_cl(e->stream, e->C, cur, nxt, e->lstm_wcl[l], e->lstm_bcl[l],
                                                      e->lstm_zero, e->cl_cstate, e->cl_flags, e->cl_err, T, N, reverse,
                                                      e->in_tmask) == 0;
-        if (cl_ok) {
+        // hac width: the weight-stationary cluster kernel for large batches (bit-identical to lstm_layer_x8_kernel)
+        const bool ws_ok = !cl_ok && e->use_cluster && e->ws_ok && e->cl_flags != nullptr && e->in_tmask == nullptr &&
+                           N >= e->ws_min_rows &&
+                           mibc_launch_lstm_layer_ws(e->stream, e->C, cur, nxt, e->lstm_w16[l], e->lstm_bn[l], e->lstm_zero,
+                                                     e->cl_cstate, e->cl_flags, e->cl_err, T, N, reverse) == 0;
+        if (cl_ok || ws_ok) {
             e->cl_used = true;
         } else if (e->in_tmask != nullptr) {
             if (mibc_launch_lstm_layer_masked(e->stream, e->C, cur, nxt, e->C >= 512 ? e->lstm_w[l] : e->lstm_w16[l],
@@ -582,13 +595,21 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     }
     e->lstm_out = cur;
     if (e->cl_used)   // hand-off time-outs of the cluster kernel surface at the next stream synchronisation
-        HIP_OK(e, hipMemcpyAsync(e->cl_err_host, e->cl_err, 4, hipMemcpyDeviceToHost, e->stream));
+        HIP_OK(e, hipMemcpyAsync(e->cl_err_host, e->cl_err, 16, hipMemcpyDeviceToHost, e->stream));
     HIP_OK(e, hipGetLastError());
     return MIBC_OK;
 }
 
 // after a stream synchronisation: did a cluster hand-off of the LSTM kernel time out?
 static int check_cluster_error(mibc_engine *e) {
+#ifdef MIBC_DEBUG_KERNELS
+    if (e->cl_err_host && (e->cl_err_host[1] | e->cl_err_host[2] | e->cl_err_host[3])) {
+        fprintf(stderr, "[mibc dbg] cluster hand-off: slow-path entries %u, worst lag %u, real waits %u\n", e->cl_err_host[1],
+                e->cl_err_host[2], e->cl_err_host[3]);
+        e->cl_err_host[1] = e->cl_err_host[2] = e->cl_err_host[3] = 0;
+        (void)hipMemsetAsync(e->cl_err, 0, 16, e->stream);
+    }
+#endif
     if (e->cl_err_host && e->cl_err_host[0] != 0) {
         const unsigned w = e->cl_err_host[0];
         e->cl_err_host[0] = 0;

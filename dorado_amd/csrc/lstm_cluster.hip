@@ -28,8 +28,7 @@
 // Every spin is bounded: on a time-out the workgroup records an error word, stops waiting for the
 // rest of the launch (results are garbage, the kernel still terminates) and the host reports it.
 #include "common.h"
-
-#include <utility>
+#include "cluster_util.h"
 
 #define CL_ROWS 256
 #define CL_BK 32
@@ -46,32 +45,6 @@
 #define CL_OFF_FLAGZ (CL_OFF_BIAS + 2 * 2 * 4 * 32 * 4)
 #define CL_OFF_SYNC (CL_OFF_FLAGZ + 256)
 #define CL_LDS_BYTES (CL_OFF_SYNC + 64)
-
-typedef __attribute__((address_space(1))) unsigned int gu32;
-
-// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) — a guaranteed full unroll
-template <typename F, int... I>
-__device__ __forceinline__ void cl_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void cl_static_for(F &&f) {
-    cl_static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-// LDS destinations are passed as byte addresses inside the workgroup's LDS allocation (wave-uniform)
-typedef __attribute__((address_space(3))) void *lds_vptr;
-#define LDSP(T) __attribute__((address_space(3))) T *
-typedef const __attribute__((address_space(1))) half_t *ghalf_p;   // global-address-space pointer (no generic selects)
-__device__ __forceinline__ void cl_dma16(ghalf_p g, unsigned lds_addr) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (lds_vptr)(size_t)lds_addr, 16, 0, 0);
-}
-__device__ __forceinline__ void cl_dma16_sc1(ghalf_p g, unsigned lds_addr) {   // agent-scope (L1 bypass) load
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (lds_vptr)(size_t)lds_addr, 16, 0, 16);
-}
-__device__ __forceinline__ void cl_dma4_sc1(const unsigned *g, unsigned lds_addr) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (lds_vptr)(size_t)lds_addr, 4, 0, 16);
-}
 
 // One launch = one layer.  grid = KCL * (clusters resident at once); a workgroup loops over the row
 // groups (clusters of 256 rows) rg = first, first + stride, ... so that N may exceed one residency.

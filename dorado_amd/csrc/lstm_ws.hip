@@ -1,0 +1,442 @@
+// dorado_amd/csrc/lstm_ws.hip — WEIGHT-STATIONARY CU-cluster LSTM layer for C = 384 (hac@v4.3).
+// Same semantics as lstm.hip (torch LSTM, dorado/nn/LSTMStack.cpp:19-41; replaces host_cutlass_lstm,
+// LSTMStack.cpp:193) and, element for element, the same arithmetic as lstm_layer_x8_kernel (same MFMA shape,
+// same k order, same gate functions): the two are bit-identical.
+//
+// Why: lstm_layer_x8_kernel re-streams the layer's 2.36 MB of weights from L2 on every one of T time steps in every
+// CU (64 rows per CU): 64 B/clk/CU, exactly the CU's L2 port, which together with the LDS fragment reads and the
+// power-limited clock holds it at 0.45 of the MFMA peak.  Here the weights never move: KCL = C/64 = 6 workgroups of
+// one XCD (one per CU, 4 waves, ONE wave per SIMD with the whole 512-register file) form a cluster; member j owns
+// hidden units [64 j, 64 j + 64), wave w of it the 16 units [64 j + 16 w, +16) = 4 gates x 16 columns x 2C = 768
+// weights per lane pair ... i.e. 96 MFMA A-fragments = 384 registers per lane, resident for the whole launch
+// (256 in AGPRs, fed to v_mfma_f32_16x16x32_f16 directly as srcA, 128 in VGPRs).
+// A cluster owns R row tiles of 16 batch rows; per time step it walks them: for row tile r the activations
+// [x_t | h_{t-1}] (16 rows x 768, 24 KB) and the tile's fp32 cell state (4 KB) arrive by direct LDS DMA through a
+// 5-stage ring, every wave runs 24 k-steps x 4 gate MFMAs on the shared tile and applies the gates to its 16 x 16
+// block, with the gate math of tile i-1 interleaved between the MFMAs of tile i (the single wave of a SIMD is its
+// own latency hiding).  h_t leaves as 16-byte write-through stores into Xout[t] — the layer output IS the exchange
+// buffer — and is read back by all six members R tiles (one time step) later, so the hand-off latency is hidden by
+// construction; progress counters per (member, wave) make it safe (cdna_hip_programming.md §6 Guideline 16 R1):
+// a wave publishes "tiles complete" only after a counted s_waitcnt has retired its h stores, a consumer checks a
+// DMA-fetched snapshot of the 24 counters before it requests rows of h_{t-1} (bounded poll as the slow path).
+// No VGPR-returning global load exists inside the loop, so the compiler never drains the DMA queue.
+#include "common.h"
+#include "cluster_util.h"
+
+#define WS_TR 16                  // batch rows per tile
+#define WS_D 3                    // tiles of DMA look-ahead
+#define WS_NST (WS_D + 2)         // ring stages
+#define WS_SPIN_LIMIT 400000u
+#define WS_RMIN (2 * WS_D + 4)    // fewest row tiles per cluster (progress is published D + 1 tiles late)
+
+typedef float float4v_ws __attribute__((ext_vector_type(4)));
+
+// weights in AGPRs: srcA of the MFMA read straight from the accumulation register file
+__device__ __forceinline__ float4v_ws ws_mfma_a(half8_t wa, half8_t b, float4v_ws c) {
+    asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "a"(wa), "v"(b));
+    return c;
+}
+// (inline asm as well: with the builtin the register allocator moves the accumulators into AGPRs and evicts resident
+// weights; the hazard recogniser does not see asm MFMAs, so the loop ends with explicit wait states)
+__device__ __forceinline__ float4v_ws ws_mfma_v(half8_t wv, half8_t b, float4v_ws c) {
+    asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(wv), "v"(b));
+    return c;
+}
+
+template <int C>
+struct WsLayout {
+    static constexpr int KCL = C / 64;
+    static constexpr int KSX = C / 32;
+    static constexpr int KS = 2 * KSX;
+    static constexpr int KA = KS < 16 ? KS : 16;              // k-steps whose weights live in AGPRs (256 registers)
+    static constexpr int ACT = KS * 1024;                     // bytes of one activation tile
+    static constexpr int STAGE = ACT + 4096;                  // + the tile's cell state (4 waves x 1 KiB)
+    static constexpr int OFF_PATCH = WS_NST * STAGE;          // [4 waves][16 rows][24 halfs]
+    static constexpr int OFF_BIAS = OFF_PATCH + 4 * 768;      // [4 waves][4 gates][16] f32
+    static constexpr int OFF_FLAGZ = OFF_BIAS + 1024;         // [4 waves][64] u32 snapshot of the cluster's counters
+    static constexpr int BYTES = OFF_FLAGZ + 1024;
+    static constexpr int NF = KCL * 4;                        // counters per cluster (member x wave)
+    static constexpr int OPS = 11;                            // VMEM operations per wave and iteration (see loop)
+    static constexpr int NWAIT = OPS * (WS_D - 1) + 2;        // outstanding operations younger than tile i's DMAs
+};
+
+// DBG (debug build only; results are wrong when non-zero): 1 no gate math, 2 no DMA after the prologue, 4 no MFMA,
+// 8 no hand-off check, 16 no fragment reads.
+template <int C, int DBG = 0>
+__global__ __launch_bounds__(256) void lstm_layer_ws_kernel(
+        const half_t *__restrict__ Xin,     // [T][N][C]
+        half_t *__restrict__ Xout,          // [T][N][C]
+        const half_t *__restrict__ Wf16,    // [C/16][2C/32][4][64][8]: lstm_layer_x8_kernel's fragment order
+        const float *__restrict__ biasn,    // [4C]: [(hidden/32)][4][32]  (b_ih + b_hh)
+        const half_t *__restrict__ zeros,   // >= 16 KiB of zeros (h_{-1}, c_{-1})
+        float *__restrict__ cbuf,           // [nclusters][KCL][rmax][4 waves][64][4] f32 cell state (private layout)
+        unsigned *__restrict__ flags,       // [nclusters][KCL * 4][16]: tiles complete (zeroed per launch)
+        unsigned *__restrict__ err,         // [4]: sticky error word
+        int T, int N, int reverse, int cpx /* clusters per XCD, 0 = linear map */, int nclusters, int rmax) {
+    using L = WsLayout<C>;
+    constexpr int KCL = L::KCL, KSX = L::KSX, KS = L::KS, KA = L::KA, NF = L::NF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LDSP(unsigned char) smem3 = (LDSP(unsigned char))smem;
+    const unsigned lds0 = (unsigned)(size_t)smem3;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    int cl, j;
+    {
+        const int b = blockIdx.x;
+        if (cpx > 0) {
+            const int xcd = b & 7, slot = b >> 3;
+            cl = xcd * cpx + slot / KCL;
+            j = slot % KCL;
+        } else {
+            cl = b / KCL;
+            j = b % KCL;
+        }
+    }
+    if (cl >= nclusters) return;
+    const bool xcd_local = cpx > 0;   // every member of the cluster runs on the same XCD (verified below)
+    const int ntiles = N / WS_TR;
+    const int rbase = ntiles / nclusters, rrem = ntiles % nclusters;
+    const int R = rbase + (cl < rrem ? 1 : 0);
+    const int n0 = (cl * rbase + (cl < rrem ? cl : rrem)) * WS_TR;
+
+    // ---- resident weights: hidden tile jt = 4 j + wave, fragment (ks, g) ----
+    const int jt = j * 4 + wave;
+    half8_t w[KS][4];
+    {
+        const half_t *wp = Wf16 + (size_t)jt * KS * 4 * 512 + lane * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) w[ks][g] = *(const half8_t *)(wp + (ks * 4 + g) * 512);
+    }
+    {
+        LDSP(float) bias_s = (LDSP(float))(smem3 + L::OFF_BIAS);
+        const int ww = tid >> 6, g = (tid >> 4) & 3, u = tid & 15, jw = j * 4 + ww;
+        bias_s[tid] = biasn[((jw >> 1) * 4 + g) * 32 + (jw & 1) * 16 + u];
+        LDSP(unsigned) fz = (LDSP(unsigned))(smem3 + L::OFF_FLAGZ);
+        fz[tid] = 0u;
+    }
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    // ---- per-lane constants ----
+    // DMA: one instruction fills one k-step block [16 rows][64 B]: lane -> (row = lane / 4, physical 16-byte column
+    // lane % 4) <- logical column (lane % 4) ^ ((row >> 2) & 3); the fragment read applies the same XOR.
+    const int drow = lane >> 2;
+    const unsigned dcol = (unsigned)(((lane & 3) ^ ((drow >> 2) & 3)) * 16);
+    const unsigned lane_off = (unsigned)(drow * C * 2) + dcol;   // bytes
+    const unsigned lane_off_z = dcol;
+    const unsigned foff = (unsigned)(l15 * 64 + ((lq ^ ((l15 >> 2) & 3)) << 4));
+    const unsigned long long x0 = (unsigned long long)Xin, o0 = (unsigned long long)Xout, z0 = (unsigned long long)zeros;
+    const unsigned long long c0 = (unsigned long long)(cbuf + ((((size_t)cl * KCL + j) * rmax) * 4 + wave) * 256);
+    gu32 *clflags = (gu32 *)(flags + (size_t)cl * NF * 16);
+    gu32 *myflag = (gu32 *)(flags + ((size_t)cl * NF + j * 4 + wave) * 16);
+    const unsigned flag_lane = (unsigned)((lane < NF ? lane : 0) * 64);   // bytes
+    LDSP(const volatile unsigned) my_fz = (LDSP(const volatile unsigned))(smem3 + L::OFF_FLAGZ + wave * 256) + lane;
+    LDSP(half_t) patch = (LDSP(half_t))(smem3 + L::OFF_PATCH + wave * 768);
+    LDSP(const float) my_bias = (LDSP(const float))(smem3 + L::OFF_BIAS) + wave * 64 + 4 * lq;
+    bool dead = false;
+
+    // Tile addresses are kept as running byte offsets (no multiplications in the loop; the single wave of a SIMD
+    // pays for every scalar instruction with an issue slot): rel = offset of the tile's 16 rows at its time step,
+    // the same in Xin (x_t) and Xout (h_t); h_{t-1} of the tile is Xout + rel - dstep.
+    const long long dstep = (reverse ? -1LL : 1LL) * (long long)N * C * 2;   // bytes per time step
+    const long long tile_b = (long long)WS_TR * C * 2;                         // bytes per row tile
+    const long long wrap_b = dstep - (long long)(R - 1) * tile_b;              // last tile of a step -> first of the next
+    const long long rel0 = ((long long)(reverse ? (T - 1) : 0) * N + n0) * C * 2;
+
+    // DMA requests of one tile into ring slot at byte offset slot_b: flags snapshot, 6 activation blocks (k-steps
+    // wave, wave + 4, ...: the first KSX / 4 from x_t, the rest from h_{t-1}), the cell-state block.
+    auto fetch = [&](long long rel, bool first, unsigned ctile_b, unsigned slot_b) __attribute__((always_inline)) {
+        unsigned long long xb = x0 + (unsigned long long)rel;
+        unsigned long long hb = first ? z0 : o0 + (unsigned long long)(rel - dstep);
+        unsigned long long cb = first ? z0 : c0 + ctile_b;
+        unsigned long long fb = (unsigned long long)clflags;
+        asm volatile("" : "+s"(xb));
+        asm volatile("" : "+s"(hb));
+        asm volatile("" : "+s"(cb));
+        asm volatile("" : "+s"(fb));
+        const unsigned hoff = first ? lane_off_z : lane_off;
+        const unsigned l = lds0 + slot_b;
+        cl_dma4_sc1((const unsigned *)(fb + flag_lane), lds0 + L::OFF_FLAGZ + wave * 256);
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+            const int ks = 4 * q + wave;
+            if (q < KSX / 4)
+                cl_dma16_sc1((ghalf_p)(xb + lane_off + (unsigned)(ks * 64)), l + (unsigned)ks * 1024u);
+            else
+                cl_dma16_sc1((ghalf_p)(hb + hoff + (unsigned)((ks - KSX) * 64)), l + (unsigned)ks * 1024u);
+        }
+        cl_dma16_sc1((ghalf_p)(cb + (unsigned)(lane * 16)), l + L::ACT + (unsigned)wave * 1024u);
+    };
+
+    const int total = T * R;
+    // next tile to request: index f, step fs (only "== 0" matters), row tile fr
+    int fs = 0, fr = 0;
+    long long frel = rel0;
+    unsigned fslot_b = 0;
+    auto advance_f = [&]() __attribute__((always_inline)) {
+        if (++fr == R) {
+            fr = 0;
+            ++fs;
+            frel += wrap_b;
+        } else {
+            frel += tile_b;
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < WS_D; ++d) {
+        fetch(frel, true, 0u, fslot_b);
+        fslot_b = (fslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : fslot_b + L::STAGE;
+        advance_f();
+    }
+
+    float4v_ws pa[4];                  // accumulators of the previous tile (its gates run under this tile's MFMAs)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pa[g] = (float4v_ws)(0.0f);
+    // tile whose MFMAs run in this iteration: row tile cr, offset crel, ring slot cslot_b; previous tile: p*
+    int cr = 0, pr = 0;
+    long long crel = rel0, prel = rel0;
+    unsigned cslot_b = 0, pslot_b = 0;
+
+#pragma nounroll
+    for (int i = 0; i <= total; ++i) {
+        // ---- tile i has landed (own requests: counted wait; the other waves': barrier) ----
+        if (DBG & 2) {
+            // ablation: no DMA -> nothing to wait for (the stores just flow)
+        } else if (i <= WS_D) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NWAIT) : "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- publish: the wait above retired every store of iterations <= i - D - 1, i.e. tiles 0 .. i - D - 2 ----
+        {
+            const int p = i - WS_D - 1;
+            if (!(DBG & 32)) {
+                if (xcd_local)   // members share one L2: a plain (write-back) store is visible to their sc1 loads
+                    __hip_atomic_store(myflag, (unsigned)(p > 0 ? p : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else
+                    __hip_atomic_store(myflag, (unsigned)(p > 0 ? p : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---- request tile i + D; its h rows were produced as tile i + D - R by all members ----
+        {
+            const int f = i + WS_D;
+            if (f < total && fs > 0 && !(DBG & 8) && !dead) {
+                const unsigned need = (unsigned)(f - R + 1);
+                const unsigned snap = *my_fz;
+                if (!__all(lane >= NF || snap >= need)) {
+#ifdef MIBC_DEBUG_KERNELS
+                    if (lane == 0) atomicAdd(err + 1, 1u);           // slow-path entries
+                    if (lane < NF && snap < need) atomicMax(err + 2, need - snap);   // worst lag seen
+#endif
+                    // slow path: refresh the snapshot by DMA and re-read it.  (No VGPR-returning global load may exist in
+                    // this loop: beside LDS-DMA traffic hipcc then drains vmcnt(0) before the first ds_read of EVERY
+                    // iteration.  A drain here is harmless for the counted waits: they only rely on issue order.)
+                    unsigned spins = 0;
+                    bool good;
+                    do {
+                        cl_dma4_sc1((const unsigned *)((unsigned long long)clflags + flag_lane),
+                                    lds0 + L::OFF_FLAGZ + wave * 256);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        const unsigned v = *my_fz;
+                        good = __all(lane >= NF || v >= need);
+                        if (!good) __builtin_amdgcn_s_sleep(8);
+                    } while (!good && ++spins < WS_SPIN_LIMIT);
+#ifdef MIBC_DEBUG_KERNELS
+                    if (lane == 0 && spins > 0) atomicAdd(err + 3, 1u);   // entries that really had to wait
+#endif
+                    if (!good) {
+                        dead = true;
+                        if (lane == 0) atomicCAS(err, 0u, 0x80000000u | ((unsigned)cl << 16) | (unsigned)(fs & 0xffff));
+                    }
+                }
+            }
+            if (!(DBG & 2) || i < R) fetch(frel, fs == 0, (unsigned)fr * 4096u, fslot_b);
+            fslot_b = (fslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : fslot_b + L::STAGE;
+            if (f + 1 < total) advance_f();   // past the end the last tile is requested again (nobody reads it)
+        }
+
+        // ---- MFMAs of tile i, gates of tile i - 1 in between (iteration 0 runs the gate math on zeros for a
+        // non-existent tile -1 and stores it where tile 0's results follow from the same wave, in order) ----
+        LDSP(const unsigned char) sp = smem3 + cslot_b + foff;
+        LDSP(const unsigned char) spc = smem3 + pslot_b + L::ACT + wave * 1024 + lane * 16;
+        float4v_ws acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = *(LDSP(const float4v_ws))(my_bias + g * 16);
+        half8_t bq[3];
+        if (DBG & 16) {
+            bq[0] = (half8_t)((half_t)0.001f);
+            bq[1] = (half8_t)((half_t)0.002f);
+            bq[2] = (half8_t)((half_t)0.003f);
+        } else {
+            bq[0] = *(LDSP(const half8_t))(sp);
+            bq[1] = *(LDSP(const half8_t))(sp + 1024);
+        }
+        float4v_ws cv = (float4v_ws)(0.0f), cn = (float4v_ws)(0.0f);
+        float sv[4][4];
+        half4_t hv = (half4_t)((half_t)0.0f);
+        cl_static_for<KS>([&](auto ks_c) __attribute__((always_inline)) {
+            constexpr int ks = decltype(ks_c)::value;
+            if (!(DBG & 16) && ks + 2 < KS) bq[(ks + 2) % 3] = *(LDSP(const half8_t))(sp + (ks + 2) * 1024);
+            if (!(DBG & 4)) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (ks < KA)
+                        acc[g] = ws_mfma_a(w[ks][g], bq[ks % 3], acc[g]);
+                    else
+                        acc[g] = ws_mfma_v(w[ks][g], bq[ks % 3], acc[g]);
+                }
+            } else {
+                asm volatile("" ::"v"(bq[ks % 3]));
+            }
+            // ---- one piece of the previous tile's gate math (D row = hidden 4 lq + e, D col = batch row l15) ----
+            if constexpr (ks == 0) cv = *(LDSP(const float4v_ws))spc;
+            if constexpr (ks < 16) {
+                constexpr int g = ks & 3, e = ks >> 2;
+                if (DBG & 1)
+                    sv[g][e] = pa[g][e];
+                else
+                    sv[g][e] = (g == 2) ? fast_tanh(pa[g][e]) : fast_sigmoid(pa[g][e]);
+            } else if constexpr (ks < 20) {
+                constexpr int e = ks - 16;
+                if (DBG & 1) {
+                    cn[e] = cv[e];
+                    hv[e] = (half_t)(1e-3f * (sv[0][e] + sv[1][e] + sv[2][e] + sv[3][e]));
+                } else {
+                    const float c = fmaf(sv[1][e], cv[e], sv[0][e] * sv[2][e]);
+                    cn[e] = c;
+                    hv[e] = (half_t)(sv[3][e] * fast_tanh(c));
+                }
+            } else if constexpr (ks == 20) {
+                *(LDSP(half4_t))(patch + l15 * 24 + 4 * lq) = hv;
+                // cell state back to its private tile (read again one time step = R tiles later)
+                if (!(DBG & 32)) *(float4v_ws *)(c0 + (size_t)pr * 4096 + (unsigned)(lane * 16)) = cn;
+            } else if constexpr (ks == 21) {
+                __builtin_amdgcn_wave_barrier();
+                const int prow = lane >> 1, seg = lane & 1;
+                const half8_t v = *(LDSP(const half8_t))(patch + prow * 24 + seg * 8);
+                const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+                        (void *)(o0 + (unsigned long long)prel), 0, WS_TR * C * 2, 0x00020000);
+                if (lane < 32 && !(DBG & 32)) {
+                    const auto vv = __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v);
+                    const int so = (prow * C + j * 64 + wave * 16 + seg * 8) * 2;
+                    if (xcd_local)
+                        __builtin_amdgcn_raw_buffer_store_b128(vv, ors, so, 0, 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(vv, ors, so, 0, 16 /* sc1: write-through */);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // XDL write -> VALU read of the accumulators (copies / next iteration's gate math): 18 wait states
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pa[g] = acc[g];
+        pr = cr;
+        prel = crel;
+        pslot_b = cslot_b;
+        cslot_b = (cslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : cslot_b + L::STAGE;
+        if (++cr == R) {
+            cr = 0;
+            crel += wrap_b;
+        } else {
+            crel += tile_b;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+extern "C" size_t mibc_lstm_ws_lds_bytes(int C) { return C == 384 ? (size_t)WsLayout<384>::BYTES : 0; }
+
+// geometry of a launch: clusters, row tiles per cluster (max), clusters per XCD (0 = linear map); 0 if not covered
+static int ws_geometry(int C, int N, int *nclusters, int *rmax, int *cpx) {
+    if (C != 384 || N % WS_TR != 0) return 0;
+    static int ncu = 0;
+    if (ncu == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int KCL = C / 64;
+    const int ntiles = N / WS_TR;
+    const int per_xcd = (ncu / 8) / KCL;          // clusters whose members share one XCD
+    int ncl = per_xcd * 8;
+    if (ncl < 1) return 0;
+    if (ntiles / ncl < WS_RMIN) ncl = ntiles / WS_RMIN;
+    if (ncl < 1) return 0;
+    *nclusters = ncl;
+    *rmax = (ntiles + ncl - 1) / ncl;
+    *cpx = (ncl % 8 == 0) ? ncl / 8 : 0;
+    return 1;
+}
+
+extern "C" size_t mibc_lstm_ws_cstate_bytes(int C, int N) {
+    int ncl, rmax, cpx;
+    if (!ws_geometry(C, N, &ncl, &rmax, &cpx)) return 0;
+    return (size_t)ncl * (C / 64) * rmax * 4096;
+}
+extern "C" size_t mibc_lstm_ws_flag_bytes(int C, int N) {
+    int ncl, rmax, cpx;
+    if (!ws_geometry(C, N, &ncl, &rmax, &cpx)) return 0;
+    return (size_t)ncl * (C / 64) * 4 * 16 * sizeof(unsigned);
+}
+
+// Returns 0 if launched, 1 if the shape is not covered (caller falls back to lstm_layer_x8_kernel).
+extern "C" int mibc_launch_lstm_layer_ws(hipStream_t s, int C, const half_t *Xin, half_t *Xout, const half_t *Wf16,
+                                         const float *biasn, const half_t *zeros, float *cbuf, unsigned *flags,
+                                         unsigned *err, int T, int N, int reverse) {
+    if (!Wf16 || !biasn || !zeros || !cbuf || !flags || !err) return 1;
+    int ncl, rmax, cpx;
+    if (!ws_geometry(C, N, &ncl, &rmax, &cpx)) return 1;
+    using L = WsLayout<384>;
+    const dim3 grid(ncl * L::KCL);
+    if (hipMemsetAsync(flags, 0, mibc_lstm_ws_flag_bytes(C, N), s) != hipSuccess) return 1;
+#define WS_LAUNCH(D_)                                                                                              \
+    do {                                                                                                           \
+        static bool once = false;                                                                                  \
+        if (!once) {                                                                                               \
+            (void)hipFuncSetAttribute((const void *)lstm_layer_ws_kernel<384, D_>,                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);                       \
+            once = true;                                                                                           \
+        }                                                                                                          \
+        hipLaunchKernelGGL((lstm_layer_ws_kernel<384, D_>), grid, dim3(256), L::BYTES, s, Xin, Xout, Wf16, biasn, \
+                           zeros, cbuf, flags, err, T, N, reverse, cpx, ncl, rmax);                                \
+    } while (0)
+#ifdef MIBC_DEBUG_KERNELS
+    static const int dbg = MIBC_ENV_INT("MIBC_WS_LSTM_DBG", 0);
+    switch (dbg) {
+        case 1: WS_LAUNCH(1); return 0;
+        case 2: WS_LAUNCH(2); return 0;
+        case 4: WS_LAUNCH(4); return 0;
+        case 8: WS_LAUNCH(8); return 0;
+        case 16: WS_LAUNCH(16); return 0;
+        case 18: WS_LAUNCH(18); return 0;
+        case 19: WS_LAUNCH(19); return 0;
+        case 27: WS_LAUNCH(27); return 0;
+        case 6: WS_LAUNCH(6); return 0;
+        case 14: WS_LAUNCH(14); return 0;
+        case 46: WS_LAUNCH(46); return 0;
+        case 59: WS_LAUNCH(59); return 0;
+        case 63: WS_LAUNCH(63); return 0;
+        case 10: WS_LAUNCH(10); return 0;
+        case 42: WS_LAUNCH(42); return 0;
+        case 32: WS_LAUNCH(32); return 0;
+        case 40: WS_LAUNCH(40); return 0;
+        case 36: WS_LAUNCH(36); return 0;
+        default: break;
+    }
+#endif
+    WS_LAUNCH(0);
+#undef WS_LAUNCH
+    return 0;
+}
