@@ -115,7 +115,7 @@ struct mibc_engine {
     unsigned *cl_err_host = nullptr; // pinned copy, checked after every stream synchronisation
     bool cl_used = false;
     bool ws_ok = false;              // lstm_ws.hip covers this width
-    int ws_min_rows = 2048;          // smallest batch that takes the weight-stationary kernel
+    int ws_min_rows = 1 << 30;       // smallest batch that takes the weight-stationary kernel (default: never)
     int use_cluster = 1;             // debug build: MIBC_LSTM_CLUSTER=0 forces the per-workgroup kernels
     half_t *head_w1 = nullptr, *head_w2 = nullptr;
     float *head_b1 = nullptr;

@@ -300,7 +300,7 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
     }
     e->use_ws = MIBC_ENV_INT("MIBC_WSGEMM", 1);
     e->use_cluster = MIBC_ENV_INT("MIBC_LSTM_CLUSTER", 1);
-    e->ws_min_rows = MIBC_ENV_INT("MIBC_WS_MIN_ROWS", 2048);
+    e->ws_min_rows = MIBC_ENV_INT("MIBC_WS_MIN_ROWS", 1 << 30);   // off: see mibc_debug_set_ws_min_rows
     const char *tp = getenv("MIBC_TAPS");
     e->taps = tp ? atoi(tp) : 0;
     // weight uploads are null-stream copies from pageable memory: hipMemcpy may return once the data sits
@@ -1149,6 +1149,13 @@ extern "C" int mibc_time_forward(mibc_engine *e, int N, int T_in, float *ms_out)
     (void)hipEventDestroy(b);
     if (rc != MIBC_OK) return rc;
     *ms_out = best;
+    return MIBC_OK;
+}
+
+extern "C" int mibc_debug_set_ws_min_rows(mibc_engine *e, int min_rows) {
+    if (!e) return fail(nullptr, MIBC_ERR_ARG, "null engine");
+    if (!e->ws_ok) return fail(e, MIBC_NOT_SUPPORTED, "the weight-stationary LSTM kernel covers lstm_size 384 only");
+    e->ws_min_rows = min_rows > 0 ? min_rows : (1 << 30);
     return MIBC_OK;
 }
 

@@ -1,43 +1,47 @@
 // dorado_amd/csrc/lstm_ws.hip — WEIGHT-STATIONARY CU-cluster LSTM layer for C = 384 (hac@v4.3).
 // Same semantics as lstm.hip (torch LSTM, dorado/nn/LSTMStack.cpp:19-41; replaces host_cutlass_lstm,
 // LSTMStack.cpp:193) and, element for element, the same arithmetic as lstm_layer_x8_kernel (same MFMA shape,
-// same k order, same gate functions): the two are bit-identical.
+// same k order per accumulator, same gate functions): the two are bit-identical.
 //
 // Why: lstm_layer_x8_kernel re-streams the layer's 2.36 MB of weights from L2 on every one of T time steps in every
 // CU (64 rows per CU): 64 B/clk/CU, exactly the CU's L2 port, which together with the LDS fragment reads and the
 // power-limited clock holds it at 0.45 of the MFMA peak.  Here the weights never move: KCL = C/64 = 6 workgroups of
-// one XCD (one per CU, 4 waves, ONE wave per SIMD with the whole 512-register file) form a cluster; member j owns
-// hidden units [64 j, 64 j + 64), wave w of it the 16 units [64 j + 16 w, +16) = 4 gates x 16 columns x 2C = 768
-// weights per lane pair ... i.e. 96 MFMA A-fragments = 384 registers per lane, resident for the whole launch
-// (256 in AGPRs, fed to v_mfma_f32_16x16x32_f16 directly as srcA, 128 in VGPRs).
-// A cluster owns R row tiles of 16 batch rows; per time step it walks them: for row tile r the activations
-// [x_t | h_{t-1}] (16 rows x 768, 24 KB) and the tile's fp32 cell state (4 KB) arrive by direct LDS DMA through a
-// 5-stage ring, every wave runs 24 k-steps x 4 gate MFMAs on the shared tile and applies the gates to its 16 x 16
-// block, with the gate math of tile i-1 interleaved between the MFMAs of tile i (the single wave of a SIMD is its
-// own latency hiding).  h_t leaves as 16-byte write-through stores into Xout[t] — the layer output IS the exchange
+// one XCD (one per CU, 8 waves) form a cluster; member j owns hidden units [64 j, 64 j + 64); the two waves of SIMD
+// s own the 16 units [64 j + 16 s, +16): the X-WAVE keeps the W_ih fragments of those units' four gates (12 k-steps
+// x 4 gates x 4 registers = 192 registers), the H-WAVE the W_hh fragments — resident for the whole launch (128 in
+// AGPRs, read by v_mfma_f32_16x16x32_f16 directly as srcA).
+// A cluster owns R row tiles of 16 batch rows; per time step it walks them.  For tile i the x-wave computes
+// A = bias + x_t W_ih^T (12 k-steps) and hands the 16 x 16 x 4 accumulators to its partner through LDS; the h-wave
+// CONTINUES the same accumulators with h_{t-1} W_hh^T (so the summation order is exactly x8's), applies the gates,
+// keeps the fp32 cell state in a private scratch tile and stores its 16 x 16 block of h_t; the x-wave is one tile
+// ahead.  One wave of a SIMD feeds the matrix pipe while the other one issues DMAs / gate math.
+// Activations [x_t | h_{t-1}] (16 rows x 768, 24 KB) and the tile's cell state (4 KB) arrive by direct LDS DMA
+// (issued by the x-waves) through a 4-stage ring.  h_t goes into Xout[t] — the layer output IS the exchange
 // buffer — and is read back by all six members R tiles (one time step) later, so the hand-off latency is hidden by
-// construction; progress counters per (member, wave) make it safe (cdna_hip_programming.md §6 Guideline 16 R1):
-// a wave publishes "tiles complete" only after a counted s_waitcnt has retired its h stores, a consumer checks a
-// DMA-fetched snapshot of the 24 counters before it requests rows of h_{t-1} (bounded poll as the slow path).
-// No VGPR-returning global load exists inside the loop, so the compiler never drains the DMA queue.
+// construction; progress counters per (member, SIMD) make it safe (cdna_hip_programming.md §6 Guideline 16 R1):
+// an h-wave publishes "tiles complete" only after a counted s_waitcnt has retired its h stores, an x-wave checks a
+// DMA-fetched snapshot of the 24 counters before it requests rows of h_{t-1} (bounded DMA-refresh poll as the slow
+// path).  No VGPR-returning global load exists inside the loop (beside LDS-DMA traffic hipcc would drain vmcnt(0)
+// before the first ds_read of every iteration).
+// Measured history in DESIGN.md §4 (one wave per SIMD holding all 384 weight registers was issue-bound: 75 ms).
 #include "common.h"
 #include "cluster_util.h"
 
 #define WS_TR 16                  // batch rows per tile
-#define WS_D 3                    // tiles of DMA look-ahead
+#define WS_D 2                    // the request for tile i + 1 + D is issued in iteration i (x-waves run one tile ahead)
 #define WS_NST (WS_D + 2)         // ring stages
 #define WS_SPIN_LIMIT 400000u
-#define WS_RMIN (2 * WS_D + 4)    // fewest row tiles per cluster (progress is published D + 1 tiles late)
+#define WS_RMIN 10                // fewest row tiles per cluster (progress is published / observed a few tiles late)
 
 typedef float float4v_ws __attribute__((ext_vector_type(4)));
 
-// weights in AGPRs: srcA of the MFMA read straight from the accumulation register file
+// resident weights as srcA: from AGPRs ("a") or VGPRs ("v").  Inline asm on purpose: with the builtin the register
+// allocator moves the accumulators into AGPRs and evicts resident weights.  The hazard recogniser does not see asm
+// MFMAs, so every MFMA block ends with explicit wait states before its accumulators are read.
 __device__ __forceinline__ float4v_ws ws_mfma_a(half8_t wa, half8_t b, float4v_ws c) {
     asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "a"(wa), "v"(b));
     return c;
 }
-// (inline asm as well: with the builtin the register allocator moves the accumulators into AGPRs and evicts resident
-// weights; the hazard recogniser does not see asm MFMAs, so the loop ends with explicit wait states)
 __device__ __forceinline__ float4v_ws ws_mfma_v(half8_t wv, half8_t b, float4v_ws c) {
     asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(wv), "v"(b));
     return c;
@@ -46,30 +50,30 @@ __device__ __forceinline__ float4v_ws ws_mfma_v(half8_t wv, half8_t b, float4v_w
 template <int C>
 struct WsLayout {
     static constexpr int KCL = C / 64;
-    static constexpr int KSX = C / 32;
+    static constexpr int KSX = C / 32;                        // k-steps per half (x or h)
     static constexpr int KS = 2 * KSX;
-    static constexpr int KA = KS < 16 ? KS : 16;              // k-steps whose weights live in AGPRs (256 registers)
+    static constexpr int KA = KSX < 8 ? KSX : 8;              // k-steps of a wave whose weights live in AGPRs
     static constexpr int ACT = KS * 1024;                     // bytes of one activation tile
-    static constexpr int STAGE = ACT + 4096;                  // + the tile's cell state (4 waves x 1 KiB)
-    static constexpr int OFF_PATCH = WS_NST * STAGE;          // [4 waves][16 rows][24 halfs]
-    static constexpr int OFF_BIAS = OFF_PATCH + 4 * 768;      // [4 waves][4 gates][16] f32
-    static constexpr int OFF_FLAGZ = OFF_BIAS + 1024;         // [4 waves][64] u32 snapshot of the cluster's counters
+    static constexpr int STAGE = ACT + 4096;                  // + the tile's cell state (4 x 1 KiB)
+    static constexpr int OFF_HAND = WS_NST * STAGE;           // [2 slots][4 SIMDs][4 gates][64 lanes] float4
+    static constexpr int OFF_PATCH = OFF_HAND + 2 * 4 * 4096; // [4][16 rows][24 halfs]
+    static constexpr int OFF_BIAS = OFF_PATCH + 4 * 768;      // [4 SIMDs][4 gates][16] f32
+    static constexpr int OFF_FLAGZ = OFF_BIAS + 1024;         // [4][64] u32 snapshot of the cluster's counters
     static constexpr int BYTES = OFF_FLAGZ + 1024;
-    static constexpr int NF = KCL * 4;                        // counters per cluster (member x wave)
-    static constexpr int OPS = 11;                            // VMEM operations per wave and iteration (see loop)
-    static constexpr int NWAIT = OPS * (WS_D - 1) + 2;        // outstanding operations younger than tile i's DMAs
+    static constexpr int NF = KCL * 4;                        // counters per cluster (member x SIMD)
+    static constexpr int XOPS = KS / 4 + 2;                   // x-wave VMEM operations per iteration: flags, blocks, c
 };
 
 // DBG (debug build only; results are wrong when non-zero): 1 no gate math, 2 no DMA after the prologue, 4 no MFMA,
-// 8 no hand-off check, 16 no fragment reads.
+// 8 no hand-off check, 16 no fragment reads, 32 no global stores.
 template <int C, int DBG = 0>
-__global__ __launch_bounds__(256) void lstm_layer_ws_kernel(
+__global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
         const half_t *__restrict__ Xin,     // [T][N][C]
         half_t *__restrict__ Xout,          // [T][N][C]
         const half_t *__restrict__ Wf16,    // [C/16][2C/32][4][64][8]: lstm_layer_x8_kernel's fragment order
         const float *__restrict__ biasn,    // [4C]: [(hidden/32)][4][32]  (b_ih + b_hh)
         const half_t *__restrict__ zeros,   // >= 16 KiB of zeros (h_{-1}, c_{-1})
-        float *__restrict__ cbuf,           // [nclusters][KCL][rmax][4 waves][64][4] f32 cell state (private layout)
+        float *__restrict__ cbuf,           // [nclusters][KCL][rmax][4][64][4] f32 cell state (private layout)
         unsigned *__restrict__ flags,       // [nclusters][KCL * 4][16]: tiles complete (zeroed per launch)
         unsigned *__restrict__ err,         // [4]: sticky error word
         int T, int N, int reverse, int cpx /* clusters per XCD, 0 = linear map */, int nclusters, int rmax) {
@@ -82,6 +86,8 @@ __global__ __launch_bounds__(256) void lstm_layer_ws_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sim = wave & 3;              // waves w and w + 4 share SIMD w
+    const bool hwave = wave >= 4;
     const int l15 = lane & 15, lq = lane >> 4;
 
     int cl, j;
@@ -97,23 +103,23 @@ __global__ __launch_bounds__(256) void lstm_layer_ws_kernel(
         }
     }
     if (cl >= nclusters) return;
-    const bool xcd_local = cpx > 0;   // every member of the cluster runs on the same XCD (verified below)
+    const bool xcd_local = cpx > 0;   // every member of the cluster runs on the same XCD (they share one L2)
     const int ntiles = N / WS_TR;
     const int rbase = ntiles / nclusters, rrem = ntiles % nclusters;
     const int R = rbase + (cl < rrem ? 1 : 0);
     const int n0 = (cl * rbase + (cl < rrem ? cl : rrem)) * WS_TR;
 
-    // ---- resident weights: hidden tile jt = 4 j + wave, fragment (ks, g) ----
-    const int jt = j * 4 + wave;
-    half8_t w[KS][4];
+    // ---- resident weights: hidden tile jt = 4 j + sim; x-wave k-steps [0, KSX), h-wave [KSX, 2 KSX) ----
+    const int jt = j * 4 + sim;
+    half8_t w[KSX][4];
     {
-        const half_t *wp = Wf16 + (size_t)jt * KS * 4 * 512 + lane * 8;
+        const half_t *wp = Wf16 + ((size_t)jt * KS + (hwave ? KSX : 0)) * 4 * 512 + lane * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+        for (int ks = 0; ks < KSX; ++ks)
 #pragma unroll
             for (int g = 0; g < 4; ++g) w[ks][g] = *(const half8_t *)(wp + (ks * 4 + g) * 512);
     }
-    {
+    if (tid < 256) {
         LDSP(float) bias_s = (LDSP(float))(smem3 + L::OFF_BIAS);
         const int ww = tid >> 6, g = (tid >> 4) & 3, u = tid & 15, jw = j * 4 + ww;
         bias_s[tid] = biasn[((jw >> 1) * 4 + g) * 32 + (jw & 1) * 16 + u];
@@ -130,27 +136,28 @@ __global__ __launch_bounds__(256) void lstm_layer_ws_kernel(
     const unsigned dcol = (unsigned)(((lane & 3) ^ ((drow >> 2) & 3)) * 16);
     const unsigned lane_off = (unsigned)(drow * C * 2) + dcol;   // bytes
     const unsigned lane_off_z = dcol;
-    const unsigned foff = (unsigned)(l15 * 64 + ((lq ^ ((l15 >> 2) & 3)) << 4));
+    const unsigned foff = (unsigned)(l15 * 64 + ((lq ^ ((l15 >> 2) & 3)) << 4)) + (hwave ? KSX * 1024u : 0u);
     const unsigned long long x0 = (unsigned long long)Xin, o0 = (unsigned long long)Xout, z0 = (unsigned long long)zeros;
-    const unsigned long long c0 = (unsigned long long)(cbuf + ((((size_t)cl * KCL + j) * rmax) * 4 + wave) * 256);
+    const unsigned long long c0 = (unsigned long long)(cbuf + ((((size_t)cl * KCL + j) * rmax) * 4 + sim) * 256);
     gu32 *clflags = (gu32 *)(flags + (size_t)cl * NF * 16);
-    gu32 *myflag = (gu32 *)(flags + ((size_t)cl * NF + j * 4 + wave) * 16);
+    gu32 *myflag = (gu32 *)(flags + ((size_t)cl * NF + j * 4 + sim) * 16);
     const unsigned flag_lane = (unsigned)((lane < NF ? lane : 0) * 64);   // bytes
-    LDSP(const volatile unsigned) my_fz = (LDSP(const volatile unsigned))(smem3 + L::OFF_FLAGZ + wave * 256) + lane;
-    LDSP(half_t) patch = (LDSP(half_t))(smem3 + L::OFF_PATCH + wave * 768);
-    LDSP(const float) my_bias = (LDSP(const float))(smem3 + L::OFF_BIAS) + wave * 64 + 4 * lq;
+    LDSP(const volatile unsigned) my_fz = (LDSP(const volatile unsigned))(smem3 + L::OFF_FLAGZ + sim * 256) + lane;
+    LDSP(half_t) patch = (LDSP(half_t))(smem3 + L::OFF_PATCH + sim * 768);
+    LDSP(const float) my_bias = (LDSP(const float))(smem3 + L::OFF_BIAS) + sim * 64 + 4 * lq;
+    LDSP(unsigned char) hand = smem3 + L::OFF_HAND + sim * 4096 + lane * 16;   // + slot * 16 KiB + gate * 1 KiB
     bool dead = false;
 
-    // Tile addresses are kept as running byte offsets (no multiplications in the loop; the single wave of a SIMD
-    // pays for every scalar instruction with an issue slot): rel = offset of the tile's 16 rows at its time step,
-    // the same in Xin (x_t) and Xout (h_t); h_{t-1} of the tile is Xout + rel - dstep.
+    // Tile addresses are running byte offsets (no multiplications in the loop): rel = offset of the tile's 16 rows at
+    // its time step, the same in Xin (x_t) and Xout (h_t); h_{t-1} of the tile is Xout + rel - dstep.
     const long long dstep = (reverse ? -1LL : 1LL) * (long long)N * C * 2;   // bytes per time step
     const long long tile_b = (long long)WS_TR * C * 2;                         // bytes per row tile
     const long long wrap_b = dstep - (long long)(R - 1) * tile_b;              // last tile of a step -> first of the next
     const long long rel0 = ((long long)(reverse ? (T - 1) : 0) * N + n0) * C * 2;
+    const int total = T * R;
 
-    // DMA requests of one tile into ring slot at byte offset slot_b: flags snapshot, 6 activation blocks (k-steps
-    // wave, wave + 4, ...: the first KSX / 4 from x_t, the rest from h_{t-1}), the cell-state block.
+    // DMA requests of one tile (x-waves): flags snapshot, KS/4 activation blocks (k-steps sim, sim + 4, ...: the
+    // first KSX / 4 from x_t, the rest from h_{t-1}), the cell-state block of SIMD sim.
     auto fetch = [&](long long rel, bool first, unsigned ctile_b, unsigned slot_b) __attribute__((always_inline)) {
         unsigned long long xb = x0 + (unsigned long long)rel;
         unsigned long long hb = first ? z0 : o0 + (unsigned long long)(rel - dstep);
@@ -162,114 +169,21 @@ __global__ __launch_bounds__(256) void lstm_layer_ws_kernel(
         asm volatile("" : "+s"(fb));
         const unsigned hoff = first ? lane_off_z : lane_off;
         const unsigned l = lds0 + slot_b;
-        cl_dma4_sc1((const unsigned *)(fb + flag_lane), lds0 + L::OFF_FLAGZ + wave * 256);
+        cl_dma4_sc1((const unsigned *)(fb + flag_lane), lds0 + L::OFF_FLAGZ + sim * 256);
 #pragma unroll
         for (int q = 0; q < KS / 4; ++q) {
-            const int ks = 4 * q + wave;
+            const int ks = 4 * q + sim;
             if (q < KSX / 4)
                 cl_dma16_sc1((ghalf_p)(xb + lane_off + (unsigned)(ks * 64)), l + (unsigned)ks * 1024u);
             else
                 cl_dma16_sc1((ghalf_p)(hb + hoff + (unsigned)((ks - KSX) * 64)), l + (unsigned)ks * 1024u);
         }
-        cl_dma16_sc1((ghalf_p)(cb + (unsigned)(lane * 16)), l + L::ACT + (unsigned)wave * 1024u);
+        cl_dma16_sc1((ghalf_p)(cb + (unsigned)(lane * 16)), l + L::ACT + (unsigned)sim * 1024u);
     };
 
-    const int total = T * R;
-    // next tile to request: index f, step fs (only "== 0" matters), row tile fr
-    int fs = 0, fr = 0;
-    long long frel = rel0;
-    unsigned fslot_b = 0;
-    auto advance_f = [&]() __attribute__((always_inline)) {
-        if (++fr == R) {
-            fr = 0;
-            ++fs;
-            frel += wrap_b;
-        } else {
-            frel += tile_b;
-        }
-    };
-#pragma unroll
-    for (int d = 0; d < WS_D; ++d) {
-        fetch(frel, true, 0u, fslot_b);
-        fslot_b = (fslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : fslot_b + L::STAGE;
-        advance_f();
-    }
-
-    float4v_ws pa[4];                  // accumulators of the previous tile (its gates run under this tile's MFMAs)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) pa[g] = (float4v_ws)(0.0f);
-    // tile whose MFMAs run in this iteration: row tile cr, offset crel, ring slot cslot_b; previous tile: p*
-    int cr = 0, pr = 0;
-    long long crel = rel0, prel = rel0;
-    unsigned cslot_b = 0, pslot_b = 0;
-
-#pragma nounroll
-    for (int i = 0; i <= total; ++i) {
-        // ---- tile i has landed (own requests: counted wait; the other waves': barrier) ----
-        if (DBG & 2) {
-            // ablation: no DMA -> nothing to wait for (the stores just flow)
-        } else if (i <= WS_D) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NWAIT) : "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // ---- publish: the wait above retired every store of iterations <= i - D - 1, i.e. tiles 0 .. i - D - 2 ----
-        {
-            const int p = i - WS_D - 1;
-            if (!(DBG & 32)) {
-                if (xcd_local)   // members share one L2: a plain (write-back) store is visible to their sc1 loads
-                    __hip_atomic_store(myflag, (unsigned)(p > 0 ? p : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                else
-                    __hip_atomic_store(myflag, (unsigned)(p > 0 ? p : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        // ---- request tile i + D; its h rows were produced as tile i + D - R by all members ----
-        {
-            const int f = i + WS_D;
-            if (f < total && fs > 0 && !(DBG & 8) && !dead) {
-                const unsigned need = (unsigned)(f - R + 1);
-                const unsigned snap = *my_fz;
-                if (!__all(lane >= NF || snap >= need)) {
-#ifdef MIBC_DEBUG_KERNELS
-                    if (lane == 0) atomicAdd(err + 1, 1u);           // slow-path entries
-                    if (lane < NF && snap < need) atomicMax(err + 2, need - snap);   // worst lag seen
-#endif
-                    // slow path: refresh the snapshot by DMA and re-read it.  (No VGPR-returning global load may exist in
-                    // this loop: beside LDS-DMA traffic hipcc then drains vmcnt(0) before the first ds_read of EVERY
-                    // iteration.  A drain here is harmless for the counted waits: they only rely on issue order.)
-                    unsigned spins = 0;
-                    bool good;
-                    do {
-                        cl_dma4_sc1((const unsigned *)((unsigned long long)clflags + flag_lane),
-                                    lds0 + L::OFF_FLAGZ + wave * 256);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        const unsigned v = *my_fz;
-                        good = __all(lane >= NF || v >= need);
-                        if (!good) __builtin_amdgcn_s_sleep(8);
-                    } while (!good && ++spins < WS_SPIN_LIMIT);
-#ifdef MIBC_DEBUG_KERNELS
-                    if (lane == 0 && spins > 0) atomicAdd(err + 3, 1u);   // entries that really had to wait
-#endif
-                    if (!good) {
-                        dead = true;
-                        if (lane == 0) atomicCAS(err, 0u, 0x80000000u | ((unsigned)cl << 16) | (unsigned)(fs & 0xffff));
-                    }
-                }
-            }
-            if (!(DBG & 2) || i < R) fetch(frel, fs == 0, (unsigned)fr * 4096u, fslot_b);
-            fslot_b = (fslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : fslot_b + L::STAGE;
-            if (f + 1 < total) advance_f();   // past the end the last tile is requested again (nobody reads it)
-        }
-
-        // ---- MFMAs of tile i, gates of tile i - 1 in between (iteration 0 runs the gate math on zeros for a
-        // non-existent tile -1 and stores it where tile 0's results follow from the same wave, in order) ----
-        LDSP(const unsigned char) sp = smem3 + cslot_b + foff;
-        LDSP(const unsigned char) spc = smem3 + pslot_b + L::ACT + wave * 1024 + lane * 16;
-        float4v_ws acc[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = *(LDSP(const float4v_ws))(my_bias + g * 16);
+    // one half of a tile's MFMAs: KSX k-steps x 4 gates on the fragments of ring slot slot_b
+    auto half_tile = [&](float4v_ws (&acc)[4], unsigned slot_b) __attribute__((always_inline)) {
+        LDSP(const unsigned char) sp = smem3 + slot_b + foff;
         half8_t bq[3];
         if (DBG & 16) {
             bq[0] = (half8_t)((half_t)0.001f);
@@ -279,12 +193,9 @@ __global__ __launch_bounds__(256) void lstm_layer_ws_kernel(
             bq[0] = *(LDSP(const half8_t))(sp);
             bq[1] = *(LDSP(const half8_t))(sp + 1024);
         }
-        float4v_ws cv = (float4v_ws)(0.0f), cn = (float4v_ws)(0.0f);
-        float sv[4][4];
-        half4_t hv = (half4_t)((half_t)0.0f);
-        cl_static_for<KS>([&](auto ks_c) __attribute__((always_inline)) {
+        cl_static_for<KSX>([&](auto ks_c) __attribute__((always_inline)) {
             constexpr int ks = decltype(ks_c)::value;
-            if (!(DBG & 16) && ks + 2 < KS) bq[(ks + 2) % 3] = *(LDSP(const half8_t))(sp + (ks + 2) * 1024);
+            if (!(DBG & 16) && ks + 2 < KSX) bq[(ks + 2) % 3] = *(LDSP(const half8_t))(sp + (ks + 2) * 1024);
             if (!(DBG & 4)) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -296,59 +207,174 @@ __global__ __launch_bounds__(256) void lstm_layer_ws_kernel(
             } else {
                 asm volatile("" ::"v"(bq[ks % 3]));
             }
-            // ---- one piece of the previous tile's gate math (D row = hidden 4 lq + e, D col = batch row l15) ----
-            if constexpr (ks == 0) cv = *(LDSP(const float4v_ws))spc;
-            if constexpr (ks < 16) {
-                constexpr int g = ks & 3, e = ks >> 2;
-                if (DBG & 1)
-                    sv[g][e] = pa[g][e];
+        });
+        // XDL write -> VALU / LDS-store read of the accumulators: 18 wait states
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+    };
+
+    if (!hwave) {
+        // =========================== X-WAVES: DMA + x half, one tile ahead ===========================
+        int fs = 0, fr = 0;                 // next tile to request: step (only "== 0" matters), row tile
+        long long frel = rel0;
+        unsigned fslot_b = 0;
+        auto advance_f = [&]() __attribute__((always_inline)) {
+            if (++fr == R) {
+                fr = 0;
+                ++fs;
+                frel += wrap_b;
+            } else {
+                frel += tile_b;
+            }
+        };
+#pragma unroll
+        for (int d = 0; d <= WS_D; ++d) {   // tiles 0 .. D
+            fetch(frel, true, 0u, fslot_b);
+            fslot_b = (fslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : fslot_b + L::STAGE;
+            advance_f();
+        }
+        unsigned cslot_b = 0;               // ring slot of the tile whose x half is computed next
+        // x half of tile 0 (hand-off slot 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            float4v_ws acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = *(LDSP(const float4v_ws))(my_bias + g * 16);
+            half_tile(acc, cslot_b);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *(LDSP(float4v_ws))(hand + g * 1024) = acc[g];
+            cslot_b += L::STAGE;
+        }
+#pragma nounroll
+        for (int i = 0; i < total; ++i) {
+            // tile i + 1 (x half, this wave) and tile i (h half, partner) have landed: requested in iteration i - D or
+            // earlier; younger requests = the XOPS of each of the D - 1 iterations since
+            if ((DBG & 2) || i <= WS_D) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::XOPS * (WS_D - 1)) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own hand-off stores of the previous iteration
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // ---- request tile f = i + 1 + D; its h rows were produced as tile f - R by all members ----
+            {
+                const int f = i + 1 + WS_D;
+                if (f < total && fs > 0 && !(DBG & 8) && !dead) {
+                    const unsigned need = (unsigned)(f - R + 1);
+                    const unsigned snap = *my_fz;
+                    if (!__all(lane >= NF || snap >= need)) {
+#ifdef MIBC_DEBUG_KERNELS
+                        if (lane == 0) atomicAdd(err + 1, 1u);           // slow-path entries
+                        if (lane < NF && snap < need) atomicMax(err + 2, need - snap);   // worst lag seen
+#endif
+                        // slow path: refresh the snapshot by DMA and re-read it (a drain is harmless for the counted
+                        // waits: they only rely on issue order)
+                        unsigned spins = 0;
+                        bool good;
+                        do {
+                            cl_dma4_sc1((const unsigned *)((unsigned long long)clflags + flag_lane),
+                                        lds0 + L::OFF_FLAGZ + sim * 256);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            const unsigned v = *my_fz;
+                            good = __all(lane >= NF || v >= need);
+                            if (!good) __builtin_amdgcn_s_sleep(8);
+                        } while (!good && ++spins < WS_SPIN_LIMIT);
+                        if (!good) {
+                            dead = true;
+                            if (lane == 0) atomicCAS(err, 0u, 0x80000000u | ((unsigned)cl << 16) | (unsigned)(fs & 0xffff));
+                        }
+                    }
+                }
+                if (!(DBG & 2) || i < R) fetch(frel, fs == 0, (unsigned)fr * 4096u, fslot_b);
+                fslot_b = (fslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : fslot_b + L::STAGE;
+                if (f + 1 < total) advance_f();   // past the end the last tile is requested again (nobody reads it)
+            }
+            // ---- x half of tile i + 1 -> hand-off slot (i + 1) & 1 (past the end: a dummy pass, nobody reads it) ----
+            float4v_ws acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = *(LDSP(const float4v_ws))(my_bias + g * 16);
+            half_tile(acc, cslot_b);
+            LDSP(unsigned char) hd = hand + (((i + 1) & 1) ? 16384 : 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *(LDSP(float4v_ws))(hd + g * 1024) = acc[g];
+            cslot_b = (cslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : cslot_b + L::STAGE;
+        }
+    } else {
+        // =========================== H-WAVES: h half, gates, stores ===========================
+        int pr = 0;                         // row tile of tile i
+        long long prel = rel0;              // its byte offset at its time step
+        unsigned pslot_b = 0;
+        __builtin_amdgcn_s_barrier();       // pairs with the x-waves' prologue barrier
+        asm volatile("" ::: "memory");
+#pragma nounroll
+        for (int i = 0; i < total; ++i) {
+            // own stores of iterations <= i - 2 have retired (3 VMEM operations per iteration)
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // ---- publish: tiles 0 .. i - 2 are complete ----
+            if (!(DBG & 32)) {
+                const unsigned p = (unsigned)(i > 1 ? i - 1 : 0);
+                if (xcd_local)   // members share one L2: a plain (write-back) store is visible to their sc1 loads
+                    __hip_atomic_store(myflag, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else
-                    sv[g][e] = (g == 2) ? fast_tanh(pa[g][e]) : fast_sigmoid(pa[g][e]);
-            } else if constexpr (ks < 20) {
-                constexpr int e = ks - 16;
+                    __hip_atomic_store(myflag, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // ---- continue the partner's accumulators with the h half of tile i ----
+            float4v_ws acc[4];
+            {
+                LDSP(const unsigned char) hd = hand + ((i & 1) ? 16384 : 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = *(LDSP(const float4v_ws))(hd + g * 1024);
+            }
+            const float4v_ws cv = *(LDSP(const float4v_ws))(smem3 + pslot_b + L::ACT + sim * 1024 + lane * 16);
+            half_tile(acc, pslot_b);
+            // ---- gates (D row = hidden 4 lq + e, D col = batch row l15) ----
+            float4v_ws cn;
+            half4_t hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
                 if (DBG & 1) {
                     cn[e] = cv[e];
-                    hv[e] = (half_t)(1e-3f * (sv[0][e] + sv[1][e] + sv[2][e] + sv[3][e]));
+                    hv[e] = (half_t)(1e-3f * (acc[0][e] + acc[1][e] + acc[2][e] + acc[3][e]));
                 } else {
-                    const float c = fmaf(sv[1][e], cv[e], sv[0][e] * sv[2][e]);
+                    const float ig = fast_sigmoid(acc[0][e]);
+                    const float fg = fast_sigmoid(acc[1][e]);
+                    const float gg = fast_tanh(acc[2][e]);
+                    const float og = fast_sigmoid(acc[3][e]);
+                    const float c = fmaf(fg, cv[e], ig * gg);
                     cn[e] = c;
-                    hv[e] = (half_t)(sv[3][e] * fast_tanh(c));
+                    hv[e] = (half_t)(og * fast_tanh(c));
                 }
-            } else if constexpr (ks == 20) {
-                *(LDSP(half4_t))(patch + l15 * 24 + 4 * lq) = hv;
-                // cell state back to its private tile (read again one time step = R tiles later)
-                if (!(DBG & 32)) *(float4v_ws *)(c0 + (size_t)pr * 4096 + (unsigned)(lane * 16)) = cn;
-            } else if constexpr (ks == 21) {
-                __builtin_amdgcn_wave_barrier();
+            }
+            *(LDSP(half4_t))(patch + l15 * 24 + 4 * lq) = hv;
+            // cell state back to its private tile (read again one time step = R tiles later)
+            if (!(DBG & 32)) *(float4v_ws *)(c0 + (size_t)pr * 4096 + (unsigned)(lane * 16)) = cn;
+            __builtin_amdgcn_wave_barrier();
+            {
                 const int prow = lane >> 1, seg = lane & 1;
                 const half8_t v = *(LDSP(const half8_t))(patch + prow * 24 + seg * 8);
                 const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
                         (void *)(o0 + (unsigned long long)prel), 0, WS_TR * C * 2, 0x00020000);
                 if (lane < 32 && !(DBG & 32)) {
                     const auto vv = __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v);
-                    const int so = (prow * C + j * 64 + wave * 16 + seg * 8) * 2;
+                    const int so = (prow * C + j * 64 + sim * 16 + seg * 8) * 2;
                     if (xcd_local)
                         __builtin_amdgcn_raw_buffer_store_b128(vv, ors, so, 0, 0);
                     else
                         __builtin_amdgcn_raw_buffer_store_b128(vv, ors, so, 0, 16 /* sc1: write-through */);
                 }
-                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        // XDL write -> VALU read of the accumulators (copies / next iteration's gate math): 18 wait states
-        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pa[g] = acc[g];
-        pr = cr;
-        prel = crel;
-        pslot_b = cslot_b;
-        cslot_b = (cslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : cslot_b + L::STAGE;
-        if (++cr == R) {
-            cr = 0;
-            crel += wrap_b;
-        } else {
-            crel += tile_b;
+            __builtin_amdgcn_wave_barrier();
+            pslot_b = (pslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : pslot_b + L::STAGE;
+            if (++pr == R) {
+                pr = 0;
+                prel += wrap_b;
+            } else {
+                prel += tile_b;
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -409,7 +435,7 @@ extern "C" int mibc_launch_lstm_layer_ws(hipStream_t s, int C, const half_t *Xin
                                       hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);                       \
             once = true;                                                                                           \
         }                                                                                                          \
-        hipLaunchKernelGGL((lstm_layer_ws_kernel<384, D_>), grid, dim3(256), L::BYTES, s, Xin, Xout, Wf16, biasn, \
+        hipLaunchKernelGGL((lstm_layer_ws_kernel<384, D_>), grid, dim3(512), L::BYTES, s, Xin, Xout, Wf16, biasn, \
                            zeros, cbuf, flags, err, T, N, reverse, cpx, ncl, rmax);                                \
     } while (0)
 #ifdef MIBC_DEBUG_KERNELS

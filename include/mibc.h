@@ -203,6 +203,12 @@ int mibc_set_profile(mibc_engine *e, int level);                   /* 0 off, 1 p
  *      5 per-block quality prob [N,T] f32 */
 int mibc_debug_tap(mibc_engine *e, int tap, void *host_dst, size_t bytes);
 
+/* ---- experimental kernel switch (test-only) ----
+ * Smallest batch (rows) that takes the weight-stationary cluster LSTM kernel (csrc/lstm_ws.hip, lstm_size 384).
+ * The kernel is bit-identical to the default one but, as measured, not yet faster, so the product
+ * default is "never"; the parity tests of that kernel enable it through this entry. */
+int mibc_debug_set_ws_min_rows(mibc_engine *e, int min_rows);
+
 #ifdef __cplusplus
 }
 #endif

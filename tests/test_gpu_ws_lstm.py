@@ -1,8 +1,8 @@
 """Weight-stationary cluster LSTM kernel, lstm_ws.hip (pytest -m gpu).
 
-For lstm_size 384 (hac) and batches of >= 2048 rows the engine runs lstm_layer_ws_kernel: six workgroups of a cluster
-keep the layer's weights in their register files and exchange h through the layer output.  It performs, element for
-element, the arithmetic of lstm_layer_x8_kernel (same MFMA shape, same k order, same gate functions), so the contract
+EXPERIMENTAL kernel (off in the product: measured slower than lstm_layer_x8_kernel so far; enabled here
+through mibc_debug_set_ws_min_rows).  For lstm_size 384 (hac) six workgroups of a cluster keep the layer's weights in
+their register files and exchange h through the layer output.  It performs, element for element, the arithmetic of lstm_layer_x8_kernel (same MFMA shape, same k order, same gate functions), so the contract
 is BIT-IDENTITY between a large batch (cluster kernel) and the same rows in batches below the threshold (x8), which
 the BASELINE-size parity test pins to the reference (test_gpu_baseline_parity.py, N = 64)."""
 import numpy as np
@@ -32,6 +32,7 @@ def test_ws_kernel_bit_identical_to_x8(N, T_in):
     ws = synth.make_weights(cfg, seed=384)
     x = synth.make_signal(N, T_in, seed=385)
     eng = capi.Engine(cfg, ws)
+    eng.set_ws_min_rows(2048)
     a_ws, s_ws = _lstm_out(eng, x)
     parts = [_lstm_out(eng, x[i:i + 1024]) for i in range(0, N, 1024)]     # below the threshold: x8
     a_x8 = np.concatenate([p[0] for p in parts], axis=1)
@@ -56,6 +57,7 @@ def test_ws_kernel_full_grid():
     T_in = 246
     base = synth.make_signal(256, T_in, seed=91)
     eng = capi.Engine(cfg, ws)
+    eng.set_ws_min_rows(2048)
     a_big, _ = _lstm_out(eng, np.tile(base, (64, 1)))
     a_x8, _ = _lstm_out(eng, base)
     T = a_big.shape[0]
