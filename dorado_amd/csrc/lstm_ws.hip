@@ -56,12 +56,12 @@ struct WsLayout {
     static constexpr int ACT = KS * 1024;                     // bytes of one activation tile
     static constexpr int STAGE = ACT + 4096;                  // + the tile's cell state (4 x 1 KiB)
     static constexpr int OFF_HAND = WS_NST * STAGE;           // [2 slots][4 SIMDs][4 gates][64 lanes] float4
-    static constexpr int OFF_PATCH = OFF_HAND + 2 * 4 * 4096; // [4][16 rows][24 halfs]
-    static constexpr int OFF_BIAS = OFF_PATCH + 4 * 768;      // [4 SIMDs][4 gates][16] f32
+    static constexpr int OFF_BIAS = OFF_HAND + 2 * 4 * 4096;  // [4 SIMDs][4 gates][16] f32
     static constexpr int OFF_FLAGZ = OFF_BIAS + 1024;         // [4][64] u32 snapshot of the cluster's counters
     static constexpr int BYTES = OFF_FLAGZ + 1024;
     static constexpr int NF = KCL * 4;                        // counters per cluster (member x SIMD)
-    static constexpr int XOPS = KS / 4 + 2;                   // x-wave VMEM operations per iteration: flags, blocks, c
+    static constexpr int XOPS = KS / 4 + 5;                   // x-wave VMEM operations per iteration: publish, h and c
+                                                              // store, flags, KS/4 blocks, c block
 };
 
 // DBG (debug build only; results are wrong when non-zero): 1 no gate math, 2 no DMA after the prologue, 4 no MFMA,
@@ -143,9 +143,12 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
     gu32 *myflag = (gu32 *)(flags + ((size_t)cl * NF + j * 4 + sim) * 16);
     const unsigned flag_lane = (unsigned)((lane < NF ? lane : 0) * 64);   // bytes
     LDSP(const volatile unsigned) my_fz = (LDSP(const volatile unsigned))(smem3 + L::OFF_FLAGZ + sim * 256) + lane;
-    LDSP(half_t) patch = (LDSP(half_t))(smem3 + L::OFF_PATCH + sim * 768);
     LDSP(const float) my_bias = (LDSP(const float))(smem3 + L::OFF_BIAS) + sim * 64 + 4 * lq;
-    LDSP(unsigned char) hand = smem3 + L::OFF_HAND + sim * 4096 + lane * 16;   // + slot * 16 KiB + gate * 1 KiB
+    // hand-off slot of this SIMD: x-wave -> h-wave [4 gates][64 lanes] float4 accumulators; once the h-wave has taken
+    // them it returns, in the same 4 KiB, the new cell state [64 lanes] float4 (gate 0 area) and the 16 x 16 block of
+    // h as [16 rows][24 halfs] (gate 1 area) for the x-wave to store (the x-wave owns all global-memory traffic)
+    LDSP(unsigned char) hand0 = smem3 + L::OFF_HAND + sim * 4096;              // + slot * 16 KiB
+    LDSP(unsigned char) hand = hand0 + lane * 16;                              // + gate * 1 KiB
     bool dead = false;
 
     // Tile addresses are running byte offsets (no multiplications in the loop): rel = offset of the tile's 16 rows at
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
             bq[0] = *(LDSP(const half8_t))(sp);
             bq[1] = *(LDSP(const half8_t))(sp + 1024);
         }
+        __builtin_amdgcn_s_setprio(1);   // the wave in its matrix block wins issue arbitration over its partner's VALU / VMEM block
         cl_static_for<KSX>([&](auto ks_c) __attribute__((always_inline)) {
             constexpr int ks = decltype(ks_c)::value;
             if (!(DBG & 16) && ks + 2 < KSX) bq[(ks + 2) % 3] = *(LDSP(const half8_t))(sp + (ks + 2) * 1024);
@@ -208,6 +212,7 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
                 asm volatile("" ::"v"(bq[ks % 3]));
             }
         });
+        __builtin_amdgcn_s_setprio(0);
         // XDL write -> VALU / LDS-store read of the accumulators: 18 wait states
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
     };
@@ -233,6 +238,8 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
             advance_f();
         }
         unsigned cslot_b = 0;               // ring slot of the tile whose x half is computed next
+        int pr = 0;                         // row tile / byte offset of the tile whose results are stored next
+        long long prel = rel0;
         // x half of tile 0 (hand-off slot 0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
             cslot_b += L::STAGE;
         }
 #pragma nounroll
-        for (int i = 0; i < total; ++i) {
+        for (int i = 0; i <= total; ++i) {   // iteration `total` only stores the last tile's results
             // tile i + 1 (x half, this wave) and tile i (h half, partner) have landed: requested in iteration i - D or
             // earlier; younger requests = the XOPS of each of the D - 1 iterations since
             if ((DBG & 2) || i <= WS_D) {
@@ -258,6 +265,40 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own hand-off stores of the previous iteration
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            // ---- publish: the wait above retired every operation of iterations <= i - 2, i.e. the stores of tiles
+            // 0 .. i - 3 ----
+            if (!(DBG & 32) && lane == 0) {
+                const unsigned p = (unsigned)(i > 2 ? i - 2 : 0);
+                if (xcd_local)   // members share one L2: a plain (write-back) store is visible to their sc1 loads
+                    __hip_atomic_store(myflag, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else
+                    __hip_atomic_store(myflag, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // ---- results of tile i - 1 (left in the hand-off slot by the partner): h block and cell state ----
+            {
+                LDSP(const unsigned char) hb = hand0 + (((i - 1) & 1) ? 16384 : 0);
+                const int prow = lane >> 1, seg = lane & 1;
+                const half8_t v = *(LDSP(const half8_t))(hb + 1024 + (prow * 24 + seg * 8) * 2);
+                const float4v_ws cn = *(LDSP(const float4v_ws))(hb + lane * 16);
+                const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+                        (void *)(o0 + (unsigned long long)prel), 0, WS_TR * C * 2, 0x00020000);
+                if (i > 0 && !(DBG & 32)) {
+                    const auto vv = __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v);
+                    const int so = (lane < 32) ? (prow * C + j * 64 + sim * 16 + seg * 8) * 2 : WS_TR * C * 2;   // >= 32: out of range, dropped
+                    if (xcd_local)
+                        __builtin_amdgcn_raw_buffer_store_b128(vv, ors, so, 0, 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(vv, ors, so, 0, 16 /* sc1: write-through */);
+                    // cell state back to its private tile (read again one time step = R tiles later)
+                    *(float4v_ws *)(c0 + (size_t)pr * 4096 + (unsigned)(lane * 16)) = cn;
+                    if (++pr == R) {
+                        pr = 0;
+                        prel += wrap_b;
+                    } else {
+                        prel += tile_b;
+                    }
+                }
+            }
             // ---- request tile f = i + 1 + D; its h rows were produced as tile f - R by all members ----
             {
                 const int f = i + 1 + WS_D;
@@ -287,7 +328,11 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
                         }
                     }
                 }
-                if (!(DBG & 2) || i < R) fetch(frel, fs == 0, (unsigned)fr * 4096u, fslot_b);
+                if (DBG & 64) {   // ablation: every request hits the same cache-resident lines
+                    fetch(rel0, true, 0u, fslot_b);
+                } else if (!(DBG & 2) || i < R) {
+                    fetch(frel, fs == 0, (unsigned)fr * 4096u, fslot_b);
+                }
                 fslot_b = (fslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : fslot_b + L::STAGE;
                 if (f + 1 < total) advance_f();   // past the end the last tile is requested again (nobody reads it)
             }
@@ -302,33 +347,21 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
             cslot_b = (cslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : cslot_b + L::STAGE;
         }
     } else {
-        // =========================== H-WAVES: h half, gates, stores ===========================
-        int pr = 0;                         // row tile of tile i
-        long long prel = rel0;              // its byte offset at its time step
+        // =========================== H-WAVES: h half, gates (no global-memory traffic) ===========================
         unsigned pslot_b = 0;
         __builtin_amdgcn_s_barrier();       // pairs with the x-waves' prologue barrier
         asm volatile("" ::: "memory");
 #pragma nounroll
-        for (int i = 0; i < total; ++i) {
-            // own stores of iterations <= i - 2 have retired (3 VMEM operations per iteration)
-            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        for (int i = 0; i <= total; ++i) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own result stores of the previous iteration
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            // ---- publish: tiles 0 .. i - 2 are complete ----
-            if (!(DBG & 32)) {
-                const unsigned p = (unsigned)(i > 1 ? i - 1 : 0);
-                if (xcd_local)   // members share one L2: a plain (write-back) store is visible to their sc1 loads
-                    __hip_atomic_store(myflag, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                else
-                    __hip_atomic_store(myflag, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (i == total) break;
             // ---- continue the partner's accumulators with the h half of tile i ----
             float4v_ws acc[4];
-            {
-                LDSP(const unsigned char) hd = hand + ((i & 1) ? 16384 : 0);
+            LDSP(unsigned char) hs = hand0 + ((i & 1) ? 16384 : 0);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = *(LDSP(const float4v_ws))(hd + g * 1024);
-            }
+            for (int g = 0; g < 4; ++g) acc[g] = *(LDSP(const float4v_ws))(hs + lane * 16 + g * 1024);
             const float4v_ws cv = *(LDSP(const float4v_ws))(smem3 + pslot_b + L::ACT + sim * 1024 + lane * 16);
             half_tile(acc, pslot_b);
             // ---- gates (D row = hidden 4 lq + e, D col = batch row l15) ----
@@ -349,32 +382,10 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
                     hv[e] = (half_t)(og * fast_tanh(c));
                 }
             }
-            *(LDSP(half4_t))(patch + l15 * 24 + 4 * lq) = hv;
-            // cell state back to its private tile (read again one time step = R tiles later)
-            if (!(DBG & 32)) *(float4v_ws *)(c0 + (size_t)pr * 4096 + (unsigned)(lane * 16)) = cn;
-            __builtin_amdgcn_wave_barrier();
-            {
-                const int prow = lane >> 1, seg = lane & 1;
-                const half8_t v = *(LDSP(const half8_t))(patch + prow * 24 + seg * 8);
-                const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
-                        (void *)(o0 + (unsigned long long)prel), 0, WS_TR * C * 2, 0x00020000);
-                if (lane < 32 && !(DBG & 32)) {
-                    const auto vv = __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v);
-                    const int so = (prow * C + j * 64 + sim * 16 + seg * 8) * 2;
-                    if (xcd_local)
-                        __builtin_amdgcn_raw_buffer_store_b128(vv, ors, so, 0, 0);
-                    else
-                        __builtin_amdgcn_raw_buffer_store_b128(vv, ors, so, 0, 16 /* sc1: write-through */);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
+            // results into the (consumed) hand-off slot; the partner stores them in the next iteration
+            *(LDSP(float4v_ws))(hs + lane * 16) = cn;
+            *(LDSP(half4_t))(hs + 1024 + (l15 * 24 + 4 * lq) * 2) = hv;
             pslot_b = (pslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : pslot_b + L::STAGE;
-            if (++pr == R) {
-                pr = 0;
-                prel += wrap_b;
-            } else {
-                prel += tile_b;
-            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -456,6 +467,9 @@ extern "C" int mibc_launch_lstm_layer_ws(hipStream_t s, int C, const half_t *Xin
         case 63: WS_LAUNCH(63); return 0;
         case 10: WS_LAUNCH(10); return 0;
         case 42: WS_LAUNCH(42); return 0;
+        case 64: WS_LAUNCH(64); return 0;
+        case 72: WS_LAUNCH(72); return 0;
+        case 68: WS_LAUNCH(68); return 0;
         case 32: WS_LAUNCH(32); return 0;
         case 40: WS_LAUNCH(40); return 0;
         case 36: WS_LAUNCH(36); return 0;
