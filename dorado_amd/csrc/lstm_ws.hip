@@ -47,6 +47,22 @@ __device__ __forceinline__ float4v_ws ws_mfma_v(half8_t wv, half8_t b, float4v_w
     return c;
 }
 
+#ifdef MIBC_DEBUG_KERNELS
+// DBG & 128: cycle stamps (s_memtime) of the phases of 16 consecutive iterations, cluster 0 / member 0 / SIMD 0,
+// x-wave stamps in [it][0][k], h-wave in [it][1][k]
+__device__ unsigned long long ws_trace[16 * 2 * 8];
+#define WS_STAMP(role, k)                                                                        \
+    do {                                                                                         \
+        if ((DBG & 128) && tracing && i >= 1000 && i < 1016)                                     \
+            ws_trace[((i - 1000) * 2 + (role)) * 8 + (k)] = __builtin_readcyclecounter();        \
+    } while (0)
+extern "C" int mibc_debug_ws_trace(unsigned long long *host_dst) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ws_trace), sizeof(ws_trace)) == hipSuccess ? 0 : -1;
+}
+#else
+#define WS_STAMP(role, k) do { } while (0)
+#endif
+
 template <int C>
 struct WsLayout {
     static constexpr int KCL = C / 64;
@@ -150,6 +166,7 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
     LDSP(unsigned char) hand0 = smem3 + L::OFF_HAND + sim * 4096;              // + slot * 16 KiB
     LDSP(unsigned char) hand = hand0 + lane * 16;                              // + gate * 1 KiB
     bool dead = false;
+    const bool tracing = (DBG & 128) && blockIdx.x == 0 && sim == 0 && lane == 0;
 
     // Tile addresses are running byte offsets (no multiplications in the loop): rel = offset of the tile's 16 rows at
     // its time step, the same in Xin (x_t) and Xout (h_t); h_{t-1} of the tile is Xout + rel - dstep.
@@ -255,6 +272,7 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
         }
 #pragma nounroll
         for (int i = 0; i <= total; ++i) {   // iteration `total` only stores the last tile's results
+            WS_STAMP(0, 5);
             // tile i + 1 (x half, this wave) and tile i (h half, partner) have landed: requested in iteration i - D or
             // earlier; younger requests = the XOPS of each of the D - 1 iterations since
             if ((DBG & 2) || i <= WS_D) {
@@ -262,9 +280,11 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
             } else {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::XOPS * (WS_D - 1)) : "memory");
             }
+            WS_STAMP(0, 6);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own hand-off stores of the previous iteration
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            WS_STAMP(0, 0);
             // ---- publish: the wait above retired every operation of iterations <= i - 2, i.e. the stores of tiles
             // 0 .. i - 3 ----
             if (!(DBG & 32) && lane == 0) {
@@ -299,6 +319,7 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
                     }
                 }
             }
+            WS_STAMP(0, 1);
             // ---- request tile f = i + 1 + D; its h rows were produced as tile f - R by all members ----
             {
                 const int f = i + 1 + WS_D;
@@ -336,15 +357,18 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
                 fslot_b = (fslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : fslot_b + L::STAGE;
                 if (f + 1 < total) advance_f();   // past the end the last tile is requested again (nobody reads it)
             }
+            WS_STAMP(0, 2);
             // ---- x half of tile i + 1 -> hand-off slot (i + 1) & 1 (past the end: a dummy pass, nobody reads it) ----
             float4v_ws acc[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = *(LDSP(const float4v_ws))(my_bias + g * 16);
             half_tile(acc, cslot_b);
+            WS_STAMP(0, 3);
             LDSP(unsigned char) hd = hand + (((i + 1) & 1) ? 16384 : 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) *(LDSP(float4v_ws))(hd + g * 1024) = acc[g];
             cslot_b = (cslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : cslot_b + L::STAGE;
+            WS_STAMP(0, 4);
         }
     } else {
         // =========================== H-WAVES: h half, gates (no global-memory traffic) ===========================
@@ -353,10 +377,12 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
         asm volatile("" ::: "memory");
 #pragma nounroll
         for (int i = 0; i <= total; ++i) {
+            WS_STAMP(1, 5);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own result stores of the previous iteration
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (i == total) break;
+            WS_STAMP(1, 0);
             // ---- continue the partner's accumulators with the h half of tile i ----
             float4v_ws acc[4];
             LDSP(unsigned char) hs = hand0 + ((i & 1) ? 16384 : 0);
@@ -364,6 +390,7 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
             for (int g = 0; g < 4; ++g) acc[g] = *(LDSP(const float4v_ws))(hs + lane * 16 + g * 1024);
             const float4v_ws cv = *(LDSP(const float4v_ws))(smem3 + pslot_b + L::ACT + sim * 1024 + lane * 16);
             half_tile(acc, pslot_b);
+            WS_STAMP(1, 2);
             // ---- gates (D row = hidden 4 lq + e, D col = batch row l15) ----
             float4v_ws cn;
             half4_t hv;
@@ -385,6 +412,7 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
             // results into the (consumed) hand-off slot; the partner stores them in the next iteration
             *(LDSP(float4v_ws))(hs + lane * 16) = cn;
             *(LDSP(half4_t))(hs + 1024 + (l15 * 24 + 4 * lq) * 2) = hv;
+            WS_STAMP(1, 4);
             pslot_b = (pslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : pslot_b + L::STAGE;
         }
     }
@@ -467,6 +495,8 @@ extern "C" int mibc_launch_lstm_layer_ws(hipStream_t s, int C, const half_t *Xin
         case 63: WS_LAUNCH(63); return 0;
         case 10: WS_LAUNCH(10); return 0;
         case 42: WS_LAUNCH(42); return 0;
+        case 128: WS_LAUNCH(128); return 0;
+        case 192: WS_LAUNCH(192); return 0;
         case 64: WS_LAUNCH(64); return 0;
         case 72: WS_LAUNCH(72); return 0;
         case 68: WS_LAUNCH(68); return 0;
