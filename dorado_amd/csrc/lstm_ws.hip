@@ -204,29 +204,29 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
     // one half of a tile's MFMAs: KSX k-steps x 4 gates on the fragments of ring slot slot_b
     auto half_tile = [&](float4v_ws (&acc)[4], unsigned slot_b) __attribute__((always_inline)) {
         LDSP(const unsigned char) sp = smem3 + slot_b + foff;
-        half8_t bq[3];
+        constexpr int PFD = 4;   // fragment buffers: PFD - 1 k-steps of LDS latency cover
+        half8_t bq[PFD];
         if (DBG & 16) {
-            bq[0] = (half8_t)((half_t)0.001f);
-            bq[1] = (half8_t)((half_t)0.002f);
-            bq[2] = (half8_t)((half_t)0.003f);
+#pragma unroll
+            for (int q = 0; q < PFD; ++q) bq[q] = (half8_t)((half_t)(0.001f * (q + 1)));
         } else {
-            bq[0] = *(LDSP(const half8_t))(sp);
-            bq[1] = *(LDSP(const half8_t))(sp + 1024);
+#pragma unroll
+            for (int q = 0; q < PFD - 1; ++q) bq[q] = *(LDSP(const half8_t))(sp + q * 1024);
         }
         __builtin_amdgcn_s_setprio(1);   // the wave in its matrix block wins issue arbitration over its partner's VALU / VMEM block
         cl_static_for<KSX>([&](auto ks_c) __attribute__((always_inline)) {
             constexpr int ks = decltype(ks_c)::value;
-            if (!(DBG & 16) && ks + 2 < KSX) bq[(ks + 2) % 3] = *(LDSP(const half8_t))(sp + (ks + 2) * 1024);
+            if (!(DBG & 16) && ks + PFD - 1 < KSX) bq[(ks + PFD - 1) % PFD] = *(LDSP(const half8_t))(sp + (ks + PFD - 1) * 1024);
             if (!(DBG & 4)) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     if (ks < KA)
-                        acc[g] = ws_mfma_a(w[ks][g], bq[ks % 3], acc[g]);
+                        acc[g] = ws_mfma_a(w[ks][g], bq[ks % PFD], acc[g]);
                     else
-                        acc[g] = ws_mfma_v(w[ks][g], bq[ks % 3], acc[g]);
+                        acc[g] = ws_mfma_v(w[ks][g], bq[ks % PFD], acc[g]);
                 }
             } else {
-                asm volatile("" ::"v"(bq[ks % 3]));
+                asm volatile("" ::"v"(bq[ks % PFD]));
             }
         });
         __builtin_amdgcn_s_setprio(0);
