@@ -28,12 +28,16 @@
 #define G2_PATCH_LD 40
 #define G2_PATCH (32 * G2_PATCH_LD)
 #define G2_OFF_PATCH (G2_NST * G2_STAGE * 2)
-#define G2_LDS_BYTES (G2_OFF_PATCH + 8 * G2_PATCH * 2)
+#define G2_OFF_BIAS (G2_OFF_PATCH + 8 * G2_PATCH * 2)     // [2][256] f32: bias of the current / previous tile's columns
+#define G2_LDS_BYTES (G2_OFF_BIAS + 2 * 256 * 4)
 
 #define LDSP(T) __attribute__((address_space(3))) T *
 typedef __attribute__((address_space(3))) void *g2_lds_vptr;
 typedef const __attribute__((address_space(1))) half_t *g2_ghalf_p;
 
+__device__ __forceinline__ void g2_dma16f(const float *g, unsigned lds_addr) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (g2_lds_vptr)(size_t)lds_addr, 16, 0, 0);
+}
 __device__ __forceinline__ void g2_dma16(g2_ghalf_p g, unsigned lds_addr) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (g2_lds_vptr)(size_t)lds_addr, 16, 0, 0);
 }
@@ -49,7 +53,9 @@ __device__ __forceinline__ void g2_static_for(F &&f) {
 
 // EPI: 0 = bias / activation (GemmArgs::act), 1 = rotary embedding on columns < rope_cols + transposed V store,
 //      2 = SwiGLU (64 y | 64 gate columns per 128: writes 64 columns).
-template <int KS, int EPI>
+// DBG (debug build only, wrong results): 1 no epilogue stores, 2 no epilogue at all, 4 A rows of every tile taken from
+// tile 0 (cache-resident), 8 no MFMA, 16 single wave group epilogue timing probe (unused)
+template <int KS, int EPI, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LDSP(unsigned char) smem3 = (LDSP(unsigned char))smem;
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     for (int q = 0; q < 2; ++q) boffb[q] = (unsigned)((drow[q] * p.K + dcol[q]) * 2);
     auto tile_src = [&](int rowtile, int c0, unsigned long long &ab, unsigned long long &bb, unsigned (&ao)[2]) __attribute__((always_inline)) {
         // A: rows m0 + drow (clamped), arbitrary row map -> per-lane offsets relative to the first row of the tile
-        const int m0 = rowtile * 256;
+        const int m0 = (DBG & 4) ? 0 : rowtile * 256;
         int mb = m0 < p.M ? m0 : p.M - 1;
         const long base0 = (long)(mb / p.a_div) * p.a_outer + (long)(mb % p.a_div) * p.a_inner;
         ab = (unsigned long long)(p.A + base0);
@@ -135,7 +141,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     half8_t wf[4], xa[2];
     // Epilogue of tile (e_rowtile, e_c0).  D row = output column n = c0 + wn*128 + g*32 + (r&3) + 8 (r>>2) + 4 lhi ;
     // D col = output row m0 + wm*64 + rt*32 + l31.
-    auto epilogue = [&](int e_rowtile, int e_c0) __attribute__((always_inline)) {
+    // e_zone: which half of the LDS bias zone holds this tile's 256 bias values (EPI 0 with a bias vector: fetched by
+    // LDS-DMA during the tile's K loop — a VGPR-returning load here would make hipcc drain vmcnt(0), i.e. the whole
+    // DMA pipeline, per element)
+    auto epilogue = [&](int e_rowtile, int e_c0, int e_zone) __attribute__((always_inline)) {
+        if (DBG & 2) {
+            asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));
+            return;
+        }
         // D row = output column n = c0 + wn*128 + g*32 + (r&3) + 8 (r>>2) + 4 lhi ; D col = output row m0 + wm*64 + rt*32 + l31
         const int m0 = e_rowtile * 256;
         const int cw = e_c0 + wn * 128;                       // first column of this wave
@@ -194,6 +207,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
             constexpr int NG = (EPI == 2) ? 2 : 4;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
+                // bias + activation of EPI 0 on the 16 values of (g, rt): the activation code is a wave-uniform switch
+                // OUTSIDE the element loops
+                if (EPI == 0) {
+                    if (p.bias != nullptr) {
+                        LDSP(const float) bz = (LDSP(const float))(smem3 + G2_OFF_BIAS) + e_zone * 256 + wn * 128 + g * 32 + 4 * lhi;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4_t bv = *(LDSP(const float4_t))(bz + 8 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[g][rt][q * 4 + e] += bv[e];
+                        }
+                    }
+                    if (p.act == 3) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[g][rt][r] = 5.0f * fast_tanh(acc[g][rt][r]);
+                    } else if (p.act == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[g][rt][r] = act_apply(acc[g][rt][r], 0);
+                    } else if (p.act == 1) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[g][rt][r] = act_apply(acc[g][rt][r], 1);
+                    } else if (p.act == 2) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[g][rt][r] = act_apply(acc[g][rt][r], 2);
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     half4_t hv;
@@ -205,10 +244,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                             // SwiGLU (nn/TxModules.cpp:171-175): silu(gate) * y on the f16-rounded GEMM outputs
                             const float y = (float)(half_t)v, gt = (float)(half_t)acc[g + 2][rt][r];
                             v = gt * fast_sigmoid(gt) * y;
-                        } else if (EPI == 0) {
-                            if (p.bias != nullptr) v += p.bias[cw + g * 32 + 8 * q + 4 * lhi + e];
-                            if (p.act == 3) v = 5.0f * fast_tanh(v);
-                            else if (p.act >= 0) v = act_apply(v, p.act);
                         }
                         hv[e] = (half_t)v;
                     }
@@ -220,7 +255,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                 for (int i = 0; i < 2; ++i) {
                     const int prow = (lane >> 2) + 16 * i, seg = lane & 3;
                     const half8_t v = *(LDSP(const half8_t))(patch + prow * G2_PATCH_LD + seg * 8);
-                    if (ook[i]) *(half8_t *)(orow[i] + ocol + seg * 8) = v;
+                    if (DBG & 1) {
+                        asm volatile("" ::"v"(v));
+                    } else if (ook[i]) {
+                        *(half8_t *)(orow[i] + ocol + seg * 8) = v;
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -256,7 +295,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                 else issue(kt & 3, a_nxt, b_nxt, aoffb_n, kt - KS);
                 // group A's epilogue of the PREVIOUS tile sits here, behind L(0) of this tile: it then runs beside
                 // group B's M(KS-1) + epilogue of that tile (half a slab later by construction) instead of before it
-                if (ks == 0 && !grpB && ti > 0) epilogue(rowtile_p, c0_p);
+                if (ks == 0 && !grpB && ti > 0) epilogue(rowtile_p, c0_p, (ti - 1) & 1);
+                // this tile's bias values -> LDS zone ti & 1 (one extra DMA of wave 0: the counted waits only get stricter)
+                if (EPI == 0 && ks == 1 && wave == 0 && p.bias != nullptr)
+                    g2_dma16f(p.bias + c0 + lane * 4, lds0 + G2_OFF_BIAS + (unsigned)(ti & 1) * 1024u);
             }
             if (grpB) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __builtin_amdgcn_s_barrier();   // B2
@@ -276,8 +318,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    acc[g][0] = mfma32x32x16(wf[g], xa[0], acc[g][0]);
-                    acc[g][1] = mfma32x32x16(wf[g], xa[1], acc[g][1]);
+                    if (!(DBG & 8)) {
+                        acc[g][0] = mfma32x32x16(wf[g], xa[0], acc[g][0]);
+                        acc[g][1] = mfma32x32x16(wf[g], xa[1], acc[g][1]);
+                    } else {
+                        asm volatile("" ::"v"(wf[g]), "v"(xa[0]), "v"(xa[1]));
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     wf[g] = *(LDSP(const half8_t))(sp + woff + g * 32 * G2_BK + c1f);
                     if (g == 0) {
@@ -288,11 +334,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    acc[g][0] = mfma32x32x16(wf[g], xb[0], acc[g][0]);
-                    acc[g][1] = mfma32x32x16(wf[g], xb[1], acc[g][1]);
+                    if (!(DBG & 8)) {
+                        acc[g][0] = mfma32x32x16(wf[g], xb[0], acc[g][0]);
+                        acc[g][1] = mfma32x32x16(wf[g], xb[1], acc[g][1]);
+                    } else {
+                        asm volatile("" ::"v"(wf[g]), "v"(xb[0]), "v"(xb[1]));
+                    }
                 }
                 __builtin_amdgcn_s_setprio(0);
-                if (ks == KS - 1 && grpB) epilogue(rowtile, c0);
+                if (ks == KS - 1 && grpB) epilogue(rowtile, c0, ti & 1);
             }
         });
 
@@ -306,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         aoffb[1] = aoffb_n[1];
     }
     if (!grpB) {
-        epilogue(rowtile_p, c0_p);   // group A's last tile
+        epilogue(rowtile_p, c0_p, (my_tiles - 1) & 1);   // group A's last tile
         __builtin_amdgcn_s_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -314,7 +364,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 
 // 0 = launched; 1 = shape not covered (caller uses gemm_dma_kernel).
 extern "C" int mibc_launch_gemm256(hipStream_t s, const GemmArgs *a) {
+#ifdef MIBC_DEBUG_KERNELS
+    const int g2dbg = (a->dbg >= 0x1000) ? (a->dbg - 0x1000) : 0;
+    if (a->Ncols % 256 != 0 || a->M < 2048 || a->ncols_valid != 0 || (a->dbg != 0 && a->dbg < 0x1000)) return 1;
+#else
     if (a->Ncols % 256 != 0 || a->M < 2048 || a->ncols_valid != 0 || a->dbg != 0) return 1;
+#endif
     if (a->K != 512 && a->K != 1024 && a->K != 2048) return 1;
     if (a->epi_mode == 1 && (a->rope_T % 256 != 0 || a->rope_cols % 128 != 0 || a->vT == nullptr)) return 1;
     static int ncu = 0;
@@ -344,6 +399,17 @@ extern "C" int mibc_launch_gemm256(hipStream_t s, const GemmArgs *a) {
         case 1024: G2_LAUNCH(32, E_);          \
         default: G2_LAUNCH(64, E_);            \
     }
+#ifdef MIBC_DEBUG_KERNELS
+#define G2_DBG(D_)                                                                                             \
+    if (g2dbg == D_ && a->epi_mode == 0 && a->K == 512) {                                                     \
+        (void)hipFuncSetAttribute((const void *)gemm256_kernel<16, 0, D_>,                                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);                  \
+        hipLaunchKernelGGL((gemm256_kernel<16, 0, D_>), dim3(grid), dim3(512), G2_LDS_BYTES, s, *a);          \
+        return 0;                                                                                             \
+    }
+    G2_DBG(1) G2_DBG(2) G2_DBG(4) G2_DBG(6) G2_DBG(8) G2_DBG(10) G2_DBG(14)
+#undef G2_DBG
+#endif
     if (a->epi_mode == 1) { G2_K(1) }
     if (a->epi_mode == 2) { G2_K(2) }
     G2_K(0)

@@ -385,6 +385,202 @@ __global__ __launch_bounds__(512) void window_attention_v2_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v3: one workgroup walks ALL query tiles of its (chunk, head) pair and keeps the key / value window in an LDS ring
+// of 512 keys (slot = key & 511): v2 re-stages 400 keys for every 128 queries (3.1x the K / V bytes, and one exposed
+// memory latency per tile with a single workgroup per CU); here a tile brings in only its 128 new keys, requested
+// before the tile's matrix work and written behind it.  Same per-wave tile mapping and operation order as v2
+// (bit-identical results).  Needs back % 16 == 0 and T % 128 == 0.
+template <int KW>
+__global__ __launch_bounds__(512) void window_attention_v3_kernel(
+        const half_t *__restrict__ qk,   // [N*T][ld]  q | k (| unused), head h at h*64
+        const half_t *__restrict__ vT,   // [N][H][64][T]
+        half_t *__restrict__ out,        // [N*T][C]
+        int T, int C, int H, int ld, int win_upper, int win_lower, int split, int back) {
+    constexpr int NK = 16 * (7 + KW);    // keys a query tile can see (staged span of v2)
+    constexpr int RING = 512;
+    static_assert(NK + 128 <= RING + 16 && NK <= RING, "ring too small");
+    constexpr int KLD = 64 + 8;
+    constexpr int VLD = RING + 8;
+    __shared__ __attribute__((aligned(16))) half_t Ks[RING * KLD];
+    __shared__ __attribute__((aligned(16))) half_t Vt[64 * VLD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int pair = blockIdx.x;
+    const int h = pair % H;
+    const int n = pair / H;
+    const size_t row0 = (size_t)n * T;
+    const half_t *vrow = vT + ((size_t)n * H + h) * 64 * T;
+    const int qtiles = T / 128;
+
+    // ---- initial window: keys [-back, -back + NK) ----
+    {
+        constexpr int KCH = (NK * 8 + 511) / 512;
+        constexpr int VCH = (64 * (NK / 8) + 511) / 512;
+        const int k0 = -back;
+        half8_t kreg[KCH], vreg[VCH];
+#pragma unroll
+        for (int it = 0; it < KCH; ++it) {
+            const int c = tid + 512 * it;
+            const int key = k0 + (c >> 3);
+            kreg[it] = (half8_t)(0);
+            if (c < NK * 8 && key >= 0 && key < T)
+                kreg[it] = *(const half8_t *)(qk + (row0 + key) * ld + C + h * 64 + (c & 7) * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < VCH; ++it) {
+            const int c = tid + 512 * it;
+            const int d = c / (NK / 8), kg = c % (NK / 8);
+            const int key = k0 + kg * 8;
+            vreg[it] = (half8_t)(0);
+            if (c < 64 * (NK / 8) && key >= 0 && key + 8 <= T) vreg[it] = *(const half8_t *)(vrow + (size_t)d * T + key);
+        }
+#pragma unroll
+        for (int it = 0; it < KCH; ++it) {
+            const int c = tid + 512 * it;
+            if (c < NK * 8) *(half8_t *)(Ks + ((k0 + (c >> 3)) & (RING - 1)) * KLD + (c & 7) * 8) = kreg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < VCH; ++it) {
+            const int c = tid + 512 * it;
+            if (c < 64 * (NK / 8))
+                *(half8_t *)(Vt + (c / (NK / 8)) * VLD + ((k0 + (c % (NK / 8)) * 8) & (RING - 1))) = vreg[it];
+        }
+    }
+    half8_t qf[2];
+    {
+        const int qi = wave * 16 + l15;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) qf[kb] = *(const half8_t *)(qk + (row0 + qi) * ld + h * 64 + kb * 32 + 8 * lq);
+    }
+    __syncthreads();
+
+    for (int qt = 0; qt < qtiles; ++qt) {
+        const int q0 = qt * 128;
+        const int k0 = q0 - back;
+        // ---- request the 128 keys the NEXT tile adds: [k0 + NK, k0 + NK + 128), and its query fragments ----
+        const bool more = (qt + 1 < qtiles);
+        half8_t kn[2], vn[2], qn[2];
+        const int knew = k0 + NK;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int c = tid + 512 * it;                  // 1024 pieces of 8 halfs
+            const int key = knew + (c >> 3);
+            kn[it] = (half8_t)(0);
+            if (more && key >= 0 && key < T) kn[it] = *(const half8_t *)(qk + (row0 + key) * ld + C + h * 64 + (c & 7) * 8);
+            const int d = c >> 4, kg = c & 15;
+            const int vkey = knew + kg * 8;
+            vn[it] = (half8_t)(0);
+            if (more && vkey >= 0 && vkey + 8 <= T) vn[it] = *(const half8_t *)(vrow + (size_t)d * T + vkey);
+        }
+        if (more) {
+            const int qi2 = q0 + 128 + wave * 16 + l15;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) qn[kb] = *(const half8_t *)(qk + (row0 + qi2) * ld + h * 64 + kb * 32 + 8 * lq);
+        } else {
+            qn[0] = qf[0];
+            qn[1] = qf[1];
+        }
+
+        // ---- this tile (v2's arithmetic; staged tile w + i lives in ring slots ((k0 + (w + i) * 16) & 511) ..) ----
+        const int qi = q0 + wave * 16 + l15;
+        float4a sc[KW];
+#pragma unroll
+        for (int i = 0; i < KW; ++i) {
+            float4a acc = (float4a)(0.0f);
+            const int slot = (k0 + (wave + i) * 16) & (RING - 1);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const half8_t kf = *(const half8_t *)(Ks + (slot + l15) * KLD + kb * 32 + 8 * lq);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kb], acc, 0, 0, 0);
+            }
+            sc[i] = acc;
+        }
+        const int qe = min(T, (qi / split + 1) * split);
+        const int jmax = min(min(qi + win_lower, T - 1), qe + win_upper - 1);
+        const int jmin = max(qi - win_upper, 0);
+        const int jbase = k0 + wave * 16 + 4 * lq;
+        float m = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < KW; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jbase + i * 16 + r;
+                const bool vis = (j >= jmin) && (j <= jmax);
+                const float v = vis ? sc[i][r] * 0.125f : -3.0e38f;
+                sc[i][r] = v;
+                m = fmaxf(m, v);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < KW; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = (sc[i][r] > -1.0e38f) ? __expf(sc[i][r] - m) : 0.0f;
+                sc[i][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        float4a oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = (float4a)(0.0f);
+#pragma unroll
+        for (int blk = 0; blk < KW / 2; ++blk) {
+            half8_t pf;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pf[i] = (half_t)(sc[2 * blk][i] * inv);
+                pf[4 + i] = (half_t)(sc[2 * blk + 1][i] * inv);
+            }
+            const int s0 = (k0 + (wave + 2 * blk) * 16) & (RING - 1);
+            const int s1 = (k0 + (wave + 2 * blk + 1) * 16) & (RING - 1);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const half_t *vp = Vt + (dt * 16 + l15) * VLD + 4 * lq;
+                const half4_t v0 = *(const half4_t *)(vp + s0);
+                const half4_t v1 = *(const half4_t *)(vp + s1);
+                half8_t vf;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    vf[i] = v0[i];
+                    vf[4 + i] = v1[i];
+                }
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
+            }
+        }
+        {
+            half_t *orow = out + (row0 + qi) * C + h * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                half4_t o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)oacc[dt][r];
+                *(half4_t *)(orow + dt * 16 + 4 * lq) = o;
+            }
+        }
+        // ---- the new keys overwrite slots of keys < k0 + 128 + ... that this tile still read: barrier on both sides ----
+        __syncthreads();
+        if (more) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int c = tid + 512 * it;
+                *(half8_t *)(Ks + ((knew + (c >> 3)) & (RING - 1)) * KLD + (c & 7) * 8) = kn[it];
+                *(half8_t *)(Vt + (c >> 4) * VLD + ((knew + (c & 15) * 8) & (RING - 1))) = vn[it];
+            }
+        }
+        qf[0] = qn[0];
+        qf[1] = qn[1];
+        __syncthreads();
+    }
+}
+
+static int g_att_force_restage = 0;   // test hook (mibc_debug_attention_compare): run the re-staging v2 kernel
+
 extern "C" int mibc_launch_window_attention_v2(hipStream_t s, const half_t *qk, const half_t *vT, half_t *out,
                                                int N, int T, int C, int H, int ld, int win_upper,
                                                int win_lower) {
@@ -396,6 +592,11 @@ extern "C" int mibc_launch_window_attention_v2(hipStream_t s, const half_t *qk, 
     kw += kw & 1;
     const int split = (((T + 11) / 12) + 3) / 4 * 4;
     const int npairs = N * H;
+    if (!g_att_force_restage && kw > 4 && kw <= 18 && back % 16 == 0 && T % 128 == 0 && T >= 256) {
+        hipLaunchKernelGGL((window_attention_v3_kernel<18>), dim3(npairs), dim3(512), 0, s, qk, vT, out, T, C, H, ld,
+                           win_upper, win_lower, split, back);
+        return 0;
+    }
     dim3 grid(((npairs + 7) / 8) * 8 * ((T + 127) / 128));
     if (kw <= 4) {
         hipLaunchKernelGGL((window_attention_v2_kernel<4>), grid, dim3(512), 0, s, qk, vT, out, T, C, H, ld, win_upper, win_lower, split, back, npairs);
@@ -463,4 +664,62 @@ extern "C" int mibc_launch_residual_rmsnorm(hipStream_t s, const half_t *in, hal
         return 1;
     }
     return 0;
+}
+
+// Test-only: run the windowed attention on random q | k, vT with the ring kernel (v3) and with the re-staging kernel
+// (v2); the two perform the same operations per (query, key tile), so their outputs must be bit-identical.
+// Returns 0 and the number of differing output halfs, the two timings (ms per launch).
+#include <vector>
+extern "C" int mibc_debug_attention_compare(int N, int T, int H, int win_upper, int win_lower, int iters,
+                                            long long *ndiff, float *ms_ring, float *ms_restage) {
+    const int C = H * 64, ld = 2 * C;
+    uint32_t seed = 777u + (uint32_t)(N + 3 * T + 7 * H);
+    auto lcg = [&]() {
+        seed = seed * 1664525u + 1013904223u;
+        return (float)((seed >> 9) & 0x7fff) / 16384.0f - 1.0f;
+    };
+    std::vector<half_t> hqk((size_t)N * T * ld), hv((size_t)N * C * T);
+    for (auto &v : hqk) v = (half_t)(lcg() * 1.5f);
+    for (auto &v : hv) v = (half_t)lcg();
+    half_t *qk = nullptr, *vT = nullptr, *o1 = nullptr, *o2 = nullptr;
+    const size_t ob = (size_t)N * T * C * 2;
+    if (hipMalloc((void **)&qk, hqk.size() * 2) != hipSuccess || hipMalloc((void **)&vT, hv.size() * 2) != hipSuccess ||
+        hipMalloc((void **)&o1, ob) != hipSuccess || hipMalloc((void **)&o2, ob) != hipSuccess)
+        return -1;
+    (void)hipMemcpy(qk, hqk.data(), hqk.size() * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(vT, hv.data(), hv.size() * 2, hipMemcpyHostToDevice);
+    (void)hipMemset(o1, 0, ob);
+    (void)hipMemset(o2, 0, ob);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float ms[2] = {0, 0};
+    int rc = 0;
+    for (int which = 0; which < 2 && rc == 0; ++which) {
+        g_att_force_restage = which;
+        half_t *o = which ? o2 : o1;
+        if (mibc_launch_window_attention_v2(nullptr, qk, vT, o, N, T, C, H, ld, win_upper, win_lower) != 0) rc = -2;
+        (void)hipEventRecord(e0, nullptr);
+        for (int i = 0; i < iters && rc == 0; ++i)
+            (void)mibc_launch_window_attention_v2(nullptr, qk, vT, o, N, T, C, H, ld, win_upper, win_lower);
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms[which], e0, e1);
+        ms[which] /= (float)(iters > 0 ? iters : 1);
+    }
+    g_att_force_restage = 0;
+    if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = -3;
+    long long nd = 0;
+    if (rc == 0) {
+        std::vector<uint16_t> a(ob / 2), b(ob / 2);
+        (void)hipMemcpy(a.data(), o1, ob, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(b.data(), o2, ob, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < a.size(); ++i) nd += (a[i] != b[i]);
+    }
+    (void)hipFree(qk); (void)hipFree(vT); (void)hipFree(o1); (void)hipFree(o2);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ndiff) *ndiff = nd;
+    if (ms_ring) *ms_ring = ms[0];
+    if (ms_restage) *ms_restage = ms[1];
+    return rc;
 }
