@@ -12,6 +12,8 @@
 // LDS as full 256-byte rows (16-byte stores per lane) — the head's scores are the largest HBM
 // stream of the LSTM models (2 KB/step for hac).
 #include "common.h"
+
+#include <type_traits>
 #include "engine.h"
 #include <stdlib.h>
 
@@ -308,7 +310,39 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmArgs p) {
         return;
     }
 
-    // epilogue: D rows = output columns (weights), D cols = output rows m
+    // epilogue: D rows = output columns (weights), D cols = output rows m.
+    // The lane's 32 bias values are fetched in ONE batch and the activation switch sits outside the element loops: a
+    // load + branch per element costs one exposed L2 round trip each (hipcc waits vmcnt(0) per load here).
+    if (p.bias != nullptr) {
+        float4_t bv[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                bv[i][q] = *(const float4_t *)(p.bias + c0 + wn * 64 + i * 32 + 8 * q + 4 * (lane >> 5));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][jj][q * 4 + e] += bv[i][q][e];
+    }
+    auto activate = [&](auto act_c) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[i][jj][r] = (ACT == 3) ? 5.0f * fast_tanh(acc[i][jj][r]) : act_apply(acc[i][jj][r], ACT);
+    };
+    if (p.act == 3) activate(std::integral_constant<int, 3>{});
+    else if (p.act == 0) activate(std::integral_constant<int, 0>{});
+    else if (p.act == 1) activate(std::integral_constant<int, 1>{});
+    else if (p.act == 2) activate(std::integral_constant<int, 2>{});
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -319,16 +353,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmArgs p) {
                 const int cloc = wn * 64 + i * 32 + 8 * q + 4 * (lane >> 5);
                 half4_t h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[i][jj][q * 4 + e];
-                    if (p.bias != nullptr) v += p.bias[c0 + cloc + e];
-                    if (p.act == 3) {
-                        v = 5.0f * fast_tanh(v);
-                    } else if (p.act >= 0) {
-                        v = act_apply(v, p.act);
-                    }
-                    h[e] = (half_t)v;
-                }
+                for (int e = 0; e < 4; ++e) h[e] = (half_t)acc[i][jj][q * 4 + e];
                 *(half4_t *)(Cs + mloc * G_CLD + cloc) = h;
             }
         }
