@@ -2,7 +2,7 @@
 """bench.py — Samples/s of the simplex-basecalling hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--model hac|sup|sup5|tiny]
-                    [--also-sup 0|1] [--through-host 0|1] [--no-cpu-baseline]
+                    [--also-sup 0|1] [--through-host 0|1] [--no-cpu-baseline] [--profile-run]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = one pass of the whole hot path (conv -> 5x LSTM | 18x transformer layer -> CRF head -> beam-search
@@ -212,7 +212,7 @@ def auto_batch(eng, cfg, t_in, device):
 
 
 def run_config(capi, synth, cfg, model_key, device, steps, warmup, batch=0, seed=0xD0AD0, timed_barrier=None,
-               with_cpu=False, cpu_kind="hac"):
+               with_cpu=False, cpu_kind="hac", check_parity=True):
     """Times `steps` steps of one configuration on this rank's GPU.  Returns (result dict, elapsed seconds)."""
     t_in = cfg.chunk_size
     ws = synth.make_weights(cfg, seed=42)
@@ -247,7 +247,8 @@ def run_config(capi, synth, cfg, model_key, device, steps, warmup, batch=0, seed
     out = np.zeros((3, n, T), np.int8)
     eng.d2h(out, d_out)
     bases = int(out[0].sum())
-    parity = bench_scale_parity(eng, out, d_in, n, t_in, T, base.shape[0])
+    # (--profile-run: skipped, so that a rocprofv3 --stats summary of this command averages full-batch launches only)
+    parity = bench_scale_parity(eng, out, d_in, n, t_in, T, base.shape[0]) if check_parity else {"ok": None, "skipped": True}
     kname, ksub = dominant_kernel(cfg, n)
     if cfg.tx is None:
         k_ms = float(np.mean(lstm_ms))
@@ -295,6 +296,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="chunks per GPU per step (0 = auto)")
     ap.add_argument("--model", default="hac")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="for rocprofv3 --stats: no small-batch parity call, so per-kernel averages are full-batch launches")
     ap.add_argument("--also-sup", type=int, default=1,
                     help="N=1 only: after the headline (hac) run, time the two sup configurations of BASELINE.json "
                          "and report them under extra (the metric names hac & sup)")
@@ -332,7 +335,8 @@ def main():
     res, el, n, T, t_in, ws = run_config(capi, synth, cfg, args.model, local_rank, args.steps, args.warmup, args.batch,
                                          seed=0xD0AD0 + rank, timed_barrier=barrier,
                                          with_cpu=single and not args.no_cpu_baseline,
-                                         cpu_kind="sup" if args.model in ("sup", "sup5") else "hac")
+                                         cpu_kind="sup" if args.model in ("sup", "sup5") else "hac",
+                                         check_parity=not args.profile_run)
     if world > 1:
         tt = torch.tensor([el], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

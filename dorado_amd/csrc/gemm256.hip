@@ -155,16 +155,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const int mrow = m0 + wm * 64 + rt * 32;        // first of the 32 rows of this accumulator column block
-            // rows this lane stores after the transposition: prow = lane/4 + 16 i
-            half_t *orow[2];
-            bool ook[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = mrow + (lane >> 2) + 16 * i;
-                ook[i] = m < p.M;
-                const int mm = ook[i] ? m : 0;
-                orow[i] = p.out + (long)(mm / p.o_div) * p.o_outer + (long)(mm % p.o_div) * p.o_inner;
-            }
             const int mmine = mrow + l31;                    // the row whose values this lane holds
             if (EPI == 1 && cw < p.rope_cols) {
                 // rotary embedding: head = 64 columns = tiles (g, g+1); first half rotates with the second
@@ -204,12 +194,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                 }
                 continue;
             }
+            // ---- bias / activation (EPI 0), SwiGLU (EPI 2), then rows leave through the wave's LDS patch.  A store
+            // instruction covers 8 rows x 128 B (whole cache lines): pairs of 32-column accumulator tiles are transposed
+            // 16 rows at a time (the CU's store path costs ~100 cycles per instruction and per 16 row segments, whatever
+            // their width: with 16 rows x 64 B per instruction the stores were a third of a K = 512 tile) ----
             constexpr int NG = (EPI == 2) ? 2 : 4;
+            if (EPI == 0) {
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                // bias + activation of EPI 0 on the 16 values of (g, rt): the activation code is a wave-uniform switch
-                // OUTSIDE the element loops
-                if (EPI == 0) {
+                for (int g = 0; g < NG; ++g) {
                     if (p.bias != nullptr) {
                         LDSP(const float) bz = (LDSP(const float))(smem3 + G2_OFF_BIAS) + e_zone * 256 + wn * 128 + g * 32 + 4 * lhi;
 #pragma unroll
@@ -219,6 +211,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                             for (int e = 0; e < 4; ++e) acc[g][rt][q * 4 + e] += bv[e];
                         }
                     }
+                    // the activation code is a wave-uniform switch OUTSIDE the element loops
                     if (p.act == 3) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[g][rt][r] = 5.0f * fast_tanh(acc[g][rt][r]);
@@ -233,35 +226,64 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                         for (int r = 0; r < 16; ++r) acc[g][rt][r] = act_apply(acc[g][rt][r], 2);
                     }
                 }
+            }
+            // rows this lane stores after the transposition of half hh: mrow + 16 hh + lane/8 + 8 i
+            half_t *orow2[2][2];
+            bool ook2[2][2];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    half4_t hv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = q * 4 + e;
-                        float v = acc[g][rt][r];
-                        if (EPI == 2) {
-                            // SwiGLU (nn/TxModules.cpp:171-175): silu(gate) * y on the f16-rounded GEMM outputs
-                            const float y = (float)(half_t)v, gt = (float)(half_t)acc[g + 2][rt][r];
-                            v = gt * fast_sigmoid(gt) * y;
-                        }
-                        hv[e] = (half_t)v;
-                    }
-                    *(LDSP(half4_t))(patch + l31 * G2_PATCH_LD + 8 * q + 4 * lhi) = hv;
-                }
-                __builtin_amdgcn_wave_barrier();
-                const int ocol = (EPI == 2) ? ((e_c0 >> 1) + wn * 64 + g * 32) : (cw + g * 32);
+            for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int prow = (lane >> 2) + 16 * i, seg = lane & 3;
-                    const half8_t v = *(LDSP(const half8_t))(patch + prow * G2_PATCH_LD + seg * 8);
-                    if (DBG & 1) {
-                        asm volatile("" ::"v"(v));
-                    } else if (ook[i]) {
-                        *(half8_t *)(orow[i] + ocol + seg * 8) = v;
-                    }
+                    const int m = mrow + 16 * hh + (lane >> 3) + 8 * i;
+                    ook2[hh][i] = m < p.M;
+                    const int mm = ook2[hh][i] ? m : 0;
+                    orow2[hh][i] = p.out + (long)(mm / p.o_div) * p.o_outer + (long)(mm % p.o_div) * p.o_inner;
                 }
-                __builtin_amdgcn_wave_barrier();
+            constexpr int NGP = NG / 2;
+            constexpr int PLD = 72;   // halfs per patch row: 64 columns + 8 pad
+#pragma unroll
+            for (int gp = 0; gp < NGP; ++gp) {
+                half4_t hv[2][4];
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int g = gp * 2 + g2;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = q * 4 + e;
+                            float v = acc[g][rt][r];
+                            if (EPI == 2) {
+                                // SwiGLU (nn/TxModules.cpp:171-175): silu(gate) * y on the f16-rounded GEMM outputs
+                                const float y = (float)(half_t)v, gt = (float)(half_t)acc[g + 2][rt][r];
+                                v = gt * fast_sigmoid(gt) * y;
+                            }
+                            hv[g2][q][e] = (half_t)v;
+                        }
+                }
+                const int ocol = (EPI == 2) ? ((e_c0 >> 1) + wn * 64) : (cw + gp * 64);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    if ((l31 >> 4) == hh) {
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                *(LDSP(half4_t))(patch + (l31 & 15) * PLD + g2 * 32 + 8 * q + 4 * lhi) = hv[g2][q];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int prow = (lane >> 3) + 8 * i, seg = lane & 7;
+                        const half8_t v = *(LDSP(const half8_t))(patch + prow * PLD + seg * 8);
+                        if (DBG & 1) {
+                            asm volatile("" ::"v"(v));
+                        } else if (ook2[hh][i]) {
+                            *(half8_t *)(orow2[hh][i] + ocol + seg * 8) = v;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
     };

@@ -15,7 +15,7 @@ cut -c1-600 $O/${TAG}_bench.json
 for spec in "hac 16384 9996" "sup 8192 9996" "sup5 1024 12288"; do
   set -- $spec; M=$1; N=$2; TIN=$3
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$M -o s -- \
-      python $R/bench.py --model $M --steps 2 --warmup 1 --also-sup 0 --through-host 0 --no-cpu-baseline > $O/stats_$M.log 2>&1
+      python $R/bench.py --model $M --steps 3 --warmup 1 --also-sup 0 --through-host 0 --no-cpu-baseline --profile-run > $O/stats_$M.log 2>&1
   f=$(find $O/stats_$M -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp $f $O/${TAG}_kernel_stats_${M}_n$N.csv && head -6 $O/${TAG}_kernel_stats_${M}_n$N.csv
   timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch_$M -o p -- \
