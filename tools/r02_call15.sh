@@ -1,6 +1,7 @@
 #!/bin/bash
-rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|mclk|Power|Temp" | head -8
-for k in 1 2; do
-python bench.py --no-cpu-baseline --also-sup 0 --through-host 0 --steps 3 --warmup 1 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['stage_ms_last_step']['lstm_layer'][:5], d['stage_ms_last_step']['decode'])"
+for k in 1 0 1 0; do
+  MIBC_DECODE_STAGGER=$k timeout 600 python tools/stage_times.py --lib dbg --model hac --batch 16384 --steps 2 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['env'], d['decode'], d['head'], d['total'])"
 done
-rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power" | head -4
+for k in 1 0; do
+  MIBC_DECODE_STAGGER=$k timeout 600 python tools/stage_times.py --lib dbg --model sup --batch 8192 --steps 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['env'], d['decode'], d['head'], d['total'])"
+done
