@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
         // double-buffering of the anti-phase schedule).  Layout [cluster][member][pass][wave][rt][q][lane][4]: every
         // access is one coalesced 1 KiB wave transaction; 32 KiB per workgroup and pass.
         auto gates = [&](int gp, int gt, bool gfirst, unsigned long long gvm) __attribute__((always_inline)) {
-            if (gfirst) {   // zero initial state (nn/LSTMStack.cpp:29-41: no h0 / c0 given)
+            if (gfirst || (DBG & 128)) {   // zero initial state (nn/LSTMStack.cpp:29-41: no h0 / c0 given); DBG 128: ablation, no c loads
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -495,7 +495,7 @@ extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin
                            Xout, Wt, biascl, zeros, cbuf, flags, err, T, N, reverse, cpx, resident, tmask); \
         return 0;                                                                                           \
     }
-        switch (dbg) { CL_DBG(1) CL_DBG(2) CL_DBG(4) CL_DBG(8) CL_DBG(16) CL_DBG(18) CL_DBG(22) CL_DBG(27) CL_DBG(32) CL_DBG(64) CL_DBG(96) default: break; }
+        switch (dbg) { CL_DBG(1) CL_DBG(2) CL_DBG(4) CL_DBG(8) CL_DBG(16) CL_DBG(18) CL_DBG(22) CL_DBG(27) CL_DBG(32) CL_DBG(64) CL_DBG(96) CL_DBG(128) default: break; }
 #undef CL_DBG
     }
 #endif
