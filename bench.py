@@ -378,7 +378,8 @@ def main():
                 th = hostapi.bench_through_host(cfg, ws, reads, n_warm=2 * n, n_reads=nb * n, num_runners=2, batch_size=n)
                 th["vs_device_resident"] = th["samples_per_s"] / value
                 th["what"] = (f"{nb} batches of {n} single-chunk reads through SimplexBasecaller (2 runners, two "
-                              f"batches in flight, pinned buffers, PCIe both ways, string slicing + stitching)")
+                              f"batches in flight, pinned buffers, PCIe both ways, string slicing + stitching), "
+                              f"timed from the first read's chunking until the last read is called")
                 line["through_host"] = th
             except Exception as ex:
                 line["through_host"] = {"error": repr(ex)}
