@@ -204,23 +204,26 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
     // one half of a tile's MFMAs: KSX k-steps x 4 gates on the fragments of ring slot slot_b
     auto half_tile = [&](float4v_ws (&acc)[4], unsigned slot_b) __attribute__((always_inline)) {
         LDSP(const unsigned char) sp = smem3 + slot_b + foff;
-        constexpr int PFD = 4;   // fragment buffers: PFD - 1 k-steps of LDS latency cover
+        // fragment ring: 5 buffers, 2 k-steps of look-ahead, order pinned (the keep-alive operands stop the register
+        // allocator from folding the ring into fewer physical buffers)
+        constexpr int PFD = 5, PLA = 2;
         half8_t bq[PFD];
         if (DBG & 16) {
 #pragma unroll
             for (int q = 0; q < PFD; ++q) bq[q] = (half8_t)((half_t)(0.001f * (q + 1)));
         } else {
 #pragma unroll
-            for (int q = 0; q < PFD - 1; ++q) bq[q] = *(LDSP(const half8_t))(sp + q * 1024);
+            for (int q = 0; q < PLA; ++q) bq[q] = *(LDSP(const half8_t))(sp + q * 1024);
         }
-        // NOTE (unresolved): this block is ORDER-SENSITIVE in a way the emitted ISA does not explain.  Pinning the
-        // prefetch in front of each k-step's MFMAs with __builtin_amdgcn_sched_barrier(0), or wrapping the block in
-        // s_setprio 1 / 0, gives WRONG results on every run although every RAW wait and MFMA wait state is present;
-        // the schedule hipcc picks by itself (below) is bit-identical to x8 on every run.  Until that is understood
-        // the kernel is an experiment: off in the product, its tests opt-in (tests/test_gpu_ws_lstm.py).
+        __builtin_amdgcn_s_setprio(1);   // the wave in its matrix block wins issue arbitration over its partner's VALU / VMEM block
         cl_static_for<KSX>([&](auto ks_c) __attribute__((always_inline)) {
             constexpr int ks = decltype(ks_c)::value;
-            if (!(DBG & 16) && ks + PFD - 1 < KSX) bq[(ks + PFD - 1) % PFD] = *(LDSP(const half8_t))(sp + (ks + PFD - 1) * 1024);
+            if (!(DBG & 16) && ks + PLA < KSX) {
+                bq[(ks + PLA) % PFD] = *(LDSP(const half8_t))(sp + (ks + PLA) * 1024);
+                if (ks > 1) asm volatile("" ::"v"(bq[(ks - 1) % PFD]), "v"(bq[(ks - 2) % PFD]));
+                else if (ks > 0) asm volatile("" ::"v"(bq[(ks - 1) % PFD]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
             if (!(DBG & 4)) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -232,10 +235,15 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
             } else {
                 asm volatile("" ::"v"(bq[ks % PFD]));
             }
+            __builtin_amdgcn_sched_barrier(0);
         });
 
+
         // XDL write -> VALU / LDS-store read of the accumulators: 18 wait states
-        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        __builtin_amdgcn_s_setprio(0);
+        // The wait is tied to the accumulators ("+v"): register-only VALU reads of acc could otherwise be scheduled ABOVE a
+        // bare asm volatile("s_nop") — right behind the last MFMA, reading accumulators that miss its contribution.
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])::"memory");
     };
 
     if (!hwave) {
@@ -392,8 +400,8 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
             LDSP(unsigned char) hs = hand0 + ((i & 1) ? 16384 : 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = *(LDSP(const float4v_ws))(hs + lane * 16 + g * 1024);
-            const float4v_ws cv = *(LDSP(const float4v_ws))(smem3 + pslot_b + L::ACT + sim * 1024 + lane * 16);
             half_tile(acc, pslot_b);
+            const float4v_ws cv = *(LDSP(const float4v_ws))(smem3 + pslot_b + L::ACT + sim * 1024 + lane * 16);
             WS_STAMP(1, 2);
             // ---- gates (D row = hidden 4 lq + e, D col = batch row l15) ----
             float4v_ws cn;

@@ -1,23 +1,15 @@
 """Weight-stationary cluster LSTM kernel, lstm_ws.hip (pytest -m gpu).
 
-EXPERIMENTAL kernel (off in the product: measured slower than lstm_layer_x8_kernel so far; enabled here
-through mibc_debug_set_ws_min_rows).  For lstm_size 384 (hac) six workgroups of a cluster keep the layer's weights in
+Enabled here through mibc_debug_set_ws_min_rows when the engine's default threshold does not select it.  For lstm_size 384 (hac) six workgroups of a cluster keep the layer's weights in
 their register files and exchange h through the layer output.  It performs, element for element, the arithmetic of lstm_layer_x8_kernel (same MFMA shape, same k order, same gate functions), so the contract
 is BIT-IDENTITY between a large batch (cluster kernel) and the same rows in batches below the threshold (x8), which
 the BASELINE-size parity test pins to the reference (test_gpu_baseline_parity.py, N = 64)."""
-import os
-
 import numpy as np
 import pytest
 
 from dorado_amd import capi, config, synth
 
-# Opt-in: MIBC_TEST_EXPERIMENTAL=1 python -m pytest tests/test_gpu_ws_lstm.py -m gpu.  The kernel is not part of the
-# product path, and two mere reschedulings of its matrix block gave wrong results for a reason not yet understood
-# (csrc/lstm_ws.hip, NOTE), so its parity tests do not gate the suite.
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("MIBC_TEST_EXPERIMENTAL") != "1",
-                                 reason="experimental kernel: set MIBC_TEST_EXPERIMENTAL=1")]
+pytestmark = pytest.mark.gpu
 
 
 def _cfg(layers=5):
