@@ -16,22 +16,23 @@
 // keeps the fp32 cell state in a private scratch tile and stores its 16 x 16 block of h_t; the x-wave is one tile
 // ahead.  One wave of a SIMD feeds the matrix pipe while the other one issues DMAs / gate math.
 // Activations [x_t | h_{t-1}] (16 rows x 768, 24 KB) and the tile's cell state (4 KB) arrive by direct LDS DMA
-// (issued by the x-waves) through a 4-stage ring.  h_t goes into Xout[t] — the layer output IS the exchange
+// (issued by the x-waves) through two 4-slot rings (the halves of a tile are consumed one iteration apart).  h_t goes into Xout[t] — the layer output IS the exchange
 // buffer — and is read back by all six members R tiles (one time step) later, so the hand-off latency is hidden by
 // construction; progress counters per (member, SIMD) make it safe (cdna_hip_programming.md §6 Guideline 16 R1):
 // an h-wave publishes "tiles complete" only after a counted s_waitcnt has retired its h stores, an x-wave checks a
 // DMA-fetched snapshot of the 24 counters before it requests rows of h_{t-1} (bounded DMA-refresh poll as the slow
 // path).  No VGPR-returning global load exists inside the loop (beside LDS-DMA traffic hipcc would drain vmcnt(0)
 // before the first ds_read of every iteration).
-// Measured history in DESIGN.md §4 (one wave per SIMD holding all 384 weight registers was issue-bound: 75 ms).
+// Measured history in DESIGN.md §4 (one wave per SIMD holding all 384 weight registers was issue-bound: 75 ms; this
+// variant 64.5 ms against 59.9 for lstm_layer_x8_kernel on the same box, so the engine does not select it by default).
 #include "common.h"
 #include "cluster_util.h"
 
 #define WS_TR 16                  // batch rows per tile
-#define WS_D 2                    // the request for tile i + 1 + D is issued in iteration i (x-waves run one tile ahead)
-#define WS_NST (WS_D + 2)         // ring stages
+#define WS_LA 3                   // look-ahead in iterations: x half of tile i + 1 + LA and h half of tile i + LA are requested in iteration i
+#define WS_NSL (WS_LA + 1)        // slots of each ring
 #define WS_SPIN_LIMIT 400000u
-#define WS_RMIN 10                // fewest row tiles per cluster (progress is published / observed a few tiles late)
+#define WS_RMIN 12                // fewest row tiles per cluster (progress is published / observed a few tiles late)
 
 typedef float float4v_ws __attribute__((ext_vector_type(4)));
 
@@ -71,7 +72,10 @@ struct WsLayout {
     static constexpr int KA = KSX < 8 ? KSX : 8;              // k-steps of a wave whose weights live in AGPRs
     static constexpr int ACT = KS * 1024;                     // bytes of one activation tile
     static constexpr int STAGE = ACT + 4096;                  // + the tile's cell state (4 x 1 KiB)
-    static constexpr int OFF_HAND = WS_NST * STAGE;           // [2 slots][4 SIMDs][4 gates][64 lanes] float4
+    static constexpr int XS = KSX * 1024;                     // x ring slot: the x_t half of a tile's activations
+    static constexpr int HS = KSX * 1024 + 4096;              // h ring slot: the h_{t-1} half + the tile's cell state
+    static constexpr int OFF_XR = 0, OFF_HR = WS_NSL * XS;
+    static constexpr int OFF_HAND = OFF_HR + WS_NSL * HS;     // [2 slots][4 SIMDs][4 gates][64 lanes] float4
     static constexpr int OFF_BIAS = OFF_HAND + 2 * 4 * 4096;  // [4 SIMDs][4 gates][16] f32
     static constexpr int OFF_FLAGZ = OFF_BIAS + 1024;         // [4][64] u32 snapshot of the cluster's counters
     static constexpr int BYTES = OFF_FLAGZ + 1024;
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
     const unsigned dcol = (unsigned)(((lane & 3) ^ ((drow >> 2) & 3)) * 16);
     const unsigned lane_off = (unsigned)(drow * C * 2) + dcol;   // bytes
     const unsigned lane_off_z = dcol;
-    const unsigned foff = (unsigned)(l15 * 64 + ((lq ^ ((l15 >> 2) & 3)) << 4)) + (hwave ? KSX * 1024u : 0u);
+    const unsigned foff = (unsigned)(l15 * 64 + ((lq ^ ((l15 >> 2) & 3)) << 4)) + (hwave ? (unsigned)L::OFF_HR : (unsigned)L::OFF_XR);
     const unsigned long long x0 = (unsigned long long)Xin, o0 = (unsigned long long)Xout, z0 = (unsigned long long)zeros;
     const unsigned long long c0 = (unsigned long long)(cbuf + ((((size_t)cl * KCL + j) * rmax) * 4 + sim) * 256);
     gu32 *clflags = (gu32 *)(flags + (size_t)cl * NF * 16);
@@ -176,29 +180,35 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
     const long long rel0 = ((long long)(reverse ? (T - 1) : 0) * N + n0) * C * 2;
     const int total = T * R;
 
-    // DMA requests of one tile (x-waves): flags snapshot, KS/4 activation blocks (k-steps sim, sim + 4, ...: the
-    // first KSX / 4 from x_t, the rest from h_{t-1}), the cell-state block of SIMD sim.
-    auto fetch = [&](long long rel, bool first, unsigned ctile_b, unsigned slot_b) __attribute__((always_inline)) {
+    // DMA requests of the x-waves (wave sim: k-steps sim, sim + 4, ... of a half).  The two halves of a tile live in
+    // two rings because they are consumed one iteration apart (the x-waves run one tile ahead): x_t half of tile i + 1 + LA
+    // and h_{t-1} half + cell state + flags snapshot of tile i + LA are requested in iteration i.
+    auto fetch_x = [&](long long rel, unsigned slot_b) __attribute__((always_inline)) {
         unsigned long long xb = x0 + (unsigned long long)rel;
+        asm volatile("" : "+s"(xb));
+        const unsigned l = lds0 + L::OFF_XR + slot_b;
+#pragma unroll
+        for (int q = 0; q < KSX / 4; ++q) {
+            const int ks = 4 * q + sim;
+            cl_dma16_sc1((ghalf_p)(xb + lane_off + (unsigned)(ks * 64)), l + (unsigned)ks * 1024u);
+        }
+    };
+    auto fetch_h = [&](long long rel, bool first, unsigned ctile_b, unsigned slot_b) __attribute__((always_inline)) {
         unsigned long long hb = first ? z0 : o0 + (unsigned long long)(rel - dstep);
         unsigned long long cb = first ? z0 : c0 + ctile_b;
         unsigned long long fb = (unsigned long long)clflags;
-        asm volatile("" : "+s"(xb));
         asm volatile("" : "+s"(hb));
         asm volatile("" : "+s"(cb));
         asm volatile("" : "+s"(fb));
         const unsigned hoff = first ? lane_off_z : lane_off;
-        const unsigned l = lds0 + slot_b;
+        const unsigned l = lds0 + L::OFF_HR + slot_b;
         cl_dma4_sc1((const unsigned *)(fb + flag_lane), lds0 + L::OFF_FLAGZ + sim * 256);
 #pragma unroll
-        for (int q = 0; q < KS / 4; ++q) {
+        for (int q = 0; q < KSX / 4; ++q) {
             const int ks = 4 * q + sim;
-            if (q < KSX / 4)
-                cl_dma16_sc1((ghalf_p)(xb + lane_off + (unsigned)(ks * 64)), l + (unsigned)ks * 1024u);
-            else
-                cl_dma16_sc1((ghalf_p)(hb + hoff + (unsigned)((ks - KSX) * 64)), l + (unsigned)ks * 1024u);
+            cl_dma16_sc1((ghalf_p)(hb + hoff + (unsigned)(ks * 64)), l + (unsigned)ks * 1024u);
         }
-        cl_dma16_sc1((ghalf_p)(cb + (unsigned)(lane * 16)), l + L::ACT + (unsigned)sim * 1024u);
+        cl_dma16_sc1((ghalf_p)(cb + (unsigned)(lane * 16)), l + KSX * 1024u + (unsigned)sim * 1024u);
     };
 
     // one half of a tile's MFMAs: KSX k-steps x 4 gates on the fragments of ring slot slot_b
@@ -248,23 +258,37 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
 
     if (!hwave) {
         // =========================== X-WAVES: DMA + x half, one tile ahead ===========================
-        int fs = 0, fr = 0;                 // next tile to request: step (only "== 0" matters), row tile
-        long long frel = rel0;
-        unsigned fslot_b = 0;
-        auto advance_f = [&]() __attribute__((always_inline)) {
-            if (++fr == R) {
-                fr = 0;
-                ++fs;
-                frel += wrap_b;
+        // next tiles to request: x half (row tile frx, offset relx, slot) and h half (step fsh, row tile frh, ...)
+        int frx = 0, fsh = 0, frh = 0;
+        long long relx = rel0, relh = rel0;
+        unsigned slotx_b = 0, sloth_b = 0;
+        auto advance_x = [&]() __attribute__((always_inline)) {
+            if (++frx == R) {
+                frx = 0;
+                relx += wrap_b;
             } else {
-                frel += tile_b;
+                relx += tile_b;
+            }
+        };
+        auto advance_h = [&]() __attribute__((always_inline)) {
+            if (++frh == R) {
+                frh = 0;
+                ++fsh;
+                relh += wrap_b;
+            } else {
+                relh += tile_b;
             }
         };
 #pragma unroll
-        for (int d = 0; d <= WS_D; ++d) {   // tiles 0 .. D
-            fetch(frel, true, 0u, fslot_b);
-            fslot_b = (fslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : fslot_b + L::STAGE;
-            advance_f();
+        for (int d = 0; d <= WS_LA; ++d) {   // x halves of tiles 0 .. LA, h halves of tiles 0 .. LA - 1
+            fetch_x(relx, slotx_b);
+            slotx_b = (slotx_b + L::XS == WS_NSL * L::XS) ? 0u : slotx_b + L::XS;
+            advance_x();
+            if (d < WS_LA) {
+                fetch_h(relh, true, 0u, sloth_b);
+                sloth_b = (sloth_b + L::HS == WS_NSL * L::HS) ? 0u : sloth_b + L::HS;
+                advance_h();
+            }
         }
         unsigned cslot_b = 0;               // ring slot of the tile whose x half is computed next
         int pr = 0;                         // row tile / byte offset of the tile whose results are stored next
@@ -280,27 +304,27 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
             half_tile(acc, cslot_b);
 #pragma unroll
             for (int g = 0; g < 4; ++g) *(LDSP(float4v_ws))(hand + g * 1024) = acc[g];
-            cslot_b += L::STAGE;
+            cslot_b += L::XS;
         }
 #pragma nounroll
         for (int i = 0; i <= total; ++i) {   // iteration `total` only stores the last tile's results
             WS_STAMP(0, 5);
-            // tile i + 1 (x half, this wave) and tile i (h half, partner) have landed: requested in iteration i - D or
-            // earlier; younger requests = the XOPS of each of the D - 1 iterations since
-            if ((DBG & 2) || i <= WS_D) {
+            // tile i + 1 (x half, this wave) and tile i (h half, partner) have landed: both requested in iteration
+            // i - LA; younger requests = the XOPS of each of the LA - 1 iterations since
+            if ((DBG & 2) || i <= WS_LA) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::XOPS * (WS_D - 1)) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::XOPS * (WS_LA - 1)) : "memory");
             }
             WS_STAMP(0, 6);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own hand-off stores of the previous iteration
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             WS_STAMP(0, 0);
-            // ---- publish: the wait above retired every operation of iterations <= i - 2, i.e. the stores of tiles
-            // 0 .. i - 3 ----
+            // ---- publish: the wait above retired every operation of iterations <= i - LA, i.e. the stores of tiles
+            // 0 .. i - LA - 1 ----
             if (!(DBG & 32) && lane == 0) {
-                const unsigned p = (unsigned)(i > 2 ? i - 2 : 0);
+                const unsigned p = (unsigned)(i > WS_LA ? i - WS_LA : 0);
                 if (xcd_local)   // members share one L2: a plain (write-back) store is visible to their sc1 loads
                     __hip_atomic_store(myflag, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else
@@ -332,10 +356,11 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
                 }
             }
             WS_STAMP(0, 1);
-            // ---- request tile f = i + 1 + D; its h rows were produced as tile f - R by all members ----
+            // ---- requests: h half of tile f = i + LA (its h rows were produced as tile f - R by all members), x half of
+            // tile f + 1 ----
             {
-                const int f = i + 1 + WS_D;
-                if (f < total && fs > 0 && !(DBG & 8) && !dead) {
+                const int f = i + WS_LA;
+                if (f < total && fsh > 0 && !(DBG & 8) && !dead) {
                     const unsigned need = (unsigned)(f - R + 1);
                     const unsigned snap = *my_fz;
                     if (!__all(lane >= NF || snap >= need)) {
@@ -357,17 +382,22 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
                         } while (!good && ++spins < WS_SPIN_LIMIT);
                         if (!good) {
                             dead = true;
-                            if (lane == 0) atomicCAS(err, 0u, 0x80000000u | ((unsigned)cl << 16) | (unsigned)(fs & 0xffff));
+                            if (lane == 0) atomicCAS(err, 0u, 0x80000000u | ((unsigned)cl << 16) | (unsigned)(fsh & 0xffff));
                         }
                     }
                 }
                 if (DBG & 64) {   // ablation: every request hits the same cache-resident lines
-                    fetch(rel0, true, 0u, fslot_b);
+                    fetch_h(rel0, true, 0u, sloth_b);
+                    fetch_x(rel0, slotx_b);
                 } else if (!(DBG & 2) || i < R) {
-                    fetch(frel, fs == 0, (unsigned)fr * 4096u, fslot_b);
+                    fetch_h(relh, fsh == 0, (unsigned)frh * 4096u, sloth_b);
+                    fetch_x(relx, slotx_b);
                 }
-                fslot_b = (fslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : fslot_b + L::STAGE;
-                if (f + 1 < total) advance_f();   // past the end the last tile is requested again (nobody reads it)
+                sloth_b = (sloth_b + L::HS == WS_NSL * L::HS) ? 0u : sloth_b + L::HS;
+                slotx_b = (slotx_b + L::XS == WS_NSL * L::XS) ? 0u : slotx_b + L::XS;
+                // past the end the last tile is requested again (nobody reads it)
+                if (f + 1 < total) advance_h();
+                if (f + 2 < total) advance_x();
             }
             WS_STAMP(0, 2);
             // ---- x half of tile i + 1 -> hand-off slot (i + 1) & 1 (past the end: a dummy pass, nobody reads it) ----
@@ -379,7 +409,7 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
             LDSP(unsigned char) hd = hand + (((i + 1) & 1) ? 16384 : 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) *(LDSP(float4v_ws))(hd + g * 1024) = acc[g];
-            cslot_b = (cslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : cslot_b + L::STAGE;
+            cslot_b = (cslot_b + L::XS == WS_NSL * L::XS) ? 0u : cslot_b + L::XS;
             WS_STAMP(0, 4);
         }
     } else {
@@ -401,7 +431,7 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = *(LDSP(const float4v_ws))(hs + lane * 16 + g * 1024);
             half_tile(acc, pslot_b);
-            const float4v_ws cv = *(LDSP(const float4v_ws))(smem3 + pslot_b + L::ACT + sim * 1024 + lane * 16);
+            const float4v_ws cv = *(LDSP(const float4v_ws))(smem3 + L::OFF_HR + pslot_b + KSX * 1024 + sim * 1024 + lane * 16);
             WS_STAMP(1, 2);
             // ---- gates (D row = hidden 4 lq + e, D col = batch row l15) ----
             float4v_ws cn;
@@ -425,7 +455,7 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
             *(LDSP(float4v_ws))(hs + lane * 16) = cn;
             *(LDSP(half4_t))(hs + 1024 + (l15 * 24 + 4 * lq) * 2) = hv;
             WS_STAMP(1, 4);
-            pslot_b = (pslot_b + L::STAGE == WS_NST * L::STAGE) ? 0u : pslot_b + L::STAGE;
+            pslot_b = (pslot_b + L::HS == WS_NSL * L::HS) ? 0u : pslot_b + L::HS;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
