@@ -27,6 +27,9 @@ __device__ __forceinline__ void cl_dma16(ghalf_p g, unsigned lds_addr) {
 __device__ __forceinline__ void cl_dma16_sc1(ghalf_p g, unsigned lds_addr) {   // agent-scope (L1 bypass) load
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (lds_vptr)(size_t)lds_addr, 16, 0, 16);
 }
+__device__ __forceinline__ void cl_dma16_nt(ghalf_p g, unsigned lds_addr) {   // non-temporal (streamed once)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (lds_vptr)(size_t)lds_addr, 16, 0, 2);
+}
 __device__ __forceinline__ void cl_dma4_sc1(const unsigned *g, unsigned lds_addr) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (lds_vptr)(size_t)lds_addr, 4, 0, 16);
 }

@@ -190,7 +190,9 @@ __global__ __launch_bounds__(512) void lstm_layer_ws_kernel(
 #pragma unroll
         for (int q = 0; q < KSX / 4; ++q) {
             const int ks = 4 * q + sim;
-            cl_dma16_sc1((ghalf_p)(xb + lane_off + (unsigned)(ks * 64)), l + (unsigned)ks * 1024u);
+            if (DBG & 256) cl_dma16_nt((ghalf_p)(xb + lane_off + (unsigned)(ks * 64)), l + (unsigned)ks * 1024u);
+            else if (DBG & 512) cl_dma16((ghalf_p)(xb + lane_off + (unsigned)(ks * 64)), l + (unsigned)ks * 1024u);
+            else cl_dma16_sc1((ghalf_p)(xb + lane_off + (unsigned)(ks * 64)), l + (unsigned)ks * 1024u);
         }
     };
     auto fetch_h = [&](long long rel, bool first, unsigned ctile_b, unsigned slot_b) __attribute__((always_inline)) {
@@ -537,6 +539,8 @@ extern "C" int mibc_launch_lstm_layer_ws(hipStream_t s, int C, const half_t *Xin
         case 63: WS_LAUNCH(63); return 0;
         case 10: WS_LAUNCH(10); return 0;
         case 42: WS_LAUNCH(42); return 0;
+        case 256: WS_LAUNCH(256); return 0;
+        case 512: WS_LAUNCH(512); return 0;
         case 128: WS_LAUNCH(128); return 0;
         case 192: WS_LAUNCH(192); return 0;
         case 64: WS_LAUNCH(64); return 0;
