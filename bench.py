@@ -116,7 +116,7 @@ def cpu_baseline(cfg, ws, t_in, kind_model):
     (dorado/basecall/crf_utils.cpp:208-233: clamp(free_RAM / (GB_per_runner * batch / 128), 1, hardware_concurrency)
     with 4.5 GB (hac) / 12.5 GB (sup) per runner at batch 128 and the CPU batch of SURVEY.md §8d, 64 / 16), one
     torch intra-op thread per runner (torch_utils.cpp:20).  Bounded sample (~10-20 s): every runner calls ONE short
-    batch — hac: 2 full chunks; sup: 1 chunk cut to 606 samples (256 concurrent sup runners stream 84 MB of f32
+    batch — hac: 2 full chunks; sup: 1 chunk cut to 606 samples (sup@v5: 1536) (256 concurrent sup runners stream 84 MB of f32
     weights per time step each and run at ~40 samples/s/thread: a full chunk would take minutes) — forward + decode;
     what was run is stated in `sample`."""
     from oracle import oracle_py as O
@@ -388,7 +388,7 @@ def main():
             for key, mk, fac, st in (("sup_v43", "sup", config.sup_v43, 3), ("sup_v50", "sup5", config.sup_v50, 3)):
                 try:
                     r2, _, _, _, _, _ = run_config(capi, synth, fac(), mk, local_rank, st, 1, 0, seed=7,
-                                                   with_cpu=(mk == "sup" and not args.no_cpu_baseline), cpu_kind="sup")
+                                                   with_cpu=not args.no_cpu_baseline, cpu_kind="sup")
                     line["extra"][key] = r2
                 except Exception as ex:
                     line["extra"][key] = {"error": repr(ex)}
