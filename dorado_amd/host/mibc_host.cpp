@@ -774,10 +774,22 @@ std::vector<CalledRead> SimplexBasecaller::basecall_views(const std::vector<Read
                 }
             }
         };
+        // an exception (bad_alloc) inside a std::thread would terminate the process: catch, join, rethrow
+        std::exception_ptr first_error;
+        std::mutex err_mut;
+        auto guarded = [&](size_t t) {
+            try {
+                chunk_range(t);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(err_mut);
+                if (!first_error) first_error = std::current_exception();
+            }
+        };
         std::vector<std::thread> thr;
-        for (size_t t = 1; t < nthr; ++t) thr.emplace_back(chunk_range, t);
-        chunk_range(0);
+        for (size_t t = 1; t < nthr; ++t) thr.emplace_back(guarded, t);
+        guarded(0);
         for (auto &th : thr) th.join();
+        if (first_error) std::rethrow_exception(first_error);
         for (size_t t = 0; t < nthr; ++t)
             for (size_t qi = 0; qi < nq; ++qi) queues[qi].insert(queues[qi].end(), local[t][qi].begin(), local[t][qi].end());
     }
