@@ -2,7 +2,8 @@
 """bench.py — Samples/s of the simplex-basecalling hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--model hac|sup|sup5|tiny]
-                    [--also-sup 0|1] [--through-host 0|1] [--no-cpu-baseline] [--profile-run]
+                    [--also-sup 0|1] [--through-host 0|1] [--host-device hip:all] [--no-cpu-baseline]
+                    [--cpu-baseline-full] [--profile-run]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = one pass of the whole hot path (conv -> 5x LSTM | 18x transformer layer -> CRF head -> beam-search
@@ -12,7 +13,8 @@ topology, chunksize 10000 -> 9996 after normalisation.  Reads shard embarrassing
 engine and its chunks; there is no data-path collective (weak scaling).  Rank 0 prints ONE JSON line.
 
 Objects in the line (headline = hac; `extra.sup_v43` and `extra.sup_v50` carry the same objects for the two sup
-configurations of BASELINE.json, N = 1 only):
+configurations of BASELINE.json at N = 1; at N > 1 they carry the whole-job weak-scaling Samples/s of the same two
+configurations — BASELINE configs[4] is sup@v5 on 8 GPUs — timed with the same barrier + max-over-ranks rule):
   roofline      dominant kernel: algorithmic MFMA flops per launch / mean launch duration measured with HIP events
                 on the engine's stream inside the timed region, against the 2.5 PFLOP/s dense f16 MFMA peak;
                 `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic_*).
@@ -23,7 +25,11 @@ configurations of BASELINE.json, N = 1 only):
                 (basecall/crf_utils.cpp:208-233), timed on a bounded sample of the same workload.
   through_host  the same workload through the C++ host layer (SimplexBasecaller -> HipModelRunner -> HipCaller ->
                 mibc_call_async: chunking, pinned batches, PCIe both ways, string slicing, stitching; 2 runners,
-                two batches in flight) — reported beside the device-resident headline, never as `value`.
+                two batches in flight) — reported beside the device-resident headline, never as `value`.  Two read
+                sets: single-chunk reads (best case: no overlap) and 5-chunk reads (chunks overlap by `overlap` samples:
+                the overlap-discounted Samples/s the reference's ProgressTracker would print, SURVEY.md §8d, beside the
+                rate including overlap).  --host-device hip:all runs it as ONE process with one HipCaller per visible
+                device (north_star's design); the default is this rank's device.
 """
 import argparse
 import glob
@@ -111,14 +117,19 @@ def host_free_ram_gb():
     return 64.0
 
 
-def cpu_baseline(cfg, ws, t_in, kind_model):
+def cpu_baseline(cfg, ws, t_in, kind_model, full=False):
     """Reference CPU basecaller on this host.  R runner threads by the reference's own rule
     (dorado/basecall/crf_utils.cpp:208-233: clamp(free_RAM / (GB_per_runner * batch / 128), 1, hardware_concurrency)
     with 4.5 GB (hac) / 12.5 GB (sup) per runner at batch 128 and the CPU batch of SURVEY.md §8d, 64 / 16), one
     torch intra-op thread per runner (torch_utils.cpp:20).  Bounded sample (~10-20 s): every runner calls ONE short
     batch — hac: 2 full chunks; sup: 1 chunk cut to 606 samples (sup@v5: 1536) (256 concurrent sup runners stream 84 MB of f32
     weights per time step each and run at ~40 samples/s/thread: a full chunk would take minutes) — forward + decode;
-    what was run is stated in `sample`."""
+    what was run is stated in `sample`.  Every runner thread first makes an untimed warm-up call (a 300-sample chunk:
+    its libtorch workspaces and the weights are paged in), the clock starts when all runners are warm.  The per-step
+    cost of the reference's CPU path does not depend on the chunk length (LSTM: one step at a time; the convolutions are
+    linear in T), so the short sup chunks change the rate by edge effects only.  full=True (--cpu-baseline-full) runs the
+    exact SURVEY §8d configuration instead — real T_in, batch 64 / 16 per runner, 1 warm-up + 1 timed batch — which takes
+    10 min (hac) to hours (sup) on 256 cores and is therefore not the default."""
     from oracle import oracle_py as O
     from dorado_amd import synth
 
@@ -128,24 +139,33 @@ def cpu_baseline(cfg, ws, t_in, kind_model):
     R = int(host_free_ram_gb() / (per_runner_gb * rule_batch / 128.0))
     R = max(1, min(R, cores))
     n_per = 1 if kind_model == "sup" else 2          # chunks per runner in the sample (<= rule_batch)
-    if kind_model == "sup":
+    if full:
+        n_per = rule_batch
+    elif kind_model == "sup":
         t_in = min(t_in, 606 if cfg.tx is None else 1536)
     x = synth.make_signal(n_per, t_in, seed=99).astype(np.float32)[:, None, :]
     done = []
+    if kind == "port":
+        R = 1  # the C port parallelises internally with OpenMP
+    gran = 192 if cfg.tx is not None else 6
+    xs = np.ascontiguousarray(x[:1, :, : max(gran, 300 // gran * gran)])
+    warm = threading.Barrier(R + 1)
+    tstart = [0.0]
 
     def runner():
+        O.decode(O.forward(cfg, ws, xs, use_ref=(kind == "reference")), use_ref=(kind == "reference"))   # warm-up
+        warm.wait()
+        warm.wait()      # main thread has stamped the start time
         s = O.forward(cfg, ws, x, use_ref=(kind == "reference"))
         O.decode(s, q_shift=cfg.qbias, q_scale=cfg.qscale, use_ref=(kind == "reference"))
         done.append(n_per)
 
-    if kind == "port":
-        R = 1  # the C port parallelises internally with OpenMP
-    xs = x[:1, :, : 6 * 100]    # warm-up (page in libtorch) on a short chunk
-    O.decode(O.forward(cfg, ws, xs, use_ref=(kind == "reference")), use_ref=(kind == "reference"))
-    t0 = time.time()
     th = [threading.Thread(target=runner) for _ in range(R)]
     for t in th:
         t.start()
+    warm.wait()
+    t0 = time.time()
+    warm.wait()
     for t in th:
         t.join()
     el = time.time() - t0
@@ -154,8 +174,8 @@ def cpu_baseline(cfg, ws, t_in, kind_model):
             "kind": kind,
             "sample": f"{sum(done)} chunks x {t_in} samples = {R} runner threads (crf_utils.cpp:208-233 rule: batch "
                       f"{rule_batch}, {per_runner_gb} GB/runner at batch 128, {host_free_ram_gb():.0f} GB free, "
-                      f"{cores} logical cores) x {n_per} chunks each, 1 torch thread per runner, forward+decode, "
-                      f"{el:.1f}s wall"}
+                      f"{cores} logical cores) x {n_per} chunks each, 1 torch thread per runner, 1 untimed warm-up "
+                      f"call per runner, forward+decode, {el:.1f}s wall"}
 
 
 def bench_scale_parity(eng, out, d_in, n, t_in, T, period):
@@ -189,7 +209,7 @@ def bench_scale_parity(eng, out, d_in, n, t_in, T, period):
 def dominant_kernel(cfg, n):
     """(name as rocprofv3 prints it, substring used to look it up in the PMC files)"""
     if cfg.tx is not None:
-        return "transformer encoder stack (gemm256_kernel + window_attention_v2_kernel + residual_rmsnorm_kernel)", None
+        return "transformer encoder stack (per layer: qkv gemm256 + window_attention_v3 + fused out-proj/MLP kernels)", None
     if cfg.lstm_size <= 384:
         return "lstm_layer_x8_kernel<%d>" % cfg.lstm_size, "lstm_layer_x8"
     if n % 256 == 0 and cfg.lstm_size in (512, 768, 1024):
@@ -212,7 +232,7 @@ def auto_batch(eng, cfg, t_in, device):
 
 
 def run_config(capi, synth, cfg, model_key, device, steps, warmup, batch=0, seed=0xD0AD0, timed_barrier=None,
-               with_cpu=False, cpu_kind="hac", check_parity=True):
+               with_cpu=False, cpu_kind="hac", check_parity=True, cpu_full=False):
     """Times `steps` steps of one configuration on this rank's GPU.  Returns (result dict, elapsed seconds)."""
     t_in = cfg.chunk_size
     ws = synth.make_weights(cfg, seed=42)
@@ -279,7 +299,7 @@ def run_config(capi, synth, cfg, model_key, device, steps, warmup, batch=0, seed
     }
     if with_cpu:
         try:
-            res["cpu_baseline"] = cpu_baseline(cfg, ws, t_in, cpu_kind)
+            res["cpu_baseline"] = cpu_baseline(cfg, ws, t_in, cpu_kind, full=cpu_full)
         except Exception as ex:  # the checker must never take the bench line down
             res["cpu_baseline"] = {"value": None, "error": repr(ex)}
     eng.device_free(d_in)
@@ -303,6 +323,12 @@ def main():
                          "and report them under extra (the metric names hac & sup)")
     ap.add_argument("--through-host", type=int, default=1,
                     help="N=1 only: also measure the headline workload through the C++ host layer")
+    ap.add_argument("--host-device", default="",
+                    help="device string of the through-host measurement (default: this rank's GPU; 'hip:all' = ONE "
+                         "process, one HipCaller per visible device fed from shared chunk queues)")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="cpu_baseline in the exact SURVEY 8d configuration (real chunk length, batch 64 / 16 per runner): "
+                         "minutes to hours of host time")
     args = ap.parse_args()
 
     import torch
@@ -336,7 +362,7 @@ def main():
                                          seed=0xD0AD0 + rank, timed_barrier=barrier,
                                          with_cpu=single and not args.no_cpu_baseline,
                                          cpu_kind="sup" if args.model in ("sup", "sup5") else "hac",
-                                         check_parity=not args.profile_run)
+                                         check_parity=not args.profile_run, cpu_full=args.cpu_baseline_full)
     if world > 1:
         tt = torch.tensor([el], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -373,25 +399,56 @@ def main():
         if single and args.through_host and args.model in ("hac", "sup", "sup5"):
             try:
                 from dorado_amd import hostapi
-                reads = synth.make_signal(256, t_in, seed=77)
+                hdev = args.host_device or f"hip:{local_rank}"
                 nb = 12 if args.model == "hac" else 8
-                th = hostapi.bench_through_host(cfg, ws, reads, n_warm=2 * n, n_reads=nb * n, num_runners=2, batch_size=n)
-                th["vs_device_resident"] = th["samples_per_s"] / value
-                th["what"] = (f"{nb} batches of {n} single-chunk reads through SimplexBasecaller (2 runners, two "
-                              f"batches in flight, pinned buffers, PCIe both ways, string slicing + stitching), "
-                              f"timed from the first read's chunking until the last read is called")
+                reads = synth.make_signal(256, t_in, seed=77)
+                th = hostapi.bench_through_host(cfg, ws, reads, n_warm=2 * n, n_reads=nb * n, device=hdev,
+                                                num_runners=2, batch_size=n)
+                ndev = max(1, th["devices"])
+                th["vs_device_resident"] = th["samples_per_s"] / (value * ndev)
+                th["what"] = (f"{nb} batches of {n} single-chunk reads through SimplexBasecaller on {hdev} ({ndev} device(s), "
+                              f"one HipCaller each, 2 runners, two batches in flight, pinned buffers, PCIe both ways, string "
+                              f"slicing + stitching), timed from the first read's chunking until the last read is called")
                 line["through_host"] = th
+                # multi-chunk reads: 5 full chunks per read, neighbouring chunks share `overlap` samples
+                k = 5
+                rl = t_in + (k - 1) * (t_in - cfg.overlap)
+                reads5 = synth.make_signal(64, rl, seed=78)
+                nr = (nb * n) // k
+                th5 = hostapi.bench_through_host(cfg, ws, reads5, n_warm=(2 * n) // k, n_reads=nr, device=hdev,
+                                                 num_runners=2, batch_size=n)
+                th5["vs_device_resident_incl_overlap"] = th5["samples_incl_padding_per_s"] / (value * ndev)
+                th5["overlap_discount"] = rl / float(k * t_in)
+                th5["what"] = (f"{nr} reads of {rl} samples = {k} chunks each (overlap {cfg.overlap}): samples_per_s counts "
+                               f"every read sample once (the reference's samples_processed / duration, overlap-discounted), "
+                               f"samples_incl_padding_per_s counts batch rows x chunk size")
+                line["through_host_multi_chunk_reads"] = th5
             except Exception as ex:
                 line["through_host"] = {"error": repr(ex)}
-        if single and args.also_sup and args.model == "hac":
-            line["extra"] = {}
-            for key, mk, fac, st in (("sup_v43", "sup", config.sup_v43, 3), ("sup_v50", "sup5", config.sup_v50, 3)):
-                try:
-                    r2, _, _, _, _, _ = run_config(capi, synth, fac(), mk, local_rank, st, 1, 0, seed=7,
-                                                   with_cpu=not args.no_cpu_baseline, cpu_kind="sup")
-                    line["extra"][key] = r2
-                except Exception as ex:
-                    line["extra"][key] = {"error": repr(ex)}
+    # the two sup configurations of BASELINE.json: full objects at N = 1, whole-job weak-scaling rates at N > 1
+    if args.also_sup and args.model == "hac":
+        extra = {}
+        for key, mk, fac, st in (("sup_v43", "sup", config.sup_v43, 3), ("sup_v50", "sup5", config.sup_v50, 3)):
+            try:
+                r2, el2, n2, _, t_in2, _ = run_config(capi, synth, fac(), mk, local_rank, st, 1, 0, seed=7 + rank,
+                                                      timed_barrier=barrier if world > 1 else None,
+                                                      with_cpu=single and not args.no_cpu_baseline, cpu_kind="sup",
+                                                      check_parity=single, cpu_full=args.cpu_baseline_full)
+                if world > 1:
+                    tt = torch.tensor([el2], device="cuda", dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    el2 = float(tt.item())
+                    r2 = {"workload": r2["workload"], "n_gpus": world, "scaling": "weak", "steps": st,
+                          "samples_per_s": float(world) * n2 * t_in2 * st / el2, "ms_per_step": el2 / st * 1e3,
+                          "chunks_per_gpu": n2, "rank0_roofline": r2["roofline"]}
+                extra[key] = r2
+            except Exception as ex:
+                if world > 1:
+                    raise          # a rank that skipped the collective would hang the others
+                extra[key] = {"error": repr(ex)}
+        if rank == 0:
+            line["extra"] = extra
+    if rank == 0:
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -50,7 +50,7 @@ EXPORTS = [
     "mibc_sync", "mibc_time_forward", "mibc_get_stage_ms", "mibc_set_profile", "mibc_debug_tap",
     "mibc_forward_i16", "mibc_call_device_i16", "mibc_call_i16", "mibc_scaler_stats", "mibc_scale_reads",
     "mibc_svb16_decode", "mibc_forward_var", "mibc_call_device_var", "mibc_call_var",
-    "mibc_call_async", "mibc_call_wait", "mibc_call_poll", "mibc_debug_set_ws_min_rows",
+    "mibc_call_async", "mibc_call_wait", "mibc_call_poll",
 ]
 
 SCALE_QUANTILE = 0
@@ -85,7 +85,6 @@ def lib():
         L.mibc_query_memory.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t),
                                         C.POINTER(C.c_size_t)]
         L.mibc_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int]
-        L.mibc_debug_set_ws_min_rows.argtypes = [C.c_void_p, C.c_int]
         L.mibc_output_steps.argtypes = [C.c_void_p, C.c_int]
         L.mibc_batch_granularity.argtypes = [C.c_void_p]
         L.mibc_host_alloc.restype = C.c_void_p
@@ -136,6 +135,16 @@ def lib():
 
 def device_count() -> int:
     return int(lib().mibc_device_count())
+
+
+def device_memory(device: int = 0):
+    """(free, total) bytes of a device (mibc_device_memory)."""
+    a, b = C.c_size_t(), C.c_size_t()
+    L = lib()
+    L.mibc_device_memory.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    if L.mibc_device_memory(device, C.byref(a), C.byref(b)) != MIBC_OK:
+        raise MibcError("mibc_device_memory failed")
+    return int(a.value), int(b.value)
 
 
 class Engine:
@@ -225,10 +234,6 @@ class Engine:
         ms = C.c_float()
         self._check(lib().mibc_time_forward(self._h, n, t_in, C.byref(ms)), "mibc_time_forward")
         return float(ms.value)
-
-    def set_ws_min_rows(self, min_rows: int):
-        """Test-only: batches of >= min_rows rows take the weight-stationary cluster LSTM kernel (lstm_size 384)."""
-        self._check(lib().mibc_debug_set_ws_min_rows(self._h, int(min_rows)), "mibc_debug_set_ws_min_rows")
 
     def tap(self, tap: int, shape, dtype) -> np.ndarray:
         out = np.zeros(shape, dtype)

@@ -22,6 +22,39 @@ typedef float float16_t __attribute__((ext_vector_type(16)));
 #define MIBC_ENV_INT(name, dflt) (dflt)
 #endif
 
+// ---- per-DEVICE launch state (host side).  Function attributes (hipFuncAttributeMaxDynamicSharedMemorySize) and
+// the CU count belong to a device, and one process drives every GPU of the node (one HipCaller per device on its own
+// thread, api/runner_creation.cpp:85-124): both are looked up by the launching thread's CURRENT device, lock-free
+// (setting the same attribute twice is idempotent; the bit only says "done on this device").
+#include <atomic>
+#define MIBC_MAX_DEVICES 64
+static inline int mibc_cur_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return (dev >= 0 && dev < MIBC_MAX_DEVICES) ? dev : 0;
+}
+static inline int mibc_ncu() {   // CU count of the current device
+    static std::atomic<int> cus[MIBC_MAX_DEVICES];
+    const int dev = mibc_cur_device();
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+#define MIBC_LDS_ATTR_ONCE(kern, bytes)                                                                       \
+    do {                                                                                                      \
+        static std::atomic<unsigned long long> done_{0};                                                      \
+        const unsigned long long bit_ = 1ull << mibc_cur_device();                                            \
+        if (!(done_.load(std::memory_order_acquire) & bit_)) {                                                \
+            (void)hipFuncSetAttribute((const void *)(kern), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                      (int)(bytes));                                                          \
+            done_.fetch_or(bit_, std::memory_order_release);                                                  \
+        }                                                                                                     \
+    } while (0)
+
 // D[row][col] layout of v_mfma_f32_32x32x16_f16 (cdna_hip_programming.md §3):
 //   col = lane & 31,  row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5),  reg in [0,16)
 // A operand: lane holds A[i = lane & 31][k = 8 * (lane >> 5) + 0..7]; B likewise with j.

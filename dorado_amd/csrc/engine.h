@@ -70,13 +70,6 @@ extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin
                                          const float *biascl, const half_t *zeros, float *cbuf, unsigned *flags,
                                          unsigned *err, int T, int N, int reverse,
                                          const unsigned long long *tmask);
-// lstm_ws.hip: weight-stationary cluster kernel (C = 384, N a multiple of 16, >= WS_RMIN row tiles per cluster)
-extern "C" size_t mibc_lstm_ws_lds_bytes(int C);
-extern "C" size_t mibc_lstm_ws_cstate_bytes(int C, int N);
-extern "C" size_t mibc_lstm_ws_flag_bytes(int C, int N);
-extern "C" int mibc_launch_lstm_layer_ws(hipStream_t s, int C, const half_t *Xin, half_t *Xout, const half_t *Wf16,
-                                         const float *biasn, const half_t *zeros, float *cbuf, unsigned *flags,
-                                         unsigned *err, int T, int N, int reverse);
 extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
                                       float beam_cut, float stay, float clampv, float q_shift, float q_scale,
                                       float *bwd, uint32_t *trace, uint16_t *path_state, int8_t *out3,
@@ -112,10 +105,10 @@ struct mibc_engine {
     unsigned *cl_flags = nullptr;    // [N_res/256][C/128][16] completed-step counters (zeroed per launch)
     float *cl_cstate = nullptr;      // [N_res][C] f32 cell state of the layer in flight (workspace)
     unsigned *cl_err = nullptr;      // device [4]: sticky hand-off time-out word
-    unsigned *cl_err_host = nullptr; // pinned copy, checked after every stream synchronisation
+    unsigned *cl_err_host = nullptr; // pinned [3][4]: copy per call slot (async slot 0 / 1, synchronous calls 2),
+                                     // taken in stream order behind the LSTM stack of that call
+    int err_slot = 2;                // where the call being enqueued reports
     bool cl_used = false;
-    bool ws_ok = false;              // lstm_ws.hip covers this width
-    int ws_min_rows = 1 << 30;       // smallest batch that takes the weight-stationary kernel (default: never)
     int use_cluster = 1;             // debug build: MIBC_LSTM_CLUSTER=0 forces the per-workgroup kernels
     half_t *head_w1 = nullptr, *head_w2 = nullptr;
     float *head_b1 = nullptr;
@@ -133,7 +126,11 @@ struct mibc_engine {
     // geometry
     int C = 0, S = 0, K = 0, stride = 1, pad3 = 0;
     // workspace
-    int N_res = 0, T_in_res = 0, T_res = 0, Tpitch = 0, Nd = 0;
+    // N_res / T_in_cap: what the workspace was allocated for (capacity); T_in_res / T_res / Tpitch: geometry of the
+    // call in flight — one engine serves every chunk size of its device (CudaCaller's m_batch_dims,
+    // CudaCaller.cpp:382-413), any (N <= N_res, T_in <= T_in_cap) runs in the same buffers
+    int N_res = 0, T_in_cap = 0, T_in_res = 0, T_res = 0, Tpitch = 0, Nd = 0;
+    size_t a2p_bytes = 0;
     half_t *in_stage = nullptr, *a2p = nullptr, *xa = nullptr, *xb = nullptr, *scores = nullptr,
            *mid = nullptr, *a1_tap = nullptr;
     float *bwd = nullptr, *prob_tap = nullptr;
@@ -181,6 +178,7 @@ struct mibc_engine {
         int D = 0, H = 0, FF = 0, depth = 0, sf = 1, conv_stride = 1;
         // workspace
         std::vector<half_t *> cbuf;   // padded conv outputs (NTC)
+        std::vector<size_t> cbuf_bytes;
         std::vector<int> ctp, ct;     // row pitch and valid steps per conv buffer
         half_t *x = nullptr, *qkv = nullptr, *attn = nullptr, *tmp = nullptr, *ff = nullptr, *up = nullptr;
         half_t *vT = nullptr;         // V transposed [N][H][64][T] (when T % 128 == 0)
@@ -213,6 +211,7 @@ void tx_destroy(mibc_engine *e);
 void tx_free_ws(mibc_engine *e);
 int tx_tokens(const mibc_engine *e, int T_in);
 int tx_reserve(mibc_engine *e, int N, int T_in, size_t *total);
+int tx_set_geometry(mibc_engine *e, int T_in);   // row pitches / token count of the call in flight; re-zeroes pad rows
 size_t tx_bytes_per_chunk(const mibc_engine *e, int T_in);
 int tx_run_network(mibc_engine *e, const half_t *in_dev, int N, int T_in);
 int tx_run_head(mibc_engine *e, int N, int n0, int ns, half_t *scores_out);

@@ -7,7 +7,8 @@
 // (per-device FIFO, runners, pinned batch buffers) lives in dorado_amd/host/.
 #include "engine.h"
 
-static int check_cluster_error(mibc_engine *e);
+static int check_cluster_error(mibc_engine *e, int slot = 2);
+static int set_geometry(mibc_engine *e, int T_in);
 
 std::string &mibc_gerr() {
     static thread_local std::string g;
@@ -257,14 +258,13 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
             e->lstm_bcl.push_back(dbcl);
         }
     }
-    e->ws_ok = (mibc_lstm_ws_lds_bytes(C) != 0);   // weight-stationary cluster kernel (lstm_ws.hip): C = 384
-    if (!e->lstm_wcl.empty() || e->ws_ok) {
+    if (!e->lstm_wcl.empty()) {
         HIP_OK(e, hipMalloc((void **)&e->lstm_zero, (size_t)256 * C * 2));
         HIP_OK(e, hipMemset(e->lstm_zero, 0, (size_t)256 * C * 2));
         HIP_OK(e, hipMalloc((void **)&e->cl_err, 16));
         HIP_OK(e, hipMemset(e->cl_err, 0, 16));
-        HIP_OK(e, hipHostMalloc((void **)&e->cl_err_host, 16, hipHostMallocDefault));
-        e->cl_err_host[0] = 0;
+        HIP_OK(e, hipHostMalloc((void **)&e->cl_err_host, 3 * 16, hipHostMallocDefault));
+        memset(e->cl_err_host, 0, 3 * 16);
     }
     // head (basecall/model/CRFModel.cpp:43-61)
     const int tanh_x5 = (d.scale == 5.0f) ? 3 : -1;
@@ -300,7 +300,6 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
     }
     e->use_ws = MIBC_ENV_INT("MIBC_WSGEMM", 1);
     e->use_cluster = MIBC_ENV_INT("MIBC_LSTM_CLUSTER", 1);
-    e->ws_min_rows = MIBC_ENV_INT("MIBC_WS_MIN_ROWS", 1 << 30);   // off: see mibc_debug_set_ws_min_rows
     const char *tp = getenv("MIBC_TAPS");
     e->taps = tp ? atoi(tp) : 0;
     // weight uploads are null-stream copies from pageable memory: hipMemcpy may return once the data sits
@@ -328,6 +327,8 @@ static void free_ws(mibc_engine *e) {
     for (auto ev : e->sub_ev) (void)hipEventDestroy(ev);
     e->sub_ev.clear();
     e->N_res = 0;
+    e->T_in_cap = 0;
+    e->T_in_res = 0;
     e->ws_bytes = 0;
 }
 
@@ -415,12 +416,32 @@ extern "C" int mibc_query_memory(const mibc_engine *e, int T_in, size_t *bytes_p
     return MIBC_OK;
 }
 
+// Geometry of the call in flight inside the reserved workspace.  A change of chunk length moves the zero padding
+// rows of the convolution buffers: they are re-zeroed on the engine's stream (a2p: 5 GB at the hac batch = ~1.5 ms,
+// paid only when consecutive batches differ in chunk size).
+static int set_geometry(mibc_engine *e, int T_in) {
+    if (e->T_in_res == T_in) return MIBC_OK;
+    const int T = mibc_output_steps(e, T_in);
+    if (T < 1) return fail(e, MIBC_ERR_ARG, "chunk too short");
+    if (e->is_tx) {
+        const int rc = tx_set_geometry(e, T_in);
+        if (rc != MIBC_OK) return rc;
+    } else {
+        // on the engine's stream: a null-stream memset is not ordered with this non-blocking stream
+        HIP_OK(e, hipMemsetAsync(e->a2p, 0, e->a2p_bytes, e->stream));
+    }
+    e->Tpitch = T_in + 2 * e->pad3 + 2;
+    e->T_in_res = T_in;
+    e->T_res = T;
+    return MIBC_OK;
+}
+
 extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
     if (!e || N_max <= 0 || T_in <= 0) return MIBC_ERR_ARG;
     if (N_max % mibc_batch_granularity(e) != 0)
         return fail(e, MIBC_ERR_ARG, "N_max must be a multiple of mibc_batch_granularity()");
     HIP_OK(e, hipSetDevice(e->device));
-    if (e->N_res >= N_max && e->T_in_res == T_in) return MIBC_OK;
+    if (e->N_res >= N_max && e->T_in_cap >= T_in) return set_geometry(e, T_in);
     HIP_OK(e, hipStreamSynchronize(e->stream));
     free_ws(e);
     const size_t T = (size_t)mibc_output_steps(e, T_in);
@@ -443,20 +464,13 @@ extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
         if (rc != MIBC_OK) return rc;
         total += txb;
     } else {
-        if (alloc((void **)&e->a2p, (N * e->Tpitch + 64) * 16 * 2)) return MIBC_ERR_MEM;
-        // on the engine's stream: a null-stream memset is not ordered with this non-blocking stream
-        HIP_OK(e, hipMemsetAsync(e->a2p, 0, (N * e->Tpitch + 64) * 16 * 2, e->stream));
+        e->a2p_bytes = (N * e->Tpitch + 64) * 16 * 2;   // zeroed by set_geometry
+        if (alloc((void **)&e->a2p, e->a2p_bytes)) return MIBC_ERR_MEM;
         if (alloc((void **)&e->xa, T * N * e->C * 2)) return MIBC_ERR_MEM;
         if (alloc((void **)&e->xb, T * N * e->C * 2)) return MIBC_ERR_MEM;
         if (!e->lstm_wcl.empty() && N >= 256) {
             if (alloc((void **)&e->cl_flags, (N / 256) * (size_t)(e->C / 128) * 16 * sizeof(unsigned))) return MIBC_ERR_MEM;
             if (alloc((void **)&e->cl_cstate, (N / 256) * 256 * (size_t)e->C * sizeof(float))) return MIBC_ERR_MEM;
-        }
-        if (e->ws_ok && mibc_lstm_ws_cstate_bytes(e->C, (int)(N / 16 * 16)) != 0) {
-            // sized for the largest batch; smaller batches use fewer / shorter clusters of the same buffers
-            if (alloc((void **)&e->cl_flags, mibc_lstm_ws_flag_bytes(e->C, (int)(N / 16 * 16)) + 4096)) return MIBC_ERR_MEM;
-            if (alloc((void **)&e->cl_cstate, mibc_lstm_ws_cstate_bytes(e->C, (int)(N / 16 * 16)) + (size_t)256 * 6 * 4096))
-                return MIBC_ERR_MEM;
         }
     }
     if (alloc((void **)&e->scores, Nd * T * e->K * 2)) return MIBC_ERR_MEM;
@@ -474,10 +488,12 @@ extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
     e->sub_ev.resize((size_t)nsub * 3);
     for (auto &ev : e->sub_ev) HIP_OK(e, hipEventCreate(&ev));
     e->N_res = N_max;
-    e->T_in_res = T_in;
-    e->T_res = (int)T;
+    e->T_in_cap = T_in;
+    e->T_in_res = 0;
     e->ws_bytes = total;
-    HIP_OK(e, hipStreamSynchronize(e->stream));  // the zero fills above
+    const int rc = set_geometry(e, T_in);
+    if (rc != MIBC_OK) return rc;
+    HIP_OK(e, hipStreamSynchronize(e->stream));  // the zero fills
     return MIBC_OK;
 }
 
@@ -574,12 +590,7 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
                            mibc_launch_lstm_layer_cl(e->stream, e->C, cur, nxt, e->lstm_wcl[l], e->lstm_bcl[l],
                                                      e->lstm_zero, e->cl_cstate, e->cl_flags, e->cl_err, T, N, reverse,
                                                      e->in_tmask) == 0;
-        // hac width: the weight-stationary cluster kernel for large batches (bit-identical to lstm_layer_x8_kernel)
-        const bool ws_ok = !cl_ok && e->use_cluster && e->ws_ok && e->cl_flags != nullptr && e->in_tmask == nullptr &&
-                           N >= e->ws_min_rows &&
-                           mibc_launch_lstm_layer_ws(e->stream, e->C, cur, nxt, e->lstm_w16[l], e->lstm_bn[l], e->lstm_zero,
-                                                     e->cl_cstate, e->cl_flags, e->cl_err, T, N, reverse) == 0;
-        if (cl_ok || ws_ok) {
+        if (cl_ok) {
             e->cl_used = true;
         } else if (e->in_tmask != nullptr) {
             if (mibc_launch_lstm_layer_masked(e->stream, e->C, cur, nxt, e->C >= 512 ? e->lstm_w[l] : e->lstm_w16[l],
@@ -594,26 +605,29 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
         nxt = t;
     }
     e->lstm_out = cur;
-    if (e->cl_used)   // hand-off time-outs of the cluster kernel surface at the next stream synchronisation
-        HIP_OK(e, hipMemcpyAsync(e->cl_err_host, e->cl_err, 16, hipMemcpyDeviceToHost, e->stream));
+    if (e->cl_used) {
+        // hand-off time-outs of the cluster kernel: the sticky device word is copied to THIS call's host slot and
+        // cleared, both in stream order, so a time-out is reported by the call it happened in and by no other
+        HIP_OK(e, hipMemcpyAsync(e->cl_err_host + 4 * e->err_slot, e->cl_err, 16, hipMemcpyDeviceToHost, e->stream));
+        HIP_OK(e, hipMemsetAsync(e->cl_err, 0, 16, e->stream));
+    }
     HIP_OK(e, hipGetLastError());
     return MIBC_OK;
 }
 
-// after a stream synchronisation: did a cluster hand-off of the LSTM kernel time out?
-static int check_cluster_error(mibc_engine *e) {
+// after the call that reports into `slot` has completed: did a cluster hand-off of its LSTM kernels time out?
+static int check_cluster_error(mibc_engine *e, int slot) {
+    if (!e->cl_err_host) return MIBC_OK;
+    unsigned *h = e->cl_err_host + 4 * slot;
 #ifdef MIBC_DEBUG_KERNELS
-    if (e->cl_err_host && (e->cl_err_host[1] | e->cl_err_host[2] | e->cl_err_host[3])) {
-        fprintf(stderr, "[mibc dbg] cluster hand-off: slow-path entries %u, worst lag %u, real waits %u\n", e->cl_err_host[1],
-                e->cl_err_host[2], e->cl_err_host[3]);
-        e->cl_err_host[1] = e->cl_err_host[2] = e->cl_err_host[3] = 0;
-        (void)hipMemsetAsync(e->cl_err, 0, 16, e->stream);
+    if (h[1] | h[2] | h[3]) {
+        fprintf(stderr, "[mibc dbg] cluster hand-off: slow-path entries %u, worst lag %u, real waits %u\n", h[1], h[2], h[3]);
+        h[1] = h[2] = h[3] = 0;
     }
 #endif
-    if (e->cl_err_host && e->cl_err_host[0] != 0) {
-        const unsigned w = e->cl_err_host[0];
-        e->cl_err_host[0] = 0;
-        (void)hipMemsetAsync(e->cl_err, 0, 16, e->stream);
+    if (h[0] != 0) {
+        const unsigned w = h[0];
+        h[0] = 0;
         return fail(e, MIBC_ERR_HIP, "LSTM cluster kernel: hand-off between workgroups timed out (cluster " +
                                              std::to_string((w >> 16) & 0x7fff) + ", step " + std::to_string(w & 0xffff) +
                                              "); results of this call are invalid");
@@ -689,11 +703,11 @@ static int check_call(mibc_engine *e, int N, int T_in) {
     if (!e) return MIBC_ERR_ARG;
     if (N <= 0 || N % mibc_batch_granularity(e) != 0)
         return fail(e, MIBC_ERR_ARG, "N must be a positive multiple of mibc_batch_granularity()");
-    if (e->N_res < N || e->T_in_res != T_in) {
-        const int rc = mibc_reserve(e, N, T_in);
+    HIP_OK(e, hipSetDevice(e->device));
+    if (e->N_res < N || e->T_in_cap < T_in || e->T_in_res != T_in) {
+        const int rc = mibc_reserve(e, N, T_in);   // grows the workspace or only switches the geometry
         if (rc != MIBC_OK) return rc;
     }
-    HIP_OK(e, hipSetDevice(e->device));
     return MIBC_OK;
 }
 
@@ -727,6 +741,7 @@ extern "C" int mibc_decode(mibc_engine *e, const uint16_t *scores_dev, int N, in
                            const mibc_decode_opts *o, int8_t *out_dev) {
     if (!e || !o || N <= 0) return MIBC_ERR_ARG;
     if (e->N_res <= 0 || T != e->T_res) return fail(e, MIBC_ERR_ARG, "mibc_reserve first (T mismatch)");
+    if (N > e->N_res) return fail(e, MIBC_ERR_ARG, "mibc_decode: N exceeds the reserved batch");
     HIP_OK(e, hipSetDevice(e->device));
     for (int n0 = 0; n0 < N; n0 += e->Nd) {
         const int ns = (N - n0 < e->Nd) ? (N - n0) : e->Nd;
@@ -835,8 +850,10 @@ extern "C" int mibc_call_async(mibc_engine *e, int slot, const void *in_host, co
         HIP_OK(e, hipMemcpyAsync(a.ss, shift_scale_host, (size_t)N * 2 * sizeof(float), hipMemcpyHostToDevice, e->s_in));
     HIP_OK(e, hipEventRecord(a.ev_in, e->s_in));
     HIP_OK(e, hipStreamWaitEvent(e->stream, a.ev_in, 0));
+    e->err_slot = slot;
     rc = shift_scale_host ? mibc_call_device_i16(e, (const int16_t *)a.in, a.ss, N, T_in, o, a.out3)
                           : mibc_call_device(e, (const uint16_t *)a.in, N, T_in, o, a.out3);
+    e->err_slot = 2;
     if (rc != MIBC_OK) return rc;
     HIP_OK(e, hipEventRecord(a.ev_done, e->stream));
     HIP_OK(e, hipStreamWaitEvent(e->s_out, a.ev_done, 0));
@@ -856,7 +873,7 @@ extern "C" int mibc_call_wait(mibc_engine *e, int slot) {
     if (!e->aslot[slot].ev_out) return fail(e, MIBC_ERR_ARG, "mibc_call_wait: nothing was submitted on this slot");
     HIP_OK(e, hipSetDevice(e->device));
     HIP_OK(e, hipEventSynchronize(e->aslot[slot].ev_out));
-    return check_cluster_error(e);
+    return check_cluster_error(e, slot);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -963,36 +980,51 @@ extern "C" int mibc_svb16_decode(mibc_engine *e, const uint8_t *streams_dev, con
 // decoder runs once per chunk on its own step interval.  Each chunk's result equals running the network on
 // that chunk alone.  LSTM models with lstm_size 128 / 256 / 384 (the x8 kernels).
 // ---------------------------------------------------------------------------------------------
-static int var_setup(mibc_engine *e, int N, int T_in, const mibc_var_chunk *ch, int n_chunks, int *Tmax_out) {
+// Builds the masks and the decoder's chunk table of a variable-chunk call.  The decoder runs per decode sub-batch of
+// e->Nd rows like the fixed path: the table is ordered by sub-batch (stable), sub_begin[k] .. sub_begin[k+1] are the
+// chunks of sub-batch k, score offsets are relative to the sub-batch's first row and back-guide rows restart at 0.
+static int var_setup(mibc_engine *e, int N, int T_in, const mibc_var_chunk *ch, int n_chunks, int *Tmax_out,
+                     std::vector<int> *sub_begin) {
     if (!ch || n_chunks <= 0) return fail(e, MIBC_ERR_ARG, "no chunks");
     if (e->is_tx) return fail(e, MIBC_NOT_SUPPORTED, "variable chunks: LSTM models only");
-    if (N > e->Nd) return fail(e, MIBC_NOT_SUPPORTED, "variable chunks: N must not exceed the decode sub-batch");
     const int stride = e->stride, T = mibc_output_steps(e, T_in);
     if (T_in % stride != 0 || T != T_in / stride) return fail(e, MIBC_ERR_ARG, "variable chunks: T_in must be a stride multiple");
     const int mw = (T_in + 31) / 32, G = N / 64;
+    const int nsub = (N + e->Nd - 1) / e->Nd;
     std::vector<uint32_t> smask((size_t)N * mw, 0u);
     std::vector<unsigned long long> tmask((size_t)T * G, 0ull);
     std::vector<int> idx((size_t)3 * n_chunks);
-    std::vector<int> row_end((size_t)N, -2);   // last occupied step per row (chunks must come in row order)
-    long brow = 0;
-    int Tmax = 0;
+    std::vector<int> row_end((size_t)N, -2);   // last occupied step per row (chunks of a row must come in order)
+    std::vector<int> count((size_t)nsub + 1, 0);
     for (int c = 0; c < n_chunks; ++c) {
         const int r = ch[c].row, s0 = ch[c].sample_start, L = ch[c].n_samples;
         if (r < 0 || r >= N || s0 < 0 || L <= 0 || s0 % stride || L % stride || s0 + L > T_in)
             return fail(e, MIBC_ERR_ARG, "variable chunks: chunk outside its row or not stride aligned");
+        ++count[(size_t)(r / e->Nd) + 1];
+    }
+    for (int k = 0; k < nsub; ++k) count[(size_t)k + 1] += count[(size_t)k];
+    if (sub_begin) *sub_begin = count;
+    std::vector<int> next(count.begin(), count.end() - 1);
+    std::vector<long> brow((size_t)nsub, 0);
+    int Tmax = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int r = ch[c].row, s0 = ch[c].sample_start, L = ch[c].n_samples;
         const int t0 = s0 / stride, Tc = L / stride;
         if (t0 < row_end[r] + 3 && row_end[r] >= 0)
             return fail(e, MIBC_ERR_ARG, "variable chunks: chunks of a row must be ordered and >= 2 steps apart");
         row_end[r] = t0 + Tc - 1;
         for (int p = s0; p < s0 + L; ++p) smask[(size_t)r * mw + (p >> 5)] |= 1u << (p & 31);
         for (int t = t0; t < t0 + Tc; ++t) tmask[(size_t)t * G + (r >> 6)] |= 1ull << (r & 63);
-        idx[c] = r * T + t0;
-        idx[n_chunks + c] = (int)brow;
-        idx[2 * n_chunks + c] = Tc;
-        brow += Tc + 1;
+        const int k = r / e->Nd, slot = next[(size_t)k]++;
+        idx[slot] = (r - k * e->Nd) * T + t0;
+        idx[n_chunks + slot] = (int)brow[(size_t)k];
+        idx[2 * n_chunks + slot] = Tc;
+        brow[(size_t)k] += Tc + 1;
         Tmax = Tc > Tmax ? Tc : Tmax;
     }
-    if (brow > (long)e->Nd * (T + 1)) return fail(e, MIBC_ERR_ARG, "variable chunks: too many chunks for the decode workspace");
+    for (int k = 0; k < nsub; ++k)
+        if (brow[(size_t)k] > (long)e->Nd * (T + 1))
+            return fail(e, MIBC_ERR_ARG, "variable chunks: too many chunks for the decode workspace");
     const size_t b0 = smask.size() * 4, b1 = tmask.size() * 8, b2 = idx.size() * 4;
     const size_t need = ((b0 + 15) & ~size_t(15)) + ((b1 + 15) & ~size_t(15)) + b2;
     if (need > e->var_scratch_bytes) {
@@ -1029,7 +1061,7 @@ extern "C" int mibc_forward_var(mibc_engine *e, const void *in_dev, const float 
     int rc = check_call(e, N, T_in);
     if (rc != MIBC_OK) return rc;
     int Tmax = 0;
-    rc = var_setup(e, N, T_in, chunks, n_chunks, &Tmax);
+    rc = var_setup(e, N, T_in, chunks, n_chunks, &Tmax, nullptr);
     if (rc != MIBC_OK) return rc;
     e->in_ss = shift_scale_dev;
     rc = mibc_forward(e, (const uint16_t *)in_dev, N, T_in, scores_dev);
@@ -1045,20 +1077,29 @@ extern "C" int mibc_call_device_var(mibc_engine *e, const void *in_dev, const fl
     if (rc != MIBC_OK) return rc;
     const int T = mibc_output_steps(e, T_in);
     int Tmax = 0;
-    rc = var_setup(e, N, T_in, chunks, n_chunks, &Tmax);
+    std::vector<int> sub_begin;
+    rc = var_setup(e, N, T_in, chunks, n_chunks, &Tmax, &sub_begin);
     if (rc != MIBC_OK) return rc;
     e->in_ss = shift_scale_dev;
     rc = run_encoder(e, (const half_t *)in_dev, N, T_in);
-    if (rc == MIBC_OK) rc = run_head(e, N, T, 0, N, e->scores);
     if (rc == MIBC_OK) {
         // gaps of the output planes stay zero
         if (hipMemsetAsync(out_dev, 0, (size_t)3 * N * T, e->stream) != hipSuccess) rc = MIBC_ERR_HIP;
     }
-    if (rc == MIBC_OK &&
-        mibc_launch_decode_var(e->stream, e->scores, n_chunks, Tmax, e->S, o->beam_width, o->beam_cut, o->blank_score,
-                               clamp_value(e), o->q_shift, o->q_scale, e->bwd, e->trace, e->path_state, out_dev,
-                               (size_t)N * T, nullptr, e->var_idx, e->var_idx + n_chunks, e->var_idx + 2 * n_chunks) != 0)
-        rc = fail(e, MIBC_NOT_SUPPORTED, "decoder: beam_width must be 1..32");
+    // head + per-chunk decode, one decode sub-batch of rows at a time (the scores / guide workspace is sized for e->Nd rows)
+    int si = 0;
+    for (int n0 = 0; n0 < N && rc == MIBC_OK; n0 += e->Nd, ++si) {
+        const int ns = (N - n0 < e->Nd) ? (N - n0) : e->Nd;
+        const int c0 = sub_begin[(size_t)si], nc = sub_begin[(size_t)si + 1] - c0;
+        if (nc == 0) continue;
+        rc = run_head(e, N, T, n0, ns, e->scores);
+        if (rc == MIBC_OK &&
+            mibc_launch_decode_var(e->stream, e->scores, nc, Tmax, e->S, o->beam_width, o->beam_cut, o->blank_score,
+                                   clamp_value(e), o->q_shift, o->q_scale, e->bwd, e->trace, e->path_state,
+                                   out_dev + (size_t)n0 * T, (size_t)N * T, nullptr, e->var_idx + c0,
+                                   e->var_idx + n_chunks + c0, e->var_idx + 2 * n_chunks + c0) != 0)
+            rc = fail(e, MIBC_NOT_SUPPORTED, "decoder: beam_width must be 1..32");
+    }
     var_clear(e);
     if (rc != MIBC_OK) return rc;
     e->last_N = N;
@@ -1149,13 +1190,6 @@ extern "C" int mibc_time_forward(mibc_engine *e, int N, int T_in, float *ms_out)
     (void)hipEventDestroy(b);
     if (rc != MIBC_OK) return rc;
     *ms_out = best;
-    return MIBC_OK;
-}
-
-extern "C" int mibc_debug_set_ws_min_rows(mibc_engine *e, int min_rows) {
-    if (!e) return fail(nullptr, MIBC_ERR_ARG, "null engine");
-    if (!e->ws_ok) return fail(e, MIBC_NOT_SUPPORTED, "the weight-stationary LSTM kernel covers lstm_size 384 only");
-    e->ws_min_rows = min_rows > 0 ? min_rows : (1 << 30);
     return MIBC_OK;
 }
 

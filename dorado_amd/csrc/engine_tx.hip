@@ -133,6 +133,7 @@ void tx_free_ws(mibc_engine *e) {
     for (auto p : tx.cbuf)
         if (p) (void)hipFree(p);
     tx.cbuf.clear();
+    tx.cbuf_bytes.clear();
     tx.ctp.clear();
     tx.ct.clear();
     void *ptrs[] = {tx.x, tx.qkv, tx.attn, tx.tmp, tx.ff, tx.up, tx.vT};
@@ -189,39 +190,51 @@ int tx_reserve(mibc_engine *e, int N_max, int T_in, size_t *total_out) {
     auto &tx = e->tx;
     const size_t N = (size_t)N_max;
     size_t total = 0;
-    auto alloc = [&](half_t **p, size_t halfs, bool zero) -> int {
+    auto alloc = [&](half_t **p, size_t halfs) -> int {
         HIP_OK(e, hipMalloc((void **)p, halfs * 2));
-        if (zero) HIP_OK(e, hipMemsetAsync(*p, 0, halfs * 2, e->stream));  // ordered with the engine's stream
         total += halfs * 2;
         return 0;
     };
-    // conv buffers: buffer i holds conv(i+1)'s output with the NEXT conv's padding rows (zero)
+    // conv buffers: buffer i holds conv(i+1)'s output with the NEXT conv's padding rows (zeroed by tx_set_geometry)
     int T = T_in, C = e->d.conv_size[0];
     for (size_t i = 0; i < tx.convs.size(); ++i) {
-        const int pad_next = tx.convs[i].pad;
-        const int tp = T + 2 * pad_next;
+        const int tp = T + 2 * tx.convs[i].pad;
         half_t *p = nullptr;
-        if (alloc(&p, (N * tp + 64) * (size_t)C, true)) return MIBC_ERR_MEM;
+        if (alloc(&p, (N * tp + 64) * (size_t)C)) return MIBC_ERR_MEM;
         tx.cbuf.push_back(p);
-        tx.ctp.push_back(tp);
-        tx.ct.push_back(T);
+        tx.cbuf_bytes.push_back((N * tp + 64) * (size_t)C * 2);
         T = (T + 2 * tx.convs[i].pad - tx.convs[i].w) / tx.convs[i].stride + 1;
         C = tx.convs[i].cout;
     }
-    tx.T_tok = T;
     if (T > (e->d.tx_max_seq_len > 0 ? e->d.tx_max_seq_len : 2048))
         return fail(e, MIBC_ERR_ARG, "RotE - maximum sequence length exceeded - chunksize too large");
     const size_t R = N * (size_t)T;
-    if (alloc(&tx.x, R * tx.D, false)) return MIBC_ERR_MEM;
-    if (alloc(&tx.qkv, R * 3 * tx.D, false)) return MIBC_ERR_MEM;
-    static const int att_v2 = MIBC_ENV_INT("MIBC_ATT_V2", 1);
-    if (att_v2 && T % 128 == 0)
-        if (alloc(&tx.vT, R * tx.D, false)) return MIBC_ERR_MEM;
-    if (alloc(&tx.attn, R * tx.D, false)) return MIBC_ERR_MEM;
-    if (alloc(&tx.tmp, R * tx.D, false)) return MIBC_ERR_MEM;
-    if (alloc(&tx.ff, R * tx.FF, false)) return MIBC_ERR_MEM;
-    if (alloc(&tx.up, R * tx.sf * tx.D, false)) return MIBC_ERR_MEM;
+    if (alloc(&tx.x, R * tx.D)) return MIBC_ERR_MEM;
+    if (alloc(&tx.qkv, R * 3 * tx.D)) return MIBC_ERR_MEM;
+    if (alloc(&tx.vT, R * tx.D)) return MIBC_ERR_MEM;      // used when the call's token count is a multiple of 128
+    if (alloc(&tx.attn, R * tx.D)) return MIBC_ERR_MEM;
+    if (alloc(&tx.tmp, R * tx.D)) return MIBC_ERR_MEM;
+    if (alloc(&tx.ff, R * tx.FF)) return MIBC_ERR_MEM;
+    if (alloc(&tx.up, R * tx.sf * tx.D)) return MIBC_ERR_MEM;
     *total_out = total;
+    return MIBC_OK;
+}
+
+int tx_set_geometry(mibc_engine *e, int T_in) {
+    auto &tx = e->tx;
+    tx.ctp.clear();
+    tx.ct.clear();
+    int T = T_in;
+    for (size_t i = 0; i < tx.convs.size(); ++i) {
+        tx.ctp.push_back(T + 2 * tx.convs[i].pad);
+        tx.ct.push_back(T);
+        T = (T + 2 * tx.convs[i].pad - tx.convs[i].w) / tx.convs[i].stride + 1;
+        // the pad rows sit where this chunk length puts them: zero the whole buffer, in stream order
+        HIP_OK(e, hipMemsetAsync(tx.cbuf[i], 0, tx.cbuf_bytes[i], e->stream));
+    }
+    if (T > (e->d.tx_max_seq_len > 0 ? e->d.tx_max_seq_len : 2048))
+        return fail(e, MIBC_ERR_ARG, "RotE - maximum sequence length exceeded - chunksize too large");
+    tx.T_tok = T;
     return MIBC_OK;
 }
 
@@ -248,7 +261,7 @@ static int gemm(mibc_engine *e, const half_t *A, const half_t *B, const float *b
         g.rope = e->tx.rope;
         g.rope_T = e->tx.T_tok;
         g.rope_cols = 2 * e->tx.D;
-        g.vT = e->tx.vT;
+        g.vT = (e->tx.T_tok % 128 == 0) ? e->tx.vT : nullptr;
     }
     return mibc_launch_gemm_tn(e->stream, &g);
 }
@@ -298,7 +311,7 @@ int tx_run_network(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
         if (gemm(e, tx.x, L.wqkv, nullptr, tx.qkv, R, 3 * C, C, -1, /*rope*/ 1) != 0)
             return fail(e, MIBC_NOT_SUPPORTED, "tx qkv gemm");
         int arc;
-        if (tx.vT)
+        if (tx.vT && T % 128 == 0)
             arc = mibc_launch_window_attention_v2(e->stream, tx.qkv, tx.vT, tx.attn, N, T, C, tx.H, 3 * C,
                                                   d.tx_win_upper, d.tx_win_lower);
         else

@@ -394,24 +394,13 @@ extern "C" int mibc_launch_gemm256(hipStream_t s, const GemmArgs *a) {
 #endif
     if (a->K != 512 && a->K != 1024 && a->K != 2048) return 1;
     if (a->epi_mode == 1 && (a->rope_T % 256 != 0 || a->rope_cols % 128 != 0 || a->vT == nullptr)) return 1;
-    static int ncu = 0;
-    if (ncu == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int ncu = mibc_ncu();   // of the launching thread's current device
     const long ntiles = (long)((a->M + 255) / 256) * (a->Ncols / 256);
     int grid = (ncu / 8) * 8;
     if (ntiles < grid) grid = (int)((ntiles + 7) / 8) * 8;
 #define G2_LAUNCH(KS_, E_)                                                                                     \
     do {                                                                                                       \
-        static bool once = false;                                                                              \
-        if (!once) {                                                                                           \
-            (void)hipFuncSetAttribute((const void *)gemm256_kernel<KS_, E_>,                                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);               \
-            once = true;                                                                                       \
-        }                                                                                                      \
+        MIBC_LDS_ATTR_ONCE((gemm256_kernel<KS_, E_>), G2_LDS_BYTES);                                           \
         hipLaunchKernelGGL((gemm256_kernel<KS_, E_>), dim3(grid), dim3(512), G2_LDS_BYTES, s, *a);             \
         return 0;                                                                                              \
     } while (0)

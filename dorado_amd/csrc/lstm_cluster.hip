@@ -448,6 +448,11 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
 extern "C" size_t mibc_lstm_cl_lds_bytes(void) { return CL_LDS_BYTES; }
 
 // Returns 0 if launched, 1 if the shape is not covered (caller falls back to the per-workgroup kernels).
+MibcClusterGate &mibc_cluster_gate() {
+    static MibcClusterGate g;
+    return g;
+}
+
 extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin, half_t *Xout, const half_t *Wt,
                                          const float *biascl, const half_t *zeros, float *cbuf, unsigned *flags,
                                          unsigned *err, int T, int N, int reverse,
@@ -457,13 +462,7 @@ extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin
     if ((C != 512 && C != 768 && C != 1024) || N < CL_ROWS || N % CL_ROWS != 0) return 1;
     const int KCL = C / 128;
     const int nclusters = N / CL_ROWS;
-    static int ncu = 0;
-    if (ncu == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int ncu = mibc_ncu();   // of the launching thread's current device
     // every member of a cluster must be resident at the same time: one workgroup per CU (the LDS request
     // guarantees it), never more workgroups than CUs
     int resident = ncu / KCL;
@@ -472,15 +471,11 @@ extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin
     int cpx = 0;
     if (resident % 8 == 0 && (resident / 8) * KCL * 8 <= ncu) cpx = resident / 8;   // same-XCD clusters
     const dim3 grid(resident * KCL);
+    MibcClusterLaunch gate(s);   // after the previous cluster kernel of this device, on whatever stream
     if (hipMemsetAsync(flags, 0, (size_t)nclusters * KCL * 16 * sizeof(unsigned), s) != hipSuccess) return 1;
 #define CL_LAUNCH(CC, M_)                                                                                   \
     do {                                                                                                    \
-        static bool once = false;                                                                           \
-        if (!once) {                                                                                        \
-            (void)hipFuncSetAttribute((const void *)lstm_layer_cl_kernel<CC, M_>,                           \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, CL_LDS_BYTES);            \
-            once = true;                                                                                    \
-        }                                                                                                   \
+        MIBC_LDS_ATTR_ONCE((lstm_layer_cl_kernel<CC, M_>), CL_LDS_BYTES);                                   \
         hipLaunchKernelGGL((lstm_layer_cl_kernel<CC, M_>), grid, dim3(512), CL_LDS_BYTES, s, Xin, Xout, Wt, \
                            biascl, zeros, cbuf, flags, err, T, N, reverse, cpx, resident, tmask);           \
     } while (0)

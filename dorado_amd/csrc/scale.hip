@@ -196,12 +196,7 @@ __global__ __launch_bounds__(256) void scale_i16_f16_kernel(const int16_t *__res
 extern "C" int mibc_launch_read_stats(hipStream_t s, const int16_t *sig, const long long *off, int n_reads,
                                       int strategy, float qa, float qb, float shift_mult, float scale_mult,
                                       float *out_ss, float *out_raw, uint32_t *scratch) {
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute((const void *)read_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * RS_LDS_BINS * 4);
-        once = true;
-    }
+    MIBC_LDS_ATTR_ONCE(read_stats_kernel, 2 * RS_LDS_BINS * 4);
     hipLaunchKernelGGL(read_stats_kernel, dim3(n_reads), dim3(RS_THREADS), 2 * RS_LDS_BINS * 4, s, sig, off,
                        strategy, qa, qb, shift_mult, scale_mult, out_ss, out_raw, scratch);
     return 0;

@@ -281,25 +281,14 @@ extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mod
         ntiles = a->N * ((a->T + rows - 1) / rows);
     }
     if (smem > (size_t)(NW == 8 ? 160 : 80) * 1024) return 1;
-    static int ncu = 0;
-    if (ncu == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int ncu = mibc_ncu();   // of the launching thread's current device
     const int slots = ncu * (NW == 8 ? 1 : 2);
     const int grid = ntiles < slots ? ntiles : slots;
     // activation is a template parameter (a run-time switch costs ~4 extra VALU per output): the
     // head uses 5*tanh (3) or none (-1), conv3 swish (0), clamped swish (1) or tanh (2)
 #define WS_ONE(KT_, M_, CT_, RT_, NW_, ACT_)                                                           \
     if (a->act == ACT_) {                                                                              \
-        static bool once = false;                                                                      \
-        if (!once) {                                                                                   \
-            (void)hipFuncSetAttribute((const void *)wsgemm_kernel<KT_, M_, CT_, RT_, NW_, ACT_>,       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
-            once = true;                                                                               \
-        }                                                                                              \
+        MIBC_LDS_ATTR_ONCE((wsgemm_kernel<KT_, M_, CT_, RT_, NW_, ACT_>), 160 * 1024);                 \
         hipLaunchKernelGGL((wsgemm_kernel<KT_, M_, CT_, RT_, NW_, ACT_>), dim3(grid), dim3(NW_ * 64),  \
                            smem, s, *a);                                                               \
         return 0;                                                                                      \

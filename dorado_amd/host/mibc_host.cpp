@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <exception>
 #include <numeric>
@@ -144,62 +145,96 @@ StitchedRead stitch_chunks(const std::vector<const Chunk *> &cc, size_t raw_samp
 }
 
 // ------------------------------------------------------------------ HipCaller
+// "Global task queues, one per GPU.  This ensures that tasks from different clients are processed in the order they
+// became ready" (CudaCaller.cpp:204-214).  Every caller of a device pushes here; a caller's GPU thread takes the front
+// task only when it is its own, and only while no OTHER caller has batches in flight on the device (`owner`), so the
+// kernels of two callers never interleave (the reference pops a task after it has completed for the same reason,
+// :709-718).
+struct HipCaller::DeviceQueue {
+    std::mutex mut;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<NNTask>> q;   // front = oldest
+    HipCaller *owner = nullptr;
+};
+
+static HipCaller::DeviceQueue &device_queue(int device) {
+    static std::mutex m;
+    static std::map<int, std::unique_ptr<HipCaller::DeviceQueue>> queues;
+    std::lock_guard<std::mutex> lk(m);
+    auto &q = queues[device];
+    if (!q) q = std::make_unique<HipCaller::DeviceQueue>();
+    return *q;
+}
+
+// Batch size for the largest chunk size.  requested > 0: as given.  Otherwise automatic — the role of
+// CudaCaller::determine_batch_dims (CudaCaller.cpp:382-627): the memory cap is memory_limit_fraction of the free device
+// memory minus 1 GB (:434-439) over mibc_query_memory's bytes per chunk (= the memory model of :323-369); inside the cap
+// either the engine's known knee (one LSTM workgroup / cluster slot on every CU) or, with run_batchsize_benchmarks
+// (or requested == -1), the reference's timing sweep (:552-627).
+int HipCaller::choose_batch_size(int chunk_size, int requested) {
+    const int g = mibc_batch_granularity(m_engine);
+    if (requested > 0) return (requested + g - 1) / g * g;
+    size_t per_chunk = 0, fixed = 0, free_b = 0, total_b = 0;
+    if (mibc_query_memory(m_engine, chunk_size, &per_chunk, &fixed) != MIBC_OK ||
+        mibc_device_memory(m_device, &free_b, &total_b) != MIBC_OK || per_chunk == 0)
+        throw std::runtime_error(std::string("auto batch size: ") + mibc_last_error(m_engine));
+    const double budget = double(m_params.memory_limit_fraction) * double(free_b) - double(1ull << 30) - double(fixed);
+    const long cap = budget > 0 ? long(budget / double(per_chunk)) / g * g : 0;
+    if (cap < g)
+        throw std::runtime_error("auto batch size: less than one batch granule fits into the memory limit (" +
+                                 std::to_string(m_params.memory_limit_fraction) + " of " + std::to_string(free_b >> 20) + " MB free)");
+    const long want = (m_desc.tx_d_model > 0) ? 1024 : 256L * g;
+    long n = std::min(want, cap);
+    if (m_params.run_batchsize_benchmarks || requested < 0) {
+        // time the network alone on a short chunk (288 output steps, :497-503) for a descending ladder of batch sizes
+        // under the cap, min of the timed runs, and take the SMALLEST batch whose time per chunk is within
+        // batch_size_time_penalty of the best
+        const int stride = dorado_amd::host::model_stride(m_desc);
+        const int gran = chunk_size_granularity(m_desc);
+        const int t_bench = std::max(gran, (288 * stride) / gran * gran);
+        const long top = std::max<long>(g, std::min<long>(2 * want, cap));
+        std::vector<long> ladder;
+        for (long b = top; b >= g && ladder.size() < 6; b = (b / 2) / g * g) ladder.push_back(b);
+        double best = 1e30;
+        std::vector<std::pair<long, double>> timed;
+        for (long b : ladder) {
+            float ms = 0;
+            if (mibc_time_forward(m_engine, int(b), t_bench, &ms) != MIBC_OK) continue;
+            timed.push_back({b, double(ms) / double(b)});
+            best = std::min(best, timed.back().second);
+            m_batch_timings.push_back({int(b), double(ms) / double(b)});
+            if (m_params.emit_batchsize_benchmarks)
+                fprintf(stderr, "[mibc] hip:%d batch %ld chunk %d: %.6f ms per chunk\n", m_device, b, t_bench, double(ms) / double(b));
+        }
+        for (auto &tb : timed)
+            if (tb.second <= best * (1.0 + double(m_params.batch_size_time_penalty))) n = tb.first;   // descending: ends at the smallest
+        n = std::min(n, cap);
+    }
+    return int(std::max<long>(g, n));
+}
+
 HipCaller::HipCaller(const mibc_model_desc &desc, const float *const *weights, int n_weights, int device,
-                     int chunk_size, int batch_size, const mibc_decode_opts &opts)
-        : m_desc(desc), m_opts(opts), m_device(device), m_chunk_size(chunk_size) {
+                     const std::vector<int> &chunk_sizes, int batch_size, const mibc_decode_opts &opts,
+                     const CallerParams &params)
+        : m_desc(desc), m_opts(opts), m_params(params), m_device(device) {
+    if (chunk_sizes.empty()) throw std::invalid_argument("HipCaller: no chunk size");
     const int rc = mibc_create(device, &desc, weights, n_weights, &m_engine);
     if (rc != MIBC_OK) throw std::runtime_error(std::string("mibc_create: ") + mibc_last_error(nullptr));
-    const int g = mibc_batch_granularity(m_engine);
-    if (batch_size <= 0) {
-        // Auto batch size (0: the known knee; -1: the reference's timing sweep, see below) (the role of CudaCaller::determine_batch_dims, CudaCaller.cpp:323-569, whose timing sweep
-        // looks for the knee of a GPU that batches across SMs).  On this engine the LSTM runs one 64-chunk workgroup
-        // per CU for the whole chunk, so the knee is known: one workgroup on every CU (256 * granularity), bounded by
-        // what fits in 80 % of the free device memory (mibc_query_memory = the memory model of :323-369).
-        size_t per_chunk = 0, fixed = 0, free_b = 0, total_b = 0;
-        if (mibc_query_memory(m_engine, chunk_size, &per_chunk, &fixed) != MIBC_OK ||
-            mibc_device_memory(device, &free_b, &total_b) != MIBC_OK || per_chunk == 0) {
-            const std::string msg = mibc_last_error(m_engine);
-            mibc_destroy(m_engine);
-            throw std::runtime_error("auto batch size: " + msg);
-        }
-        const double budget = 0.8 * double(free_b) - double(fixed);
-        long cap = budget > 0 ? long(budget / double(per_chunk)) : 0;
-        long want = (desc.tx_d_model > 0) ? 1024 : 256L * g;
-        long n = std::min(want, cap / g * g);
-        if (batch_size < 0) {
-            // Timing-based selection, the reference's procedure (CudaCaller.cpp:552-627): time the network alone on
-            // a short chunk (288 output steps, :497-503) for a ladder of batch sizes up to the memory cap, min of the
-            // timed runs, and take the SMALLEST batch whose time per chunk is within `penalty` of the best.
-            const int stride = dorado_amd::host::model_stride(desc);
-            const int gran = chunk_size_granularity(desc);
-            const int t_bench = std::max(gran, (288 * stride) / gran * gran);
-            const long top = std::max<long>(g, std::min<long>(std::max(want, 2 * want), cap / g * g));
-            std::vector<long> ladder;
-            for (long b = top; b >= g && ladder.size() < 6; b = (b / 2) / g * g) ladder.push_back(b);
-            double best = 1e30;
-            std::vector<std::pair<long, double>> timed;
-            for (long b : ladder) {
-                float ms = 0;
-                if (mibc_time_forward(m_engine, int(b), t_bench, &ms) != MIBC_OK) continue;
-                timed.push_back({b, double(ms) / double(b)});
-                best = std::min(best, timed.back().second);
-                m_batch_timings.push_back({int(b), double(ms) / double(b)});
-            }
-            const double penalty = 0.05;
-            n = want;
-            for (auto &tb : timed)
-                if (tb.second <= best * (1.0 + penalty)) n = tb.first;   // ladder is descending: ends at the smallest
-            n = std::min(n, cap / g * g);
-        }
-        batch_size = int(std::max<long>(g, n));
-    }
-    m_batch_size = (batch_size + g - 1) / g * g;
-    m_T = mibc_output_steps(m_engine, chunk_size);
-    if (mibc_reserve(m_engine, m_batch_size, chunk_size) != MIBC_OK) {
-        const std::string msg = mibc_last_error(m_engine);
+    try {
+        // batch dimensions, largest chunk size first (CudaCaller.cpp:408-410); one workspace, sized for the largest,
+        // serves all of them (the engine switches geometry per call)
+        std::vector<int> sizes(chunk_sizes);
+        std::sort(sizes.rbegin(), sizes.rend());
+        sizes.erase(std::unique(sizes.begin(), sizes.end()), sizes.end());
+        const int n = choose_batch_size(sizes[0], batch_size);
+        for (int cs : sizes) m_dims.push_back({n, cs, mibc_output_steps(m_engine, cs)});
+        if (mibc_reserve(m_engine, n, sizes[0]) != MIBC_OK)
+            throw std::runtime_error(std::string("mibc_reserve: ") + mibc_last_error(m_engine));
+    } catch (...) {
         mibc_destroy(m_engine);
-        throw std::runtime_error("mibc_reserve: " + msg);
+        throw;
     }
+    m_queue = &device_queue(device);
     start_thread();
 }
 
@@ -215,7 +250,10 @@ void HipCaller::start_thread() {
 
 void HipCaller::terminate() {  // idempotent (CudaCaller.cpp:273-281)
     m_terminate.store(true);
-    m_cv.notify_all();
+    {
+        std::lock_guard<std::mutex> lk(m_queue->mut);
+    }
+    m_queue->cv.notify_all();
     if (m_thread.joinable()) m_thread.join();
 }
 
@@ -223,35 +261,42 @@ void HipCaller::restart() {  // CudaCaller.cpp:283-287
     if (m_terminate.load()) start_thread();
 }
 
-std::vector<DecodedChunk> HipCaller::call_chunks(const uint16_t *in, int8_t *out, int num_chunks) {
-    return submit(in, nullptr, out, num_chunks);
-}
-
-std::vector<DecodedChunk> HipCaller::call_chunks_i16(const int16_t *in, const float *ss, int8_t *out,
-                                                     int num_chunks) {
-    if (!ss) throw std::invalid_argument("call_chunks_i16: shift/scale pairs missing");
-    return submit(reinterpret_cast<const uint16_t *>(in), ss, out, num_chunks);
-}
-
-std::vector<DecodedChunk> HipCaller::call_chunks_var(const uint16_t *in, int8_t *out,
-                                                     const std::vector<mibc_var_chunk> &chunks) {
-    if (chunks.empty()) return {};
-    auto task = std::make_shared<NNTask>();
-    task->in = in;
-    task->out = out;
-    task->num_chunks = int(chunks.size());
-    task->var = &chunks;
+void HipCaller::run_task(const std::shared_ptr<NNTask> &task) {
+    task->caller = this;
     {
-        std::lock_guard<std::mutex> lk(m_mutex);
-        m_queue.push_front(task);
+        std::lock_guard<std::mutex> lk(m_queue->mut);
+        m_queue->q.push_back(task);
     }
-    m_cv.notify_one();
+    m_queue->cv.notify_all();
     {
         std::unique_lock<std::mutex> lk(task->mut);
         task->cv.wait(lk, [&] { return task->done; });
     }
-    if (task->rc != MIBC_OK) throw std::runtime_error(std::string("mibc_call_var: ") + mibc_last_error(m_engine));
-    const size_t N = size_t(m_batch_size), T = size_t(m_T);
+    if (task->rc != MIBC_OK) throw std::runtime_error("mibc_call: " + task->error);
+}
+
+std::vector<DecodedChunk> HipCaller::call_chunks(size_t dims, const uint16_t *in, int8_t *out, int num_chunks) {
+    return submit(dims, in, nullptr, out, num_chunks);
+}
+
+std::vector<DecodedChunk> HipCaller::call_chunks_i16(size_t dims, const int16_t *in, const float *ss, int8_t *out,
+                                                     int num_chunks) {
+    if (!ss) throw std::invalid_argument("call_chunks_i16: shift/scale pairs missing");
+    return submit(dims, reinterpret_cast<const uint16_t *>(in), ss, out, num_chunks);
+}
+
+std::vector<DecodedChunk> HipCaller::call_chunks_var(size_t dims, const uint16_t *in, int8_t *out,
+                                                     const std::vector<mibc_var_chunk> &chunks) {
+    if (chunks.empty()) return {};
+    auto task = std::make_shared<NNTask>();
+    task->dims = dims;
+    task->in = in;
+    task->out = out;
+    task->num_chunks = int(chunks.size());
+    task->var = &chunks;
+    run_task(task);
+    const BatchDims &bd = m_dims.at(dims);
+    const size_t N = size_t(bd.N), T = size_t(bd.T_out);
     const int stride = model_stride();
     std::vector<DecodedChunk> res(chunks.size());
     for (size_t i = 0; i < chunks.size(); ++i) {
@@ -267,25 +312,18 @@ std::vector<DecodedChunk> HipCaller::call_chunks_var(const uint16_t *in, int8_t 
     return res;
 }
 
-std::vector<DecodedChunk> HipCaller::submit(const uint16_t *in, const float *ss, int8_t *out, int num_chunks) {
+std::vector<DecodedChunk> HipCaller::submit(size_t dims, const uint16_t *in, const float *ss, int8_t *out, int num_chunks) {
     if (num_chunks <= 0) return {};
     auto task = std::make_shared<NNTask>();
+    task->dims = dims;
     task->in = in;
     task->ss = ss;
     task->out = out;
     task->num_chunks = num_chunks;
-    {
-        std::lock_guard<std::mutex> lk(m_mutex);
-        m_queue.push_front(task);
-    }
-    m_cv.notify_one();
-    {
-        std::unique_lock<std::mutex> lk(task->mut);
-        task->cv.wait(lk, [&] { return task->done; });
-    }
-    if (task->rc != MIBC_OK) throw std::runtime_error(std::string("mibc_call: ") + mibc_last_error(m_engine));
+    run_task(task);
     // part 2: slice the [3][N][T] planes into strings (decode/CUDADecoder.cpp:115-173)
-    const size_t N = size_t(m_batch_size), T = size_t(m_T);
+    const BatchDims &bd = m_dims.at(dims);
+    const size_t N = size_t(bd.N), T = size_t(bd.T_out);
     std::vector<DecodedChunk> res(static_cast<size_t>(num_chunks));
     for (int i = 0; i < num_chunks; ++i) {
         const int8_t *mv = out + size_t(i) * T;
@@ -342,47 +380,66 @@ void HipCaller::gpu_thread_fn() {
     // Two batches in flight (the reference gets the same overlap from its runners' own streams,
     // CudaCaller.cpp:645-719): a task is submitted to the engine as soon as one of the two slots is free — its H2D
     // copy runs beside the kernels of the batch in front of it, and the D2H copy + the runner's string slicing of
-    // a finished batch run beside the kernels of the next one.  Completion is reported in submission order.
+    // a finished batch run beside the kernels of the next one.  Completion is reported in submission order.  The two
+    // batches may belong to different batch dimensions: the engine switches its geometry in stream order.
+    using Clock = std::chrono::steady_clock;
     struct InFlight {
         std::shared_ptr<NNTask> task;
         int slot;
         int rc;
-        std::chrono::steady_clock::time_point t0;
+        bool waited;          // mibc_call_wait already consumed this slot's status (rc holds it)
+        Clock::time_point t0;
     };
+    DeviceQueue &dq = *m_queue;
     std::deque<InFlight> inflight;
     bool slot_busy[2] = {false, false};
+    Clock::time_point last_done = Clock::now();
     auto finish = [&](InFlight &f, int rc) {
-        m_model_decode_us += std::chrono::duration_cast<std::chrono::microseconds>(
-                                     std::chrono::steady_clock::now() - f.t0).count();
+        // a batch is charged from its submission or the completion of the batch in front of it, whichever is later
+        const auto now = Clock::now();
+        m_model_decode_us += std::chrono::duration_cast<std::chrono::microseconds>(now - std::max(f.t0, last_done)).count();
+        last_done = now;
         ++m_batches;
         {
             std::lock_guard<std::mutex> lk(f.task->mut);
             f.task->rc = rc;
+            if (rc != MIBC_OK) f.task->error = mibc_last_error(m_engine);
             f.task->done = true;
         }
         f.task->cv.notify_one();
     };
     auto run_sync = [&](NNTask &t) {   // whole call on the engine's stream (variable chunks; retries)
         std::lock_guard<std::mutex> elk(m_engine_mutex);
+        const BatchDims &bd = m_dims.at(t.dims);
         if (t.var)
-            return mibc_call_var(m_engine, t.in, nullptr, m_batch_size, m_chunk_size, t.var->data(), int(t.var->size()),
-                                 &m_opts, t.out);
-        return t.ss ? mibc_call_i16(m_engine, reinterpret_cast<const int16_t *>(t.in), t.ss, m_batch_size, m_chunk_size,
-                                    &m_opts, t.out)
-                    : mibc_call(m_engine, t.in, m_batch_size, m_chunk_size, &m_opts, t.out);
+            return mibc_call_var(m_engine, t.in, nullptr, bd.N, bd.T_in, t.var->data(), int(t.var->size()), &m_opts, t.out);
+        return t.ss ? mibc_call_i16(m_engine, reinterpret_cast<const int16_t *>(t.in), t.ss, bd.N, bd.T_in, &m_opts, t.out)
+                    : mibc_call(m_engine, t.in, bd.N, bd.T_in, &m_opts, t.out);
+    };
+    // with dq.mut held
+    auto front_is_mine = [&] {
+        return !dq.q.empty() && dq.q.front()->caller == this && (dq.owner == nullptr || dq.owner == this);
+    };
+    auto has_mine = [&] {
+        for (auto &t : dq.q)
+            if (t->caller == this) return true;
+        return false;
     };
     while (true) {
         // 1. take new tasks while a slot is free
         {
-            std::unique_lock<std::mutex> lk(m_mutex);
-            if (inflight.empty()) m_cv.wait(lk, [&] { return m_terminate.load() || !m_queue.empty(); });
-            if (m_queue.empty() && inflight.empty()) return;   // terminate and drained
-            while (!m_queue.empty() && (!slot_busy[0] || !slot_busy[1])) {
-                std::shared_ptr<NNTask> task = m_queue.back();
+            std::unique_lock<std::mutex> lk(dq.mut);
+            if (inflight.empty()) {
+                dq.cv.wait(lk, [&] { return front_is_mine() || (m_terminate.load() && !has_mine()); });
+                if (!front_is_mine()) return;   // terminate, and nothing of ours is queued
+            }
+            while (front_is_mine() && (!slot_busy[0] || !slot_busy[1])) {
+                std::shared_ptr<NNTask> task = dq.q.front();
                 if (task->var && !inflight.empty()) break;       // synchronous path: drain first
-                m_queue.pop_back();
+                dq.q.pop_front();
+                dq.owner = this;
                 lk.unlock();
-                InFlight f{task, -1, MIBC_OK, std::chrono::steady_clock::now()};
+                InFlight f{task, -1, MIBC_OK, false, Clock::now()};
                 // the engine decodes all batch rows (stale rows included), the node uses the first n
                 // (CudaCaller.cpp:269-270, BasecallerNode.cpp:185-189)
                 if (task->var) {
@@ -391,40 +448,56 @@ void HipCaller::gpu_thread_fn() {
                     finish(f, rc);
                 } else {
                     f.slot = slot_busy[0] ? 1 : 0;
+                    const BatchDims &bd = m_dims.at(task->dims);
                     {
                         std::lock_guard<std::mutex> elk(m_engine_mutex);
-                        f.rc = mibc_call_async(m_engine, f.slot, task->in, task->ss, m_batch_size, m_chunk_size, &m_opts,
-                                               task->out);
+                        f.rc = mibc_call_async(m_engine, f.slot, task->in, task->ss, bd.N, bd.T_in, &m_opts, task->out);
                     }
                     slot_busy[f.slot] = true;
                     inflight.push_back(std::move(f));
                 }
                 lk.lock();
             }
+            if (inflight.empty()) {   // the device is free for the next caller in the queue
+                if (dq.owner == this) dq.owner = nullptr;
+                lk.unlock();
+                dq.cv.notify_all();
+                continue;
+            }
         }
-        if (inflight.empty()) continue;
-        // 2. oldest batch: done?  (poll, so that a task arriving meanwhile still gets its copy started)
+        // 2. oldest batch.  While the second slot is free and could be filled, poll (a task arriving meanwhile gets its
+        //    copy started at once); otherwise block on the batch's completion event.
         InFlight &f = inflight.front();
-        bool ready = (f.rc != MIBC_OK);
+        bool ready = (f.rc != MIBC_OK) || f.waited;
         if (!ready) {
             std::lock_guard<std::mutex> elk(m_engine_mutex);
             ready = mibc_call_poll(m_engine, f.slot) != 0;
         }
         if (!ready) {
-            std::unique_lock<std::mutex> lk(m_mutex);
-            const bool can_take = !slot_busy[0] || !slot_busy[1];
-            m_cv.wait_for(lk, std::chrono::microseconds(100), [&] { return can_take && !m_queue.empty(); });
-            continue;
+            const bool slot_free = !slot_busy[0] || !slot_busy[1];
+            bool could_take = false;
+            if (slot_free) {
+                std::unique_lock<std::mutex> lk(dq.mut);
+                auto takeable = [&] { return front_is_mine() && dq.q.front()->var == nullptr; };
+                could_take = dq.cv.wait_for(lk, std::chrono::microseconds(200), takeable);
+                if (!could_take && !(front_is_mine() && dq.q.front()->var)) continue;   // keep polling
+            }
+            if (could_take) continue;
+            // both slots busy, or the next task must wait for the drain anyway: sleep on the event
+            std::lock_guard<std::mutex> elk(m_engine_mutex);
+            f.rc = mibc_call_wait(m_engine, f.slot);
+            f.waited = true;
         }
         int rc = f.rc;
-        if (rc == MIBC_OK) {
+        if (rc == MIBC_OK && !f.waited) {
             std::lock_guard<std::mutex> elk(m_engine_mutex);
             rc = mibc_call_wait(m_engine, f.slot);
         }
         if (rc != MIBC_OK) {   // retry once, synchronously (:698-704) — after the other slot has drained
-            if (inflight.size() > 1) {
+            if (inflight.size() > 1 && !inflight[1].waited && inflight[1].rc == MIBC_OK) {
                 std::lock_guard<std::mutex> elk(m_engine_mutex);
-                (void)mibc_call_wait(m_engine, inflight[1].slot);
+                inflight[1].rc = mibc_call_wait(m_engine, inflight[1].slot);   // its own status: kept, not discarded
+                inflight[1].waited = true;
             }
             rc = run_sync(*f.task);
         }
@@ -541,17 +614,19 @@ int dna_trim_start(const SignalNormalisationParams &p, const uint16_t *scaled, s
 // ------------------------------------------------------------------ HipModelRunner
 static std::atomic<int> g_runner_id{0};
 
-HipModelRunner::HipModelRunner(std::shared_ptr<HipCaller> caller) : m_caller(std::move(caller)), m_id(g_runner_id++) {
-    const size_t N = size_t(m_caller->batch_size());
-    m_in = static_cast<uint16_t *>(mibc_host_alloc(N * size_t(m_caller->chunk_size()) * 2));
-    m_out = static_cast<int8_t *>(mibc_host_alloc(3 * N * size_t(m_caller->output_steps())));
+HipModelRunner::HipModelRunner(std::shared_ptr<HipCaller> caller, size_t batch_dims_idx)
+        : m_caller(std::move(caller)), m_dims(batch_dims_idx), m_id(g_runner_id++) {
+    const size_t N = batch_size();
+    m_in = static_cast<uint16_t *>(mibc_host_alloc(N * chunk_size() * 2));
+    m_out = static_cast<int8_t *>(mibc_host_alloc(3 * N * size_t(m_caller->output_steps(m_dims))));
     m_ss = static_cast<float *>(mibc_host_alloc(N * 2 * sizeof(float)));
     if (!m_in || !m_out || !m_ss) throw std::runtime_error("mibc_host_alloc failed");
     for (size_t i = 0; i < N; ++i) {
         m_ss[2 * i] = 0.0f;
         m_ss[2 * i + 1] = 1.0f;
     }
-    std::memset(m_in, 0, N * size_t(m_caller->chunk_size()) * 2);
+    std::memset(m_in, 0, N * chunk_size() * 2);
+    m_var_fill.assign(N, 0);
 }
 
 HipModelRunner::~HipModelRunner() {
@@ -561,15 +636,46 @@ HipModelRunner::~HipModelRunner() {
 }
 
 void HipModelRunner::accept_chunk(int idx, const uint16_t *f16, size_t n) {
-    if (idx < 0 || idx >= m_caller->batch_size() || n != size_t(m_caller->chunk_size()))
-        throw std::runtime_error("accept_chunk: bad index or chunk length");
     if (m_mode == 2) throw std::runtime_error("accept_chunk: this batch already holds raw int16 chunks");
+    if (variable_chunk_sizes()) {
+        // pack behind the chunks already accepted (CudaModelRunner.cpp:21-32): next-fit over the last few open rows,
+        // 2 output steps between the chunks of a row
+        const size_t cs = chunk_size(), stride = size_t(m_caller->model_stride()), gap = 2 * stride;
+        if (n == 0 || n > cs || n % stride != 0)
+            throw std::runtime_error("accept_chunk: a variable chunk must be a stride multiple of at most chunk_size samples");
+        m_mode = 1;
+        if (m_var_overflow.empty()) {
+            const int nrows = int(batch_size());
+            int row = -1;
+            for (int r = std::max(0, m_var_row - 7); r <= m_var_row && r < nrows; ++r)
+                if (size_t(m_var_fill[size_t(r)]) + n <= cs) {
+                    row = r;
+                    break;
+                }
+            if (row < 0 && m_var_row + 1 < nrows) row = ++m_var_row;
+            if (row >= 0) {
+                const int start = m_var_fill[size_t(row)];
+                std::memcpy(m_in + size_t(row) * cs + size_t(start), f16, n * 2);
+                m_var_fill[size_t(row)] = int(size_t(start) + n + gap);
+                m_var_table.push_back({row, start, int(n)});
+                return;
+            }
+        }
+        // the rows are full although the node's aggregate budget (len / stride + 2 steps per chunk) was not: a chunk
+        // cannot straddle two rows here.  Kept aside and called in a second engine batch by call_chunks; to keep the
+        // result order trivial everything accepted from now on follows it.
+        m_var_overflow.push_back({0, 0, int(n)});
+        m_var_overflow_data.emplace_back(f16, f16 + n);
+        return;
+    }
+    if (idx < 0 || idx >= int(batch_size()) || n != chunk_size())
+        throw std::runtime_error("accept_chunk: bad index or chunk length");
     m_mode = 1;
     std::memcpy(m_in + size_t(idx) * n, f16, n * 2);
 }
 
 void HipModelRunner::accept_chunk_i16(int idx, const int16_t *raw, size_t n, float shift, float scale) {
-    if (idx < 0 || idx >= m_caller->batch_size() || n != size_t(m_caller->chunk_size()))
+    if (idx < 0 || idx >= int(batch_size()) || n != chunk_size())
         throw std::runtime_error("accept_chunk_i16: bad index or chunk length");
     if (m_mode == 1) throw std::runtime_error("accept_chunk_i16: this batch already holds scaled f16 chunks");
     m_mode = 2;
@@ -582,14 +688,37 @@ std::vector<DecodedChunk> HipModelRunner::call_chunks(int num_chunks) {
     ++m_batches;
     const int mode = m_mode;
     m_mode = 0;
-    if (mode == 2) return m_caller->call_chunks_i16(reinterpret_cast<const int16_t *>(m_in), m_ss, m_out, num_chunks);
-    return m_caller->call_chunks(m_in, m_out, num_chunks);
+    if (variable_chunk_sizes()) {
+        if (size_t(num_chunks) != m_var_table.size() + m_var_overflow.size())
+            throw std::runtime_error("call_chunks: num_chunks differs from the number of accepted chunks");
+        std::vector<DecodedChunk> res;
+        auto reset = [&] {
+            m_var_table.clear();
+            std::fill(m_var_fill.begin(), m_var_fill.end(), 0);
+            m_var_row = 0;
+        };
+        while (true) {
+            auto part = m_caller->call_chunks_var(m_dims, m_in, m_out, m_var_table);
+            for (auto &d : part) res.push_back(std::move(d));
+            reset();
+            if (m_var_overflow.empty()) break;
+            // second engine batch for what did not fit (rare: see accept_chunk)
+            std::vector<std::vector<uint16_t>> data;
+            data.swap(m_var_overflow_data);
+            m_var_overflow.clear();
+            for (auto &d : data) accept_chunk(0, d.data(), d.size());
+            m_mode = 0;
+        }
+        return res;
+    }
+    if (mode == 2) return m_caller->call_chunks_i16(m_dims, reinterpret_cast<const int16_t *>(m_in), m_ss, m_out, num_chunks);
+    return m_caller->call_chunks(m_dims, m_in, m_out, num_chunks);
 }
 
 std::vector<DecodedChunk> HipModelRunner::call_chunks_var(const std::vector<mibc_var_chunk> &chunks) {
     ++m_batches;
     m_mode = 0;
-    return m_caller->call_chunks_var(m_in, m_out, chunks);
+    return m_caller->call_chunks_var(m_dims, m_in, m_out, chunks);
 }
 
 std::string HipModelRunner::get_name() const {  // unique per instance (CudaModelRunner.cpp:61-67)
@@ -638,22 +767,21 @@ std::vector<std::vector<RunnerPtr>> create_basecall_runners(const mibc_model_des
                                                             const float *const *weights, int n_weights,
                                                             const std::string &device_string, int num_runners,
                                                             const std::vector<int> &chunk_sizes, int batch_size,
-                                                            const mibc_decode_opts &opts) {
+                                                            const mibc_decode_opts &opts, const CallerParams &params) {
     std::vector<int> ids;
     std::string err;
     if (!try_parse_device_ids(device_string, size_t(mibc_device_count()), ids, err)) throw std::runtime_error(err);
     if (ids.empty()) throw std::runtime_error("no GPU device in '" + device_string + "' (the HIP engine has no CPU fallback)");
     if (chunk_sizes.empty()) throw std::invalid_argument("create_basecall_runners: no chunk size");
-    // callers of different devices are built concurrently (api/runner_creation.cpp:95-113: one pool thread per device)
-    std::vector<std::vector<std::shared_ptr<HipCaller>>> callers(ids.size());
+    // ONE caller per device, built concurrently (api/runner_creation.cpp:85-113: one pool thread per device)
+    std::vector<std::shared_ptr<HipCaller>> callers(ids.size());
     std::vector<std::thread> pool;
     std::exception_ptr first;
     std::mutex emut;
     for (size_t di = 0; di < ids.size(); ++di)
         pool.emplace_back([&, di] {
             try {
-                for (int cs : chunk_sizes)
-                    callers[di].push_back(std::make_shared<HipCaller>(desc, weights, n_weights, ids[di], cs, batch_size, opts));
+                callers[di] = std::make_shared<HipCaller>(desc, weights, n_weights, ids[di], chunk_sizes, batch_size, opts, params);
             } catch (...) {
                 std::lock_guard<std::mutex> lk(emut);
                 if (!first) first = std::current_exception();
@@ -661,11 +789,14 @@ std::vector<std::vector<RunnerPtr>> create_basecall_runners(const mibc_model_des
         });
     for (auto &t : pool) t.join();
     if (first) std::rethrow_exception(first);
+    // [device][runner][batch dims] (api/runner_creation.cpp:115-123); the caller orders its batch dimensions largest
+    // chunk size first, the runner list follows the caller's order
     std::vector<std::vector<RunnerPtr>> out;
     for (size_t di = 0; di < ids.size(); ++di) {
         std::vector<RunnerPtr> rs;
         for (int r = 0; r < num_runners; ++r)
-            for (auto &caller : callers[di]) rs.push_back(std::make_unique<HipModelRunner>(caller));
+            for (size_t bd = 0; bd < callers[di]->num_batch_dims(); ++bd)
+                rs.push_back(std::make_unique<HipModelRunner>(callers[di], bd));
         out.push_back(std::move(rs));
     }
     return out;
@@ -1080,22 +1211,35 @@ int mibch_basecall_raw_reads(const mibc_model_desc *desc, const float *const *we
 
 // Throughput of the whole host path (bench.py --through-host): create_basecall_runners + SimplexBasecaller on
 // synthetic f16 reads held in host memory: chunking, pinned batch assembly, H2D, network + decode, D2H, string
-// slicing and stitching, `num_runners` runners per device with two batches in flight.  n_warm reads are called first
-// (untimed), then n_reads are timed.  out4 = {samples/s, seconds, batches, bases}.
+// slicing and stitching, `num_runners` runners per device and batch dimension with two batches in flight per device.
+// device_string may name several devices ("hip:all"): one process, one HipCaller per device, shared chunk queues.
+// n_warm reads are called first (untimed), then n_reads are timed.  two_queues: the reference's extra 0.5x chunk queue.
+// out8 = {read samples/s (what BasecallerNode counts as samples_processed: overlaps are called twice but counted once),
+//         seconds, batches, bases, samples incl. overlap and padding per second (batch rows x chunk size), devices,
+//         partial batches, 0}.
 int mibch_bench_through_host(const mibc_model_desc *desc, const float *const *weights, int n_weights,
                              const char *device_string, int num_runners, int chunk_size, int overlap, int batch_size,
                              const mibc_decode_opts *opts, const uint16_t *signals, int n_distinct, int64_t read_len,
-                             int64_t n_warm, int64_t n_reads, double *out4) {
+                             int64_t n_warm, int64_t n_reads, int two_queues, double *out8) {
     try {
-        auto node = make_node(desc, weights, n_weights, device_string, num_runners, chunk_size, overlap, batch_size, opts);
+        auto node = make_node(desc, weights, n_weights, device_string, num_runners, chunk_size, overlap, batch_size, opts,
+                              two_queues != 0);
         if (n_warm > 0) (void)node->basecall_repeated(signals, size_t(n_distinct), size_t(read_len), size_t(n_warm));
-        const double b0 = node->sample_stats()["batches_called"];
+        auto st0 = node->sample_stats();
         double sec = 0.0;
         const size_t bases = node->basecall_repeated(signals, size_t(n_distinct), size_t(read_len), size_t(n_reads), &sec);
-        out4[0] = double(n_reads) * double(read_len) / sec;
-        out4[1] = sec;
-        out4[2] = node->sample_stats()["batches_called"] - b0;
-        out4[3] = double(bases);
+        auto st1 = node->sample_stats();
+        std::vector<int> ids;
+        std::string err;
+        (void)try_parse_device_ids(device_string, size_t(mibc_device_count()), ids, err);
+        out8[0] = double(n_reads) * double(read_len) / sec;
+        out8[1] = sec;
+        out8[2] = st1["batches_called"] - st0["batches_called"];
+        out8[3] = double(bases);
+        out8[4] = (st1["samples_incl_padding"] - st0["samples_incl_padding"]) / sec;
+        out8[5] = double(ids.size());
+        out8[6] = st1["partial_batches_called"] - st0["partial_batches_called"];
+        out8[7] = 0.0;
         return 0;
     } catch (const std::exception &e) {
         g_herr = e.what();
@@ -1137,7 +1281,7 @@ int mibch_auto_batch_size(const mibc_model_desc *desc, const float *const *weigh
                           int chunk_size, int mode, const mibc_decode_opts *opts, int *chosen, double *timings_out,
                           int max_t, int *n_t) {
     try {
-        HipCaller c(*desc, weights, n_weights, device, chunk_size, mode, *opts);
+        HipCaller c(*desc, weights, n_weights, device, chunk_size, mode, *opts);   // mode -1: timing sweep
         *chosen = c.batch_size();
         const auto &t = c.batch_timings();
         *n_t = int(t.size());

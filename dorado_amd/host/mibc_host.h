@@ -6,8 +6,8 @@
 //                     only signature change is accept_chunk(idx, const uint16_t* f16, n) instead
 //                     of an at::Tensor — INTEGRATION.md shows the one-line adapter)
 //   HipModelRunner    dorado/basecall/CudaModelRunner.cpp:13-79 (pinned in/out, delegates to caller)
-//   HipCaller         dorado/basecall/CudaCaller.cpp:149-287,634-720 (1 per device: engine, FIFO,
-//                     one GPU thread, stats, terminate/restart)
+//   HipCaller         dorado/basecall/CudaCaller.cpp:149-287,634-720 (1 per device: engine, batch dimensions for
+//                     every chunk size, the device's FIFO, one GPU thread, stats, terminate/restart)
 //   create_basecall_runners  dorado/api/runner_creation.cpp:46-133 ([device][runner] order)
 //   generate_chunks / stitch_chunks  dorado/read_pipeline/base/{chunk,stitch}.cpp
 //   ScalerNode (host half)  dorado/read_pipeline/nodes/ScalerNode.cpp:144-269: scaling parameters of a
@@ -134,60 +134,92 @@ int trim_signal(const uint16_t *signal_f16, int n, float threshold = 2.4f, int w
 // min(8000, n/2) scaled samples; 0 when the trim would swallow the read.
 int dna_trim_start(const SignalNormalisationParams &p, const uint16_t *scaled_f16, size_t n_samples);
 
+// The fields of basecall::BasecallerCreationParams that shape a caller (basecall/include/basecall/ModelRunnerBase.h:43-52;
+// model_config / device / pipeline_type arrive as constructor arguments).
+struct CallerParams {
+    float memory_limit_fraction = 0.8f;    // of the free device memory, minus 1 GB (CudaCaller.cpp:434-439)
+    float batch_size_time_penalty = 0.05f; // smallest batch within (1 + penalty) of the best time per chunk (:603-627)
+    bool run_batchsize_benchmarks = false; // true: the reference's timing sweep; false: the engine's known knee
+    bool emit_batchsize_benchmarks = false;// print the sweep's (batch, ms per chunk) table to stderr
+    bool variable_chunk_sizes = false;     // runners pack several chunks per batch row (CudaModelRunner.cpp:21-49)
+};
+
+struct BatchDims {  // CudaCaller::BatchDims (basecall/include/basecall/CudaCaller.h): batch, samples, output steps
+    int N = 0, T_in = 0, T_out = 0;
+};
+
+// One per DEVICE (CudaCaller.cpp:149-200): one engine, one workspace, one GPU thread; every chunk size of the pipeline
+// is a "batch dimension" of this caller (m_batch_dims, :382-413) and all of them go through the device's one FIFO
+// (:204-214 "Global task queues, one per GPU").
 class HipCaller {
 public:
     HipCaller(const mibc_model_desc &desc, const float *const *weights, int n_weights, int device,
-              int chunk_size, int batch_size, const mibc_decode_opts &opts);
+              const std::vector<int> &chunk_sizes, int batch_size, const mibc_decode_opts &opts,
+              const CallerParams &params = CallerParams());
+    HipCaller(const mibc_model_desc &desc, const float *const *weights, int n_weights, int device,
+              int chunk_size, int batch_size, const mibc_decode_opts &opts)
+            : HipCaller(desc, weights, n_weights, device, std::vector<int>{chunk_size}, batch_size, opts) {}
     ~HipCaller();
     // Blocks until decoded (CudaCaller::call_chunks, CudaCaller.cpp:224-271).
-    // in: pinned f16 [batch][chunk]; out: pinned int8 [3][batch][T].
-    std::vector<DecodedChunk> call_chunks(const uint16_t *in_pinned, int8_t *out_pinned, int num_chunks);
+    // in: pinned f16 [batch][chunk]; out: pinned int8 [3][batch][T] of batch dimension `dims`.
+    std::vector<DecodedChunk> call_chunks(size_t dims, const uint16_t *in_pinned, int8_t *out_pinned, int num_chunks);
     // Raw int16 batch + pinned [batch][2] (shift, scale): scaling fused into conv1 (mibc_call_i16).
-    std::vector<DecodedChunk> call_chunks_i16(const int16_t *in_pinned, const float *shift_scale_pinned,
+    std::vector<DecodedChunk> call_chunks_i16(size_t dims, const int16_t *in_pinned, const float *shift_scale_pinned,
                                               int8_t *out_pinned, int num_chunks);
     // Several chunks per row (mibc_call_var); returns one DecodedChunk per entry of `chunks`.
-    std::vector<DecodedChunk> call_chunks_var(const uint16_t *in_pinned, int8_t *out_pinned,
+    std::vector<DecodedChunk> call_chunks_var(size_t dims, const uint16_t *in_pinned, int8_t *out_pinned,
                                               const std::vector<mibc_var_chunk> &chunks);
-    int model_stride() const { return m_chunk_size / m_T; }
+    int model_stride() const { return m_dims[0].T_in / m_dims[0].T_out; }
     // Per-read (shift, scale) of the QUANTILE / MED_MAD strategies on the device (mibc_scaler_stats).
     std::vector<std::pair<float, float>> scaler_stats(const std::vector<std::pair<const int16_t *, size_t>> &reads,
                                                       const SignalNormalisationParams &p);
     void terminate();
     void restart();
     const mibc_model_desc &config() const { return m_desc; }
-    int chunk_size() const { return m_chunk_size; }
-    int batch_size() const { return m_batch_size; }
-    int output_steps() const { return m_T; }
+    size_t num_batch_dims() const { return m_dims.size(); }
+    const BatchDims &batch_dims(size_t i) const { return m_dims.at(i); }
+    int chunk_size(size_t dims = 0) const { return m_dims.at(dims).T_in; }
+    int batch_size(size_t dims = 0) const { return m_dims.at(dims).N; }
+    int output_steps(size_t dims = 0) const { return m_dims.at(dims).T_out; }
     int device() const { return m_device; }
+    bool variable_chunk_sizes() const { return m_params.variable_chunk_sizes; }
     std::pair<int, int> batch_timeouts_ms() const { return {300000, 30000}; }  // CudaCaller.cpp:126-132
     NamedStats sample_stats() const;
     std::string get_name() const { return "HipCaller_hip:" + std::to_string(m_device); }
-    // (batch size, ms per chunk) pairs of the timing sweep (batch_size = -1 at construction); empty otherwise
+    // (batch size, ms per chunk) pairs of the timing sweep (run_batchsize_benchmarks / batch_size = -1); empty otherwise
     const std::vector<std::pair<int, double>> &batch_timings() const { return m_batch_timings; }
+    const CallerParams &params() const { return m_params; }
 
-private:
     struct NNTask {
-        const uint16_t *in;
+        HipCaller *caller = nullptr;
+        size_t dims = 0;
+        const uint16_t *in = nullptr;
         const float *ss = nullptr;   // non-null: `in` holds raw int16 samples
         const std::vector<mibc_var_chunk> *var = nullptr;   // non-null: several chunks per row
-        int8_t *out;
-        int num_chunks;
+        int8_t *out = nullptr;
+        int num_chunks = 0;
         int rc = 0;
+        std::string error;
         bool done = false;
         std::mutex mut;
         std::condition_variable cv;
     };
+    struct DeviceQueue;   // the per-device FIFO shared by every caller of that device
+
+private:
     void start_thread();
     void gpu_thread_fn();
-    std::vector<DecodedChunk> submit(const uint16_t *in, const float *ss, int8_t *out, int num_chunks);
+    void run_task(const std::shared_ptr<NNTask> &task);   // enqueue + wait + throw on error
+    std::vector<DecodedChunk> submit(size_t dims, const uint16_t *in, const float *ss, int8_t *out, int num_chunks);
+    int choose_batch_size(int chunk_size, int requested);
     std::mutex m_engine_mutex;  // the engine (one stream) is used by the GPU thread and by scaler_stats
     mibc_model_desc m_desc;
     mibc_decode_opts m_opts;
+    CallerParams m_params;
     mibc_engine *m_engine = nullptr;
-    int m_device, m_chunk_size, m_batch_size, m_T = 0;
-    std::deque<std::shared_ptr<NNTask>> m_queue;
-    std::mutex m_mutex;
-    std::condition_variable m_cv;
+    int m_device;
+    std::vector<BatchDims> m_dims;
+    DeviceQueue *m_queue = nullptr;
     std::thread m_thread;
     std::atomic<bool> m_terminate{false};
     std::atomic<int64_t> m_batches{0};
@@ -197,34 +229,46 @@ private:
 
 class HipModelRunner final : public ModelRunnerBase {
 public:
-    explicit HipModelRunner(std::shared_ptr<HipCaller> caller);
+    explicit HipModelRunner(std::shared_ptr<HipCaller> caller, size_t batch_dims_idx = 0);
     ~HipModelRunner() override;
+    // Fixed chunks: row chunk_idx of the batch.  Variable chunk sizes (the caller was created with
+    // CallerParams::variable_chunk_sizes): chunk_idx is ignored and the chunk — any stride-multiple length up to
+    // chunk_size() — is packed behind the previous ones, several per batch row, exactly as
+    // CudaModelRunner::accept_chunk does (CudaModelRunner.cpp:21-32); BasecallerNode budgets len/stride + 2 steps per
+    // chunk (BasecallerNode.cpp:408-430), which is this engine's 2-step gap rule.
     void accept_chunk(int chunk_idx, const uint16_t *chunk_f16, size_t n_samples) override;
     // Raw ADC samples of one chunk + its read's (shift, scale): the batch is then scaled on the device.
     // A batch is either all-f16 or all-int16 (the mode resets after every call_chunks).
     void accept_chunk_i16(int chunk_idx, const int16_t *chunk_raw, size_t n_samples, float shift, float scale);
     std::vector<DecodedChunk> call_chunks(int num_chunks) override;
-    // variable mode: write samples anywhere into the pinned batch, then call with the chunk table
-    uint16_t *batch_row(int row) { return m_in + size_t(row) * m_caller->chunk_size(); }
+    // variable mode, explicit form: write samples anywhere into the pinned batch, then call with the chunk table
+    uint16_t *batch_row(int row) { return m_in + size_t(row) * chunk_size(); }
     std::vector<DecodedChunk> call_chunks_var(const std::vector<mibc_var_chunk> &chunks);
-    bool variable_chunk_sizes() const override { return true; }
+    bool variable_chunk_sizes() const override { return m_caller->variable_chunk_sizes(); }
     const mibc_model_desc &config() const override { return m_caller->config(); }
-    size_t chunk_size() const override { return size_t(m_caller->chunk_size()); }
-    size_t batch_size() const override { return size_t(m_caller->batch_size()); }
+    size_t chunk_size() const override { return size_t(m_caller->chunk_size(m_dims)); }
+    size_t batch_size() const override { return size_t(m_caller->batch_size(m_dims)); }
     std::pair<int, int> batch_timeouts_ms() const override { return m_caller->batch_timeouts_ms(); }
     void terminate() override { m_caller->terminate(); }
     void restart() override { m_caller->restart(); }
     std::string get_name() const override;
     NamedStats sample_stats() const override;
+    HipCaller &caller() { return *m_caller; }
 
 private:
     std::shared_ptr<HipCaller> m_caller;
+    size_t m_dims;
     uint16_t *m_in = nullptr;  // pinned [batch][chunk]
     float *m_ss = nullptr;     // pinned [batch][2]
     int8_t *m_out = nullptr;   // pinned [3][batch][T]
     int m_mode = 0;            // 0 undecided, 1 f16 chunks, 2 raw int16 chunks
     int m_id;
     std::atomic<int64_t> m_batches{0};
+    // variable-chunk packing state of the batch being filled
+    std::vector<mibc_var_chunk> m_var_table, m_var_overflow;
+    std::vector<std::vector<uint16_t>> m_var_overflow_data;
+    std::vector<int> m_var_fill;   // samples used per row (incl. the gap behind the last chunk)
+    int m_var_row = 0;
 };
 
 // Samples per output step: product of the conv strides, divided by the upsample factor of the transformer models
@@ -242,13 +286,13 @@ size_t get_chunk_queue_idx(const std::vector<size_t> &chunk_sizes, size_t read_r
 
 // [device][runner][chunk_size] (inner vector: runner-major, chunk sizes in the order given) — the order
 // api::create_basecall_runners returns and BasecallerNode relies on (api/runner_creation.cpp:115-123,
-// BasecallerNode.cpp:494-501).  One caller (engine + workspace) per device and chunk size, num_runners runners
-// sharing each (utils/include/utils/parameters.h:11 num_runners = 2).  batch_size 0 = automatic, sized against the
-// device memory that is still free when the caller is created.
+// BasecallerNode.cpp:494-501).  ONE caller (engine + workspace + GPU thread) per device, serving every chunk size
+// as a batch dimension; num_runners runners per batch dimension (utils/include/utils/parameters.h:11 num_runners = 2).
+// batch_size 0 = automatic, sized against the device memory that is still free when the caller is created.
 std::vector<std::vector<RunnerPtr>> create_basecall_runners(
         const mibc_model_desc &desc, const float *const *weights, int n_weights,
         const std::string &device_string, int num_runners, const std::vector<int> &chunk_sizes, int batch_size,
-        const mibc_decode_opts &opts);
+        const mibc_decode_opts &opts, const CallerParams &params = CallerParams());
 // single chunk size
 std::vector<std::vector<RunnerPtr>> create_basecall_runners(
         const mibc_model_desc &desc, const float *const *weights, int n_weights,

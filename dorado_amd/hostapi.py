@@ -170,23 +170,27 @@ def basecall_reads(cfg: ModelConfig, weights, reads_f16, device="hip:0", num_run
 
 
 def bench_through_host(cfg: ModelConfig, weights, reads_f16, n_warm, n_reads, device="hip:0", num_runners=2,
-                       batch_size=0, beam_width=32):
-    """Throughput of the C++ host path (SimplexBasecaller, `num_runners` runners, two batches in flight) on synthetic
-    reads: reads_f16 [n_distinct, read_len] f16 are cycled n_reads times.  Returns dict(samples_per_s, seconds,
-    batches, bases)."""
+                       batch_size=0, beam_width=32, two_queues=False):
+    """Throughput of the C++ host path (SimplexBasecaller, `num_runners` runners per device and batch dimension, two
+    batches in flight per device) on synthetic reads: reads_f16 [n_distinct, read_len] f16 are cycled n_reads times;
+    device may name several GPUs ("hip:all": one process, one HipCaller per device).  Returns dict(samples_per_s = read
+    samples per second (overlap counted once, as BasecallerNode's samples_processed), samples_incl_padding_per_s,
+    seconds, batches, partial_batches, bases, devices)."""
     L = lib()
     d = cfg.to_desc()
     ws = [np.ascontiguousarray(w, np.float32) for w in weights]
     arr = (C.POINTER(C.c_float) * len(ws))(*[w.ctypes.data_as(C.POINTER(C.c_float)) for w in ws])
     opts = capi.DecodeOptsC(beam_width, 100.0, 2.0, cfg.qbias, cfg.qscale)
     sig = np.ascontiguousarray(reads_f16, np.float16)
-    out = (C.c_double * 4)()
+    out = (C.c_double * 8)()
     rc = L.mibch_bench_through_host(C.byref(d), arr, len(ws), device.encode(), num_runners, cfg.chunk_size, cfg.overlap,
                                     batch_size, C.byref(opts), sig.ctypes.data_as(C.c_void_p), int(sig.shape[0]),
-                                    C.c_int64(sig.shape[1]), C.c_int64(n_warm), C.c_int64(n_reads), out)
+                                    C.c_int64(sig.shape[1]), C.c_int64(n_warm), C.c_int64(n_reads),
+                                    C.c_int(1 if two_queues else 0), out)
     if rc != 0:
         raise capi.MibcError(L.mibch_last_error().decode())
-    return {"samples_per_s": out[0], "seconds": out[1], "batches": out[2], "bases": out[3]}
+    return {"samples_per_s": out[0], "seconds": out[1], "batches": out[2], "bases": out[3],
+            "samples_incl_padding_per_s": out[4], "devices": int(out[5]), "partial_batches": out[6]}
 
 
 # ---------------------------------------------------------------- ScalerNode host half (SURVEY.md 8f-1)

@@ -167,7 +167,8 @@ int mibc_scale_reads(mibc_engine *e, const int16_t *sig_dev, const int64_t *offs
  * occupies steps [sample_start / stride, (sample_start + n_samples) / stride) of its row in each plane (bases and
  * qstring packed at the front of that interval, NUL padded); everything else is 0.
  * shift_scale: NULL (input rows are scaled f16) or float [N][2] (input rows are raw int16, see above).
- * LSTM models with lstm_size 128 / 256 / 384; others return MIBC_NOT_SUPPORTED. */
+ * LSTM models of every supported lstm_size (128 ... 1024; the reference's range: api/runner_creation.cpp:24-44);
+ * transformer models return MIBC_NOT_SUPPORTED (the reference's Tx path has no variable chunks either). */
 typedef struct mibc_var_chunk {
     int row;
     int sample_start;
@@ -202,12 +203,6 @@ int mibc_set_profile(mibc_engine *e, int level);                   /* 0 off, 1 p
  *      3 LSTM stack out [T,N,C] f16 | 4 back-guides [N,T+1,S] f32 (first decode sub-batch)
  *      5 per-block quality prob [N,T] f32 */
 int mibc_debug_tap(mibc_engine *e, int tap, void *host_dst, size_t bytes);
-
-/* ---- experimental kernel switch (test-only) ----
- * Smallest batch (rows) that takes the weight-stationary cluster LSTM kernel (csrc/lstm_ws.hip, lstm_size 384).
- * The kernel is bit-identical to the default one but, as measured, not yet faster, so the product
- * default is "never"; the parity tests of that kernel enable it through this entry. */
-int mibc_debug_set_ws_min_rows(mibc_engine *e, int min_rows);
 
 #ifdef __cplusplus
 }

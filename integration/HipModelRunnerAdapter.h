@@ -9,8 +9,14 @@
 //   accept_chunk(at::Tensor)  the only libtorch type that crosses the boundary: the [1, T_in] f16 slice
 //                             BasecallerNode hands over (BasecallerNode.cpp:397-444) -> raw pointer + length
 //   create_hip_basecall_runners  the branch api::create_basecall_runners gains beside its "cuda" branch
-//                             (api/runner_creation.cpp:85-124): same [devices][runners][chunk_sizes] order,
-//                             same {chunk, 0.5 x chunk} batch dimensions for PipelineType::simplex
+//                             (api/runner_creation.cpp:85-124): ONE caller per device, same
+//                             [devices][runners][batch dims] order, same {chunk, 0.5 x chunk} batch dimensions for
+//                             PipelineType::simplex; every field of BasecallerCreationParams is honoured
+//                             (memory_limit_fraction, batch_size_time_penalty, run_/emit_batchsize_benchmarks,
+//                             variable_chunk_sizes)
+//   variable chunk sizes      accept_chunk packs variable-length slices behind each other exactly as
+//                             CudaModelRunner::accept_chunk does (CudaModelRunner.cpp:21-32); variable_chunk_sizes()
+//                             reports what the caller was created with
 #pragma once
 #include "basecall/ModelRunnerBase.h"
 #include "config/BasecallModelConfig.h"
@@ -70,9 +76,11 @@ inline mibc_model_desc mibc_desc_from_config(const config::BasecallModelConfig &
 
 class HipModelRunnerAdapter final : public ModelRunnerBase {
 public:
-    HipModelRunnerAdapter(std::unique_ptr<dorado_amd::host::ModelRunnerBase> impl, const config::BasecallModelConfig &cfg,
-                          bool low_latency)
-            : m_impl(std::move(impl)), m_cfg(cfg), m_low_latency(low_latency) {}
+    // cfg: the caller's OWN copy of the model configuration, shared by its runners (CudaCaller keeps m_config by value,
+    // CudaCaller.h; CudaModelRunner::config() returns that copy) — never a reference into the creation parameters
+    HipModelRunnerAdapter(std::unique_ptr<dorado_amd::host::ModelRunnerBase> impl,
+                          std::shared_ptr<const config::BasecallModelConfig> cfg, bool low_latency)
+            : m_impl(std::move(impl)), m_cfg(std::move(cfg)), m_low_latency(low_latency) {}
 
     void accept_chunk(int chunk_idx, const at::Tensor &chunk) override {
         // [1, T_in] (or [T_in]) f16 view of the read's signal, possibly shorter than chunk_size for variable chunks
@@ -86,13 +94,12 @@ public:
             out[i] = {std::move(r[i].sequence), std::move(r[i].qstring), std::move(r[i].moves)};
         return out;
     }
-    const config::BasecallModelConfig &config() const override { return m_cfg; }
+    const config::BasecallModelConfig &config() const override { return *m_cfg; }
     size_t chunk_size() const override { return m_impl->chunk_size(); }
     size_t batch_size() const override { return m_impl->batch_size(); }
-    // ModelRunnerBase.h:29.  The packed-rows form of variable chunk sizes needs the node to place several chunks in
-    // one batch row (HipModelRunner::batch_row + call_chunks_var); through THIS interface — one chunk per
-    // accept_chunk index — chunks are fixed-size, so the node must use generate_chunks: report false.
-    bool variable_chunk_sizes() const override { return false; }
+    // ModelRunnerBase.h:29: true when the caller was created with BasecallerCreationParams::variable_chunk_sizes and
+    // the model supports it; the node then cuts reads with generate_variable_chunks and accept_chunk packs the slices
+    bool variable_chunk_sizes() const override { return m_impl->variable_chunk_sizes(); }
     std::pair<int, int> batch_timeouts_ms() const override {
         // CudaCaller.cpp:126-138: low latency 350 ms / 350 ms, else 300 s first chunk / 30 s last chunk
         return m_low_latency ? std::pair<int, int>{350, 350} : m_impl->batch_timeouts_ms();
@@ -109,9 +116,15 @@ public:
 
 private:
     std::unique_ptr<dorado_amd::host::ModelRunnerBase> m_impl;
-    const config::BasecallModelConfig &m_cfg;
+    std::shared_ptr<const config::BasecallModelConfig> m_cfg;
     bool m_low_latency;
 };
+
+// api::check_variable_chunk_sizes_supported (api/runner_creation.cpp:24-44) for this engine: the same model range (LSTM
+// models, 128 < lstm_size <= 1024, multiples of 128); the device condition (koi_can_use_cutlass) has no counterpart.
+inline bool hip_variable_chunk_sizes_supported(const config::BasecallModelConfig &c) {
+    return c.is_lstm_model() && !c.is_flstm_model() && c.lstm_size > 128 && c.lstm_size <= 1024 && c.lstm_size % 128 == 0;
+}
 
 // The "hip:" branch of api::create_basecall_runners (api/runner_creation.cpp:85-124).  weights: host f32 tensors in
 // module.parameters() order (what basecall::load_crf_model_weights returns, crf_utils.cpp:26-150).
@@ -119,7 +132,8 @@ private:
 inline std::pair<std::vector<RunnerPtr>, size_t> create_hip_basecall_runners(const BasecallerCreationParams &params,
                                                                             const std::vector<at::Tensor> &weights,
                                                                             size_t num_gpu_runners) {
-    const config::BasecallModelConfig &cfg = params.model_config;
+    auto cfg_owned = std::make_shared<const config::BasecallModelConfig>(params.model_config);
+    const config::BasecallModelConfig &cfg = *cfg_owned;
     const mibc_model_desc desc = mibc_desc_from_config(cfg);
     std::vector<at::Tensor> keep;
     std::vector<const float *> wp;
@@ -133,13 +147,19 @@ inline std::pair<std::vector<RunnerPtr>, size_t> create_hip_basecall_runners(con
     const std::vector<int> sizes = (params.pipeline_type == PipelineType::simplex)
                                            ? dorado_amd::host::simplex_chunk_sizes(desc, chunk, overlap)
                                            : std::vector<int>{chunk};
+    dorado_amd::host::CallerParams cp;
+    cp.memory_limit_fraction = params.memory_limit_fraction;       // CudaCaller.cpp:434-439
+    cp.batch_size_time_penalty = params.batch_size_time_penalty;   // :603-627
+    cp.run_batchsize_benchmarks = params.run_batchsize_benchmarks;
+    cp.emit_batchsize_benchmarks = params.emit_batchsize_benchmarks;
+    cp.variable_chunk_sizes = params.variable_chunk_sizes && hip_variable_chunk_sizes_supported(cfg);
     auto per_device = dorado_amd::host::create_basecall_runners(desc, wp.data(), int(wp.size()), params.device,
                                                                 int(num_gpu_runners), sizes,
-                                                                int(cfg.basecaller.batch_size()), opts);
+                                                                int(cfg.basecaller.batch_size()), opts, cp);
     std::vector<RunnerPtr> runners;
     const bool low_latency = params.pipeline_type == PipelineType::simplex_low_latency;
     for (auto &dev : per_device)
-        for (auto &r : dev) runners.push_back(std::make_unique<HipModelRunnerAdapter>(std::move(r), cfg, low_latency));
+        for (auto &r : dev) runners.push_back(std::make_unique<HipModelRunnerAdapter>(std::move(r), cfg_owned, low_latency));
     return {std::move(runners), per_device.size()};
 }
 

@@ -76,9 +76,94 @@ def test_adapter_through_reference_interface(pipeline, model):
     assert info[0] == 2 * len(sizes) and info[1] == 1
     assert [info[2 + i] for i in range(min(4, info[0]))] == (sizes * 2)[:min(4, info[0])]
     assert info[6] == 0 and info[7] == (1 if pipeline == 0 else 0) and info[8] == batch
+    assert info[11] == 1, "config() must stay valid after the creation parameters are gone (runner-owned copy)"
     assert (info[9], info[10]) == ((350, 350) if pipeline == 0 else (300000, 30000))
     assert name.value.decode().startswith("HipModelRunner_")
     for i, (s, q, m) in enumerate(want):
         assert seq[i, :len(s)].tobytes().decode() == s and not seq[i, len(s):].any()
         assert qs[i, :len(q)].tobytes().decode() == q
         assert (mv[i] == m).all()
+
+
+@needs_so
+@pytest.mark.gpu
+def test_adapter_variable_chunks_through_reference_interface():
+    """BasecallerCreationParams::variable_chunk_sizes = true: variable_chunk_sizes() is reported, chunks of any
+    stride-multiple length go in through accept_chunk (index ignored, CudaModelRunner.cpp:21-32) and come back from one
+    call_chunks in order; every chunk must equal the engine's call of that chunk ALONE (zero state, zero padding)."""
+    L = _load()
+    cfg = config.tiny(256, 4)
+    cfg.lstm_layers = 3
+    cfg.chunk_size, cfg.overlap = 1200, 120
+    cfg.normalise_basecaller_params()
+    ws = [np.ascontiguousarray(w, np.float32) for w in synth.make_weights(cfg, seed=71)]
+    stride, t_in, batch = cfg.stride, cfg.chunk_size, 64
+    rng = np.random.default_rng(5)
+    # > batch chunks, many short ones (several per row) and a few just over half a row (one per row: forces the
+    # overflow batch of HipModelRunner::call_chunks as well)
+    lens = [int(v) * stride for v in rng.integers(2, t_in // stride // 3, size=70)] + [(t_in // stride // 2 + 1) * stride] * 40
+    rng.shuffle(lens)
+    sig = synth.make_signal(1, int(sum(lens)), seed=72)[0]
+    T = t_in // stride
+    eng = capi.Engine(cfg, ws)
+    want, pos = [], 0
+    for ln in lens:                       # the chunk alone, in row 0 of an otherwise empty batch
+        xb = np.zeros((batch, t_in), np.float16)
+        xb[0, :ln] = sig[pos:pos + ln]
+        want.append(eng.call_var(xb, [(0, 0, ln)])[0])
+        pos += ln
+    eng.close()
+    d = cfg.to_desc()
+    arr = (C.POINTER(C.c_float) * len(ws))(*[w.ctypes.data_as(C.POINTER(C.c_float)) for w in ws])
+    numel = (C.c_int64 * len(ws))(*[w.size for w in ws])
+    n = len(lens)
+    seq, qs, mv = np.zeros((n, T), np.uint8), np.zeros((n, T), np.uint8), np.zeros((n, T), np.uint8)
+    mlen = np.zeros(n, np.int64)
+    clens = (C.c_int64 * n)(*lens)
+    info = (C.c_int * 8)()
+    rc = L.adapter_run_variable(C.byref(d), arr, numel, len(ws), b"hip:0", t_in, cfg.overlap, batch, C.c_float(cfg.qscale),
+                                C.c_float(cfg.qbias), np.ascontiguousarray(sig).ctypes.data_as(C.c_void_p), clens, n, T,
+                                seq.ctypes.data_as(C.c_void_p), qs.ctypes.data_as(C.c_void_p),
+                                mv.ctypes.data_as(C.c_void_p), mlen.ctypes.data_as(C.c_void_p), info)
+    assert rc == 0, L.adapter_last_error().decode()
+    assert info[0] == 1 and info[1] == batch and info[2] == t_in
+    for i, (s, q, m) in enumerate(want):
+        assert mlen[i] == lens[i] // stride == len(m)
+        assert (mv[i, :len(m)] == m).all(), f"chunk {i}: moves differ from the stand-alone call"
+        assert seq[i, :len(s)].tobytes().decode() == s and qs[i, :len(q)].tobytes().decode() == q
+
+
+@needs_so
+@pytest.mark.gpu
+def test_adapter_honours_creation_params():
+    """memory_limit_fraction caps the automatic batch size (CudaCaller.cpp:434-439); run_batchsize_benchmarks selects
+    the timing sweep with batch_size_time_penalty (:603-627)."""
+    L = _load()
+    cfg = config.tiny(128, 4)
+    cfg.chunk_size, cfg.overlap = 2400, 120
+    cfg.normalise_basecaller_params()
+    ws = [np.ascontiguousarray(w, np.float32) for w in synth.make_weights(cfg, seed=3)]
+    d = cfg.to_desc()
+    arr = (C.POINTER(C.c_float) * len(ws))(*[w.ctypes.data_as(C.POINTER(C.c_float)) for w in ws])
+    numel = (C.c_int64 * len(ws))(*[w.size for w in ws])
+    free_b, _ = capi.device_memory(0)
+
+    def auto(frac, penalty=0.05, bench=0):
+        out = C.c_int(0)
+        rc = L.adapter_auto_batch(C.byref(d), arr, numel, len(ws), b"hip:0", cfg.chunk_size, cfg.overlap, C.c_float(frac),
+                                  C.c_float(penalty), bench, C.byref(out))
+        return rc, out.value
+
+    rc, full = auto(0.8)
+    assert rc == 0 and full == 256 * 64, L.adapter_last_error().decode()       # the knee: one workgroup per CU
+    # a fraction that leaves (after the 1 GB reserve) room for only a few hundred chunks
+    eng = capi.Engine(cfg, ws)
+    per, fixed = eng.query_memory(cfg.chunk_size)
+    eng.close()
+    frac = ((1 << 30) + fixed + 1000 * per) / free_b
+    rc, small = auto(frac)
+    assert rc == 0 and 64 <= small <= 1000 and small % 64 == 0, (small, L.adapter_last_error().decode())
+    rc, _ = auto(((1 << 30) * 0.5) / free_b)
+    assert rc != 0 and b"memory limit" in L.adapter_last_error()
+    rc, swept = auto(0.8, penalty=0.5, bench=1)      # a generous penalty accepts a smaller batch than the best one
+    assert rc == 0 and 64 <= swept <= 2 * full and swept % 64 == 0

@@ -237,3 +237,29 @@ def test_live_against_compiled_reference():
         d_r = O.decode(s_r, use_ref=True)
         for a, b in zip(d_o, d_r):
             assert a[0] == b[0] and (a[2] == b[2]).all()
+
+
+@pytest.mark.parametrize("name", ["hac", "sup43", "sup5"])
+def test_dense_baseline_fixture_consistent_with_sampled_fixture(golden_dir, name):
+    """base_<name>_dense.npz (all steps of the first chunks, compiled reference + f16 emulation) and base_<name>.npz
+    (sampled steps of all chunks) come from separate runs of the same generator: where they overlap they must agree
+    to the dense file's fixed-point resolution, and the emulation's distance to the reference must be the same noise
+    level in both."""
+    g = np.load(os.path.join(golden_dir, f"base_{name}.npz"))
+    d = np.load(os.path.join(golden_dir, f"base_{name}_dense.npz"))
+    T = int(g["T"])
+    K = g["ref_scores"].shape[2]
+    ncols, scale = int(d["ncols"]), float(d["scale"])
+    assert d["ref_q"].shape == (len(d["chunks"]), T, ncols) and d["f16_q"].shape == d["ref_q"].shape
+    grp = K // ncols
+    worst = 0.0
+    for ci, n in enumerate(d["chunks"]):
+        for si, t in enumerate(g["steps"][n]):
+            cols = np.arange(ncols) * grp + t % grp
+            worst = max(worst, float(np.abs(d["ref_q"][ci, t] / scale - g["ref_scores"][n, si, cols]).max()))
+            worst = max(worst, float(np.abs(d["f16_q"][ci, t] / scale -
+                                            g["f16_scores"][n, si, cols].astype(np.float32)).max()))
+    assert worst <= 0.5 / scale + 1e-6, worst
+    e = (d["f16_q"].astype(np.float64) - d["ref_q"]) / scale
+    rms = float(np.sqrt((e ** 2).mean()))
+    assert abs(rms - float(g["f16_vs_ref_rms"])) <= 0.25 * float(g["f16_vs_ref_rms"]), (rms, float(g["f16_vs_ref_rms"]))
