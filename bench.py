@@ -210,6 +210,8 @@ def dominant_kernel(cfg, n):
     """(name as rocprofv3 prints it, substring used to look it up in the PMC files)"""
     if cfg.tx is not None:
         return "transformer encoder stack (per layer: qkv gemm256 + window_attention_v3 + fused out-proj/MLP kernels)", None
+    if cfg.lstm_size <= 384 and getattr(cfg, "lstm_quant", False):
+        return "lstm_layer_q8_kernel<%d>" % cfg.lstm_size, "lstm_layer_q8"
     if cfg.lstm_size <= 384:
         return "lstm_layer_x8_kernel<%d>" % cfg.lstm_size, "lstm_layer_x8"
     if n % 256 == 0 and cfg.lstm_size in (512, 768, 1024):
@@ -270,7 +272,16 @@ def run_config(capi, synth, cfg, model_key, device, steps, warmup, batch=0, seed
     # (--profile-run: skipped, so that a rocprofv3 --stats summary of this command averages full-batch launches only)
     parity = bench_scale_parity(eng, out, d_in, n, t_in, T, base.shape[0]) if check_parity else {"ok": None, "skipped": True}
     kname, ksub = dominant_kernel(cfg, n)
-    if cfg.tx is None:
+    peak, dt = MFMA_F16_PEAK, "f16"
+    if cfg.tx is None and getattr(cfg, "lstm_quant", False):
+        # layers 2..L are the int8 kernel (layer 1 = f16 kernel + conversion): dense int8 MFMA peak = 2x the f16 peak
+        per_layer = np.array(lstm_ms).reshape(-1, cfg.lstm_layers)[:, 1:]
+        k_ms = float(per_layer.mean())
+        fl = lstm_flops_per_launch(cfg, n, T)
+        tr = pmc_traffic(ksub, model_key + "_q8", n, t_in)
+        alg_bytes = 2.0 * n * T * cfg.lstm_size * 1
+        peak, dt = 2.0 * MFMA_F16_PEAK, "i8"
+    elif cfg.tx is None:
         k_ms = float(np.mean(lstm_ms))
         fl = lstm_flops_per_launch(cfg, n, T)
         tr = pmc_traffic(ksub, model_key, n, t_in)
@@ -291,8 +302,8 @@ def run_config(capi, synth, cfg, model_key, device, steps, warmup, batch=0, seed
         "parity": parity,
         "network_tflops": n * t_in * steps / el * network_flops_per_sample(cfg) / 1e12,
         "roofline": {
-            "kernel": kname, "bound": "mfma", "achieved": achieved / 1e12, "peak": MFMA_F16_PEAK / 1e12,
-            "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK,
+            "kernel": kname, "bound": "mfma", "achieved": achieved / 1e12, "peak": peak / 1e12, "mfma_dtype": dt,
+            "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": (tr or {}).get("hbm_bytes"), "traffic_source": (tr or {}).get("source"),
             "traffic_algorithmic": alg_bytes, "launch_ms": k_ms, "flops_per_launch": fl,
         },
@@ -446,6 +457,16 @@ def main():
                 if world > 1:
                     raise          # a rank that skipped the collective would hang the others
                 extra[key] = {"error": repr(ex)}
+        if single:
+            # the opt-in int8 LSTM path (the reference's quantised path) on the headline workload: reported beside the f16
+            # headline, never as `value` (its tolerance is its own: tests/test_gpu_baseline_parity.py)
+            try:
+                qcfg = config.hac_v43()
+                qcfg.lstm_quant = True
+                r3, _, _, _, _, _ = run_config(capi, synth, qcfg, "hac", local_rank, 3, 1, 0, seed=0xD0AD0, with_cpu=False)
+                extra["hac_int8_lstm"] = r3
+            except Exception as ex:
+                extra["hac_int8_lstm"] = {"error": repr(ex)}
         if rank == 0:
             line["extra"] = extra
     if rank == 0:

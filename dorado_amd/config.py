@@ -51,6 +51,7 @@ class ModelDescC(ctypes.Structure):
         ("crf_scale", ctypes.c_float),
         ("crf_blank_score", ctypes.c_float),
         ("crf_expand_blanks", ctypes.c_int),
+        ("lstm_quant", ctypes.c_int),
     ]
 
 
@@ -103,6 +104,7 @@ class ModelConfig:
     overlap: int = DEFAULT_OVERLAP
     name: str = "synthetic"
     tx: Optional[TxParams] = None
+    lstm_quant: bool = False   # opt-in: the reference's int8 LSTM path (nn/LSTMStack.cpp:127-211), csrc/lstm_q8.hip
 
     @property
     def is_tx(self) -> bool:
@@ -177,6 +179,7 @@ class ModelConfig:
             d.tx_deepnorm_alpha, d.tx_theta = t.deepnorm_alpha, t.theta
             d.up_size, d.up_scale_factor = t.d_model, t.up_scale_factor
             d.crf_scale, d.crf_blank_score, d.crf_expand_blanks = t.crf_scale, t.crf_blank_score, 1
+        d.lstm_quant = 1 if self.lstm_quant else 0
         return d
 
 

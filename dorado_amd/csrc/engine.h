@@ -65,6 +65,10 @@ extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, h
                                       const half_t *Wf, const half_t *Wf16, const float *biasn, int T, int N,
                                       int reverse);
 extern "C" int mibc_lstm_rows_per_wg(int C);
+// lstm_q8.hip: int8 layer (Xin int8 [T][N][C]; Xout int8 or f16) and the f16 -> int8 conversion behind the first layer
+extern "C" int mibc_launch_lstm_layer_q8(hipStream_t s, int C, const int8_t *Xin, void *Xout, const int8_t *Wq,
+                                         const float *biasn, const float *deqn, int T, int N, int reverse, int out_f16);
+extern "C" int mibc_launch_q8_convert(hipStream_t s, const half_t *in, int8_t *out, size_t n);
 // lstm_cluster.hip: hidden-split cluster kernel (C = 512 / 768 / 1024, N a multiple of 256); 1 = shape not covered
 extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin, half_t *Xout, const half_t *Wt,
                                          const float *biascl, const half_t *zeros, float *cbuf, unsigned *flags,
@@ -80,6 +84,15 @@ extern "C" int mibc_launch_decode(hipStream_t st, const half_t *scores, int N, i
                                   float q_scale, float *bwd, uint32_t *trace,
                                   uint16_t *path_state, int8_t *out3, size_t plane_stride,
                                   float *prob_tap);
+
+// Stage markers for rocprofv3 traces (the role of utils::ScopedProfileRange, torch_utils/include/torch_utils/
+// gpu_profiling.h:32-99, which wraps nvtx ranges): roctx push / pop around the stages of a call when the engine's profile
+// level is >= 2 (mibc_set_profile).  libroctx64 is looked up at run time (dlopen), so the product has no link dependency.
+struct MibcRange {
+    bool on;
+    MibcRange(const struct mibc_engine *e, const char *name);
+    ~MibcRange();
+};
 
 std::string &mibc_gerr();
 #define g_err (mibc_gerr())
@@ -98,6 +111,9 @@ struct mibc_engine {
     std::vector<half_t *> lstm_w;    // 32-unit tiles, k-steps of 16 (v_mfma 32x32x16)
     std::vector<half_t *> lstm_w16;  // 16-unit tiles, k-steps of 32 (v_mfma 16x16x32); C <= 384 only
     std::vector<float *> lstm_bn;  // b_ih + b_hh, [C/32][4][32]
+    // quantised path (lstm_q8.hip): int8 [W_ih | W_hh] in 16x64 fragment order, 1 / (127 * row scale) in bias order
+    std::vector<int8_t *> lstm_wq;
+    std::vector<float *> lstm_deq;
     // cluster kernel (lstm_cluster.hip), C = 512 / 768 / 1024 only
     std::vector<half_t *> lstm_wcl;  // [C/128 members][2 passes][2C/32 slabs][256 gate rows][32] swizzled LDS images
     std::vector<float *> lstm_bcl;   // [C/128][2][2][4][32]
@@ -167,6 +183,7 @@ struct mibc_engine {
     };
     struct TxLayer {
         half_t *wqkv = nullptr, *wo = nullptr, *wfc1 = nullptr, *wfc2 = nullptr;
+        half_t *wimg = nullptr;   // txlayer.hip: out-proj + MLP weights as one fragment-ordered stream (d_model 512)
         float *bo = nullptr, *n1 = nullptr, *n2 = nullptr;
     };
     struct Tx {
@@ -176,6 +193,7 @@ struct mibc_engine {
         half_t *wup = nullptr, *wcrf = nullptr;
         float *bup = nullptr, *rope = nullptr;
         int D = 0, H = 0, FF = 0, depth = 0, sf = 1, conv_stride = 1;
+        int fused = 1;                // layer tail through txlayer.hip (tests compare against the five-launch path)
         // workspace
         std::vector<half_t *> cbuf;   // padded conv outputs (NTC)
         std::vector<size_t> cbuf_bytes;
@@ -204,6 +222,12 @@ inline int fail(mibc_engine *e, int code, const std::string &m) {
     return code;
 }
 
+
+// txlayer.hip: fused layer tail (out-proj + RMSNorm + gated MLP + RMSNorm), d_model 512
+std::vector<half_t> tx_layer_image(const float *wo, const float *w1, const float *w2, int FF);
+bool tx_layer_supported(int d_model, int ff);
+extern "C" int mibc_launch_tx_layer(hipStream_t s, const half_t *attn, half_t *x, const half_t *wimg, const float *bo,
+                                    const float *n1, const float *n2, float alpha, long R, int FF, int mode);
 
 // engine_tx.hip
 int tx_create(mibc_engine *e, const mibc_model_desc &d, const float *const *weights, int n_weights);

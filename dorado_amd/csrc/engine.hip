@@ -10,6 +10,35 @@
 static int check_cluster_error(mibc_engine *e, int slot = 2);
 static int set_geometry(mibc_engine *e, int T_in);
 
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+            pop = (int (*)())dlsym(h, "roctxRangePop");
+        }
+    }
+};
+Roctx &roctx() {
+    static Roctx r;
+    return r;
+}
+}  // namespace
+MibcRange::MibcRange(const mibc_engine *e, const char *name) : on(false) {
+    if (e && e->profile >= 2 && roctx().push && roctx().pop) {
+        (void)roctx().push(name);
+        on = true;
+    }
+}
+MibcRange::~MibcRange() {
+    if (on) (void)roctx().pop();
+}
+
 std::string &mibc_gerr() {
     static thread_local std::string g;
     return g;
@@ -127,6 +156,8 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
                                                    std::to_string(n_weights) + ", expected " +
                                                    std::to_string(expect));
     }
+    if (d.lstm_quant && ((C != 128 && C != 256 && C != 384) || d.lstm_layers < 2))
+        return fail(nullptr, MIBC_NOT_SUPPORTED, "lstm_quant: lstm_size 128 / 256 / 384 and at least two layers");
     if (two_stage && (d.out_features % 128 != 0)) {
         return fail(nullptr, MIBC_NOT_SUPPORTED, "out_features must be a multiple of 128");
     }
@@ -226,6 +257,42 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
         if (upload(e, &dw, wf) || upload(e, &dbn, bn)) return MIBC_ERR_HIP;
         e->lstm_w.push_back(dw);
         e->lstm_bn.push_back(dbn);
+        int8_t *dwq = nullptr;
+        float *ddeq = nullptr;
+        if (d.lstm_quant && l >= 1) {
+            // utils::quantize_tensor(cat(W_ih, W_hh, 1), 1) (torch_utils/tensor_utils.cpp:293-300, LSTMStack.cpp:165-172):
+            // per output row scale = 128 / max|row|, round to nearest even, clip +-127
+            const int KS64 = 2 * C / 64;
+            std::vector<float> scale((size_t)4 * C);
+            for (int row = 0; row < 4 * C; ++row) {
+                float amax = 0.0f;
+                for (int k = 0; k < C; ++k) {
+                    amax = fmaxf(amax, fabsf((float)(half_t)Wih[(size_t)row * C + k]));
+                    amax = fmaxf(amax, fabsf((float)(half_t)Whh[(size_t)row * C + k]));
+                }
+                scale[row] = amax > 0.0f ? 128.0f / amax : 1.0f;
+            }
+            std::vector<int8_t> wq((size_t)4 * C * 2 * C);
+            for (int j = 0; j < C / 16; ++j)
+                for (int ks = 0; ks < KS64; ++ks)
+                    for (int g = 0; g < 4; ++g)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int i = 0; i < 16; ++i) {
+                                const int row = g * C + 16 * j + (lane & 15);
+                                const int k = ks * 64 + 16 * (lane >> 4) + i;
+                                const float w = (float)(half_t)((k < C) ? Wih[(size_t)row * C + k] : Whh[(size_t)row * C + (k - C)]);
+                                float q = nearbyintf(w * scale[row]);
+                                q = fminf(127.0f, fmaxf(-127.0f, q));
+                                wq[((((size_t)j * KS64 + ks) * 4 + g) * 64 + lane) * 16 + i] = (int8_t)q;
+                            }
+            std::vector<float> deq((size_t)4 * C);
+            for (int j = 0; j < C / 32; ++j)
+                for (int g = 0; g < 4; ++g)
+                    for (int h = 0; h < 32; ++h) deq[((size_t)j * 4 + g) * 32 + h] = 1.0f / (127.0f * scale[g * C + 32 * j + h]);
+            if (upload(e, &dwq, wq) || upload(e, &ddeq, deq)) return MIBC_ERR_HIP;
+        }
+        e->lstm_wq.push_back(dwq);
+        e->lstm_deq.push_back(ddeq);
         if (C == 512 || C == 768 || C == 1024) {
             // cluster kernel (lstm_cluster.hip): member j of a cluster owns hidden units [128 j, 128 j + 128); its
             // weight slab (pass p, k-slab ks) is stored as the exact LDS image it is DMA'd into: 256 gate rows
@@ -346,6 +413,10 @@ extern "C" void mibc_destroy(mibc_engine *e) {
     for (auto p : e->lstm_w16)
         if (p) (void)hipFree(p);
     for (auto p : e->lstm_bn) (void)hipFree(p);
+    for (auto p : e->lstm_wq)
+        if (p) (void)hipFree(p);
+    for (auto p : e->lstm_deq)
+        if (p) (void)hipFree(p);
     for (auto &a : e->aslot) {
         if (a.in) (void)hipFree(a.in);
         if (a.ss) (void)hipFree(a.ss);
@@ -542,6 +613,7 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     const mibc_model_desc &d = e->d;
     const int T = mibc_output_steps(e, T_in);
     const bool prof = e->profile > 0;
+    MibcRange r_enc(e, "mibc:encoder");
     if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_START], e->stream));
     if (mibc_launch_conv12(e->stream, in_dev, e->w1, e->b1, e->w2, e->b2, e->a2p, e->a1_tap, e->in_ss, e->in_smask, N, T_in,
                            e->Tpitch, e->pad3, d.conv_act[0], d.conv_act[1]) != 0)
@@ -584,13 +656,30 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     for (int l = 0; l < d.lstm_layers; ++l) {
         // LSTMStack(layers, size, reverse_first = true): nn/LSTMStack.cpp:29-41, CRFModel.cpp:41
         const int reverse = (l % 2 == 0) ? 1 : 0;
+        MibcRange r_layer(e, "lstm_layer");   // the reference's range name (nn/LSTMStack.cpp:100,148)
         // wide layers: the hidden-split cluster kernel whenever the batch is a whole number of 256-row clusters
         // (same arithmetic, element for element, as the per-workgroup kernel it replaces)
         const bool cl_ok = e->use_cluster && !e->lstm_wcl.empty() && e->cl_flags != nullptr && N % 256 == 0 &&
                            mibc_launch_lstm_layer_cl(e->stream, e->C, cur, nxt, e->lstm_wcl[l], e->lstm_bcl[l],
                                                      e->lstm_zero, e->cl_cstate, e->cl_flags, e->cl_err, T, N, reverse,
                                                      e->in_tmask) == 0;
-        if (cl_ok) {
+        if (d.lstm_quant) {
+            // the reference's quantised path: first layer f16 + conversion of its output (LSTMStack.cpp:199-207), then int8
+            if (e->in_tmask != nullptr) return fail(e, MIBC_NOT_SUPPORTED, "lstm_quant: variable chunks are not supported");
+            int qrc;
+            if (l == 0) {
+                qrc = mibc_launch_lstm_layer(e->stream, e->C, cur, nxt, e->lstm_w[l], e->lstm_w16[l], e->lstm_bn[l], T, N, reverse);
+                // f16 output of layer 0 (nxt) -> int8 into the buffer layer 0 read from (cur): layer 1 then reads `cur`,
+                // so the ping-pong is NOT swapped after this layer
+                if (qrc == 0) qrc = mibc_launch_q8_convert(e->stream, nxt, (int8_t *)cur, (size_t)T * N * e->C);
+                if (qrc != 0) return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
+                if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_LSTM0 + l], e->stream));
+                continue;
+            }
+            qrc = mibc_launch_lstm_layer_q8(e->stream, e->C, (const int8_t *)cur, nxt, e->lstm_wq[l], e->lstm_bn[l], e->lstm_deq[l],
+                                            T, N, reverse, l + 1 == d.lstm_layers ? 1 : 0);
+            if (qrc != 0) return fail(e, MIBC_NOT_SUPPORTED, "lstm_quant: batch must be a multiple of 64");
+        } else if (cl_ok) {
             e->cl_used = true;
         } else if (e->in_tmask != nullptr) {
             if (mibc_launch_lstm_layer_masked(e->stream, e->C, cur, nxt, e->C >= 512 ? e->lstm_w[l] : e->lstm_w16[l],
@@ -638,6 +727,7 @@ static int check_cluster_error(mibc_engine *e, int slot) {
 // head for chunk rows [n0, n0+ns) of the LSTM output -> scores_out [ns][T][K]
 static int run_head(mibc_engine *e, int N, int T, int n0, int ns, half_t *scores_out) {
     const mibc_model_desc &d = e->d;
+    MibcRange r_head(e, "linear");
     GemmArgs g{};
     g.A = e->lstm_out + (size_t)n0 * e->C;
     g.M = ns * T;
@@ -775,6 +865,7 @@ extern "C" int mibc_call_device(mibc_engine *e, const uint16_t *in_dev, int N, i
         rc = e->is_tx ? tx_run_head(e, N, n0, ns, e->scores) : run_head(e, N, T, n0, ns, e->scores);
         if (rc != MIBC_OK) return rc;
         if (prof) HIP_OK(e, hipEventRecord(e->sub_ev[si * 3 + 1], e->stream));
+        MibcRange r_dec(e, "beam_search");
         if (mibc_launch_decode(e->stream, e->scores, ns, T, e->S, o->beam_width, o->beam_cut,
                                o->blank_score, clamp_value(e), o->q_shift, o->q_scale, e->bwd, e->trace,
                                e->path_state, out_dev + (size_t)n0 * T, (size_t)N * T,

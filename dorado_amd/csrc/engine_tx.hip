@@ -101,6 +101,8 @@ int tx_create(mibc_engine *e, const mibc_model_desc &d, const float *const *weig
         if (mibc_upload(e, &L.wfc2, f2h(wfc2, (size_t)C * FF))) return MIBC_ERR_HIP;
         if (mibc_upload(e, &L.n1, std::vector<float>(n1, n1 + C))) return MIBC_ERR_HIP;
         if (mibc_upload(e, &L.n2, std::vector<float>(n2, n2 + C))) return MIBC_ERR_HIP;
+        if (tx_layer_supported(C, FF))
+            if (mibc_upload(e, &L.wimg, tx_layer_image(wo, wfc1, wfc2, FF))) return MIBC_ERR_HIP;
         tx.layers.push_back(L);
     }
     {
@@ -153,7 +155,7 @@ void tx_destroy(mibc_engine *e) {
         if (c.bias) (void)hipFree(c.bias);
     }
     for (auto &l : tx.layers) {
-        void *lp[] = {l.wqkv, l.wo, l.wfc1, l.wfc2, l.bo, l.n1, l.n2};
+        void *lp[] = {l.wqkv, l.wo, l.wfc1, l.wfc2, l.bo, l.n1, l.n2, l.wimg};
         for (void *p : lp)
             if (p) (void)hipFree(p);
     }
@@ -308,6 +310,7 @@ int tx_run_network(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     const long R = (long)N * T;
     for (int l = 0; l < tx.depth; ++l) {
         const auto &L = tx.layers[l];
+        MibcRange r_layer(e, "TxEncoder");
         if (gemm(e, tx.x, L.wqkv, nullptr, tx.qkv, R, 3 * C, C, -1, /*rope*/ 1) != 0)
             return fail(e, MIBC_NOT_SUPPORTED, "tx qkv gemm");
         int arc;
@@ -318,6 +321,10 @@ int tx_run_network(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
             arc = mibc_launch_window_attention(e->stream, tx.qkv, tx.attn, N, T, C, tx.H, d.tx_win_upper,
                                                d.tx_win_lower);
         if (arc != 0) return fail(e, MIBC_NOT_SUPPORTED, "tx attention shape");
+        // everything behind the attention in ONE launch (txlayer.hip) when the model has the sup@v5 width
+        if (L.wimg != nullptr && tx.fused &&
+            mibc_launch_tx_layer(e->stream, tx.attn, tx.x, L.wimg, L.bo, L.n1, L.n2, d.tx_deepnorm_alpha, R, tx.FF, 3) == 0)
+            continue;
         if (gemm(e, tx.attn, L.wo, L.bo, tx.tmp, R, C, C, -1) != 0) return fail(e, MIBC_NOT_SUPPORTED, "tx out_proj");
         if (mibc_launch_residual_rmsnorm(e->stream, tx.tmp, tx.x, L.n1, R, C, d.tx_deepnorm_alpha) != 0)
             return fail(e, MIBC_NOT_SUPPORTED, "tx rmsnorm");
@@ -344,4 +351,125 @@ int tx_run_head(mibc_engine *e, int N, int n0, int ns, half_t *scores_out) {
     if (gemm(e, A, tx.wcrf, nullptr, scores_out, rows, e->K, tx.D, -1) != 0)
         return fail(e, MIBC_NOT_SUPPORTED, "tx crf gemm");
     return MIBC_OK;
+}
+
+// Test entry (not part of the public ABI): the fused layer tail (txlayer.hip) against the five-launch path it replaces
+// (gemm256 out-proj -> residual_rmsnorm -> gemm256 FC1 + SwiGLU -> gemm256 FC2 -> residual_rmsnorm) on the same
+// pseudo-random attn / x / weights.  mode 3 = whole tail, 1 = out-proj + norm 1 only (contract: bit-identical), 2 = MLP +
+// norm 2 only (x holds x1).  Reports the number of differing output halfs, the largest difference, the rms difference,
+// the largest |reference| and both run times.
+extern "C" int mibc_debug_txlayer_compare(long R, int FF, int mode, int iters, long long *ndiff, float *maxdiff, float *rmsdiff,
+                                          float *amax_out, float *ms_fused, float *ms_unfused) {
+    const int C = 512;
+    if (!tx_layer_supported(C, FF) || mode < 1 || mode > 3) return 1;
+    auto lcg = [](uint32_t &s) {
+        s = s * 1664525u + 1013904223u;
+        return (float)((s >> 9) & 0x7fff) / 16384.0f - 1.0f;   // [-1, 1)
+    };
+    uint32_t seed = 4242u + (uint32_t)(R + 3 * FF + mode);
+    std::vector<float> wo((size_t)C * C), w1((size_t)2 * FF * C), w2((size_t)C * FF), bo(C), n1(C), n2(C);
+    for (auto &v : wo) v = lcg(seed) * 0.06f;
+    for (auto &v : w1) v = lcg(seed) * 0.06f;
+    for (auto &v : w2) v = lcg(seed) * 0.03f;
+    for (auto &v : bo) v = lcg(seed) * 0.1f;
+    for (auto &v : n1) v = 1.0f + 0.1f * lcg(seed);
+    for (auto &v : n2) v = 1.0f + 0.1f * lcg(seed);
+    std::vector<half_t> hattn((size_t)R * C), hx((size_t)R * C);
+    for (auto &v : hattn) v = (half_t)lcg(seed);
+    for (auto &v : hx) v = (half_t)(lcg(seed) * 0.7f);
+    mibc_engine eng{};
+    mibc_engine *e = &eng;
+    e->tx.D = C;
+    e->tx.FF = FF;
+    half_t *attn = nullptr, *x0 = nullptr, *xa = nullptr, *xb = nullptr, *tmp = nullptr, *ff = nullptr;
+    half_t *dwo = nullptr, *dw1 = nullptr, *dw2 = nullptr, *dimg = nullptr;
+    float *dbo = nullptr, *dn1 = nullptr, *dn2 = nullptr;
+    const size_t xb_bytes = (size_t)R * C * 2;
+    auto cleanup = [&]() {
+        for (void *q : {(void *)attn, (void *)x0, (void *)xa, (void *)xb, (void *)tmp, (void *)ff, (void *)dwo, (void *)dw1,
+                        (void *)dw2, (void *)dimg, (void *)dbo, (void *)dn1, (void *)dn2})
+            if (q) (void)hipFree(q);
+    };
+    std::vector<half_t> w1i((size_t)2 * FF * C);   // the unfused path's 64 y | 64 gate interleave (tx_create)
+    for (int blk = 0; blk < FF / 64; ++blk)
+        for (int j = 0; j < 64; ++j)
+            for (int k = 0; k < C; ++k) {
+                w1i[((size_t)blk * 128 + j) * C + k] = (half_t)w1[((size_t)blk * 64 + j) * C + k];
+                w1i[((size_t)blk * 128 + 64 + j) * C + k] = (half_t)w1[((size_t)FF + blk * 64 + j) * C + k];
+            }
+    if (hipMalloc((void **)&attn, xb_bytes) != hipSuccess || hipMalloc((void **)&x0, xb_bytes) != hipSuccess ||
+        hipMalloc((void **)&xa, xb_bytes) != hipSuccess || hipMalloc((void **)&xb, xb_bytes) != hipSuccess ||
+        hipMalloc((void **)&tmp, xb_bytes) != hipSuccess || hipMalloc((void **)&ff, (size_t)R * FF * 2) != hipSuccess ||
+        mibc_upload(e, &dwo, f2h(wo.data(), wo.size())) || mibc_upload(e, &dw1, w1i) ||
+        mibc_upload(e, &dw2, f2h(w2.data(), w2.size())) || mibc_upload(e, &dimg, tx_layer_image(wo.data(), w1.data(), w2.data(), FF)) ||
+        mibc_upload(e, &dbo, bo) || mibc_upload(e, &dn1, n1) || mibc_upload(e, &dn2, n2)) {
+        cleanup();
+        return -1;
+    }
+    (void)hipMemcpy(attn, hattn.data(), xb_bytes, hipMemcpyHostToDevice);
+    (void)hipMemcpy(x0, hx.data(), xb_bytes, hipMemcpyHostToDevice);
+    const float alpha = 2.4494897f;
+    auto unfused = [&](half_t *x) -> int {
+        if (mode & 1) {
+            if (gemm(e, attn, dwo, dbo, tmp, R, C, C, -1) != 0) return 1;
+            if (mibc_launch_residual_rmsnorm(e->stream, tmp, x, dn1, R, C, alpha) != 0) return 1;
+        }
+        if (mode & 2) {
+            if (gemm(e, x, dw1, nullptr, ff, R, 2 * FF, C, -1, 2, 0, FF) != 0) return 1;
+            if (gemm(e, ff, dw2, nullptr, tmp, R, C, FF, -1) != 0) return 1;
+            if (mibc_launch_residual_rmsnorm(e->stream, tmp, x, dn2, R, C, alpha) != 0) return 1;
+        }
+        return 0;
+    };
+    auto fused = [&](half_t *x) -> int {
+        return mibc_launch_tx_layer(e->stream, attn, x, dimg, dbo, dn1, dn2, alpha, R, FF, mode);
+    };
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float ms[2] = {0, 0};
+    int rc = 0;
+    for (int which = 0; which < 2 && rc == 0; ++which) {
+        half_t *x = which ? xb : xa;
+        (void)hipMemcpy(x, x0, xb_bytes, hipMemcpyDeviceToDevice);
+        rc = which ? unfused(x) : fused(x);                       // the compared result: exactly one application
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0, nullptr);
+        for (int i = 0; i < iters && rc == 0; ++i) rc = which ? unfused(x0) : fused(x0);   // timing only (x0 is scratch here)
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms[which], e0, e1);
+        ms[which] /= (float)(iters > 0 ? iters : 1);
+        if (which == 0) (void)hipMemcpy(x0, hx.data(), xb_bytes, hipMemcpyHostToDevice);   // restore for the reference run
+    }
+    if (rc != 0 || hipDeviceSynchronize() != hipSuccess) {
+        cleanup();
+        return -2;
+    }
+    std::vector<half_t> oa((size_t)R * C), ob((size_t)R * C);
+    (void)hipMemcpy(oa.data(), xa, xb_bytes, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(ob.data(), xb, xb_bytes, hipMemcpyDeviceToHost);
+    long long nd = 0;
+    float md = 0.0f, amax = 0.0f;
+    double sq = 0.0;
+    for (size_t i = 0; i < oa.size(); ++i) {
+        uint16_t a, b;
+        memcpy(&a, &oa[i], 2);
+        memcpy(&b, &ob[i], 2);
+        const float d = fabsf((float)oa[i] - (float)ob[i]);
+        if (a != b) ++nd;
+        if (!(d <= md)) md = d;       // NaN-propagating max
+        sq += (double)d * d;
+        amax = fmaxf(amax, fabsf((float)ob[i]));
+    }
+    *ndiff = nd;
+    *maxdiff = md;
+    *rmsdiff = (float)sqrt(sq / (double)oa.size());
+    *amax_out = amax;
+    *ms_fused = ms[0];
+    *ms_unfused = ms[1];
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    cleanup();
+    return 0;
 }

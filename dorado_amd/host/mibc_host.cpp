@@ -430,6 +430,12 @@ void HipCaller::gpu_thread_fn() {
         {
             std::unique_lock<std::mutex> lk(dq.mut);
             if (inflight.empty()) {
+                // nothing of this caller is on the device: hand the device to whoever is next in the FIFO before sleeping
+                // (also on the way out: a stale owner would block every later caller of this device)
+                if (dq.owner == this) {
+                    dq.owner = nullptr;
+                    dq.cv.notify_all();
+                }
                 dq.cv.wait(lk, [&] { return front_is_mine() || (m_terminate.load() && !has_mine()); });
                 if (!front_is_mine()) return;   // terminate, and nothing of ours is queued
             }
@@ -458,12 +464,7 @@ void HipCaller::gpu_thread_fn() {
                 }
                 lk.lock();
             }
-            if (inflight.empty()) {   // the device is free for the next caller in the queue
-                if (dq.owner == this) dq.owner = nullptr;
-                lk.unlock();
-                dq.cv.notify_all();
-                continue;
-            }
+            if (inflight.empty()) continue;   // (a synchronous task just ran) back to the top: release the device, sleep
         }
         // 2. oldest batch.  While the second slot is free and could be filled, poll (a task arriving meanwhile gets its
         //    copy started at once); otherwise block on the batch's completion event.

@@ -53,6 +53,11 @@ typedef struct mibc_model_desc {
     int up_size, up_scale_factor;
     float crf_scale, crf_blank_score;
     int crf_expand_blanks;
+    /* 1: the reference's quantised LSTM path (nn/LSTMStack.cpp:127-211, KOI_I8): layers 2..L run on int8 weights
+     * (per-row scales, utils::quantize_tensor) and int8 activations, the first layer in f16 (:199-207).  LSTM models with
+     * lstm_size 128 / 256 / 384 and >= 2 layers; not combinable with variable chunks.  0 (default): f16 throughout —
+     * the path the parity contract is stated for. */
+    int lstm_quant;
 } mibc_model_desc;
 
 /* basecall::decode::DecoderOptions (dorado/basecall/include/basecall/DecodedChunk.h:15-23). */
@@ -196,7 +201,10 @@ int mibc_svb16_decode(mibc_engine *e, const uint8_t *streams_dev, const int64_t 
 /* ---- measurement (replaces CudaCaller.cpp:552-569 timing + gpu_profiling.h ranges) ---- */
 int mibc_time_forward(mibc_engine *e, int N, int T_in, float *ms); /* min of 2 runs, like :552-569 */
 int mibc_get_stage_ms(mibc_engine *e, mibc_stage_ms *out);         /* hipEvent times, last call */
-int mibc_set_profile(mibc_engine *e, int level);                   /* 0 off, 1 per-stage events */
+int mibc_set_profile(mibc_engine *e, int level);                   /* 0 off, 1 per-stage events, 2 + roctx ranges around the
+                                                                      stages (utils::ScopedProfileRange,
+                                                                      torch_utils/gpu_profiling.h:32-99) for rocprofv3
+                                                                      --marker-trace */
 
 /* ---- parity taps (test-only; copy an intermediate of the LAST call to the host) ----
  * tap: 0 conv1 out [N,T_in,16] f16 | 1 conv2 out (padded rows) | 2 conv3 out [T,N,C] f16

@@ -170,3 +170,49 @@ def test_baseline_size_vs_reference(name):
         f"identity vs f16 emulation {rep['identity_vs_f16_emulation']} below the precision floor {floor:.4f}"
     assert np.median(id_ref) >= floor - 0.02, \
         f"identity vs reference {rep['identity_vs_reference']} below the precision floor {floor:.4f}"
+
+
+def test_quantised_lstm_vs_reference():
+    """The opt-in int8 LSTM path (csrc/lstm_q8.hip; the reference's KOI_I8 path, nn/LSTMStack.cpp:127-211) on the hac
+    configuration at BASELINE size against the compiled f32 reference.  An 8-bit path has its OWN stated tolerance — it is
+    reported beside the f16 path, which stays the parity headline:
+        scores vs reference (dense, 4 chunks x all steps): rms <= 0.25, and the decoder stays bit-exact on the device's own
+        scores; identity on the reference's confident bases (q >= 20) >= 0.97; measured values are written to
+        gpurun_out/parity_base_hac_q8.json (DESIGN.md quotes them)."""
+    g = np.load(os.path.join(GOLDEN, "base_hac.npz"))
+    gd = np.load(os.path.join(GOLDEN, "base_hac_dense.npz"))
+    cfg = config.hac_v43()
+    cfg.lstm_quant = True
+    N, t_in = int(g["N"]), int(g["T_in"])
+    ws = synth.make_weights(cfg, seed=int(g["weight_seed"]))
+    x16 = synth.make_signal(N, t_in, seed=int(g["signal_seed"]))
+    eng = capi.Engine(cfg, ws)
+    T = eng.output_steps(t_in)
+    scf = np.clip(eng.forward(x16).astype(np.float32), -5.0, 5.0)
+    got = eng.call(x16)
+    eng.close()
+    rows = np.arange(N)[:, None]
+    e_ref = _err(scf[rows, g["steps"]], g["ref_scores"])
+    grp = scf.shape[2] // int(gd["ncols"])
+    dcols = np.arange(int(gd["ncols"]))[None, :] * grp + (np.arange(T) % grp)[:, None]
+    ed_ref = _err(scf[gd["chunks"]][:, np.arange(T)[:, None], dcols], gd["ref_q"].astype(np.float32) / float(gd["scale"]))
+    want_own = O.decode(scf, q_shift=cfg.qbias, q_scale=cfg.qscale, det=1)
+    dec_bad = sum(1 for a, b in zip(got, want_own) if a[0] != b[0] or not (a[2] == b[2]).all())
+    ref_calls = _calls(g, "ref")
+    cg, ct, ca = confident_identity(got, ref_calls, 20)
+    id_ref = np.array([identity(a[0], b[0]) for a, b in zip(got, ref_calls)])
+    rep = {"case": "hac int8 LSTM (lstm_quant)", "N": N, "scores_vs_reference_sampled": {"max_abs": e_ref[0], "rms": e_ref[1]},
+           "scores_vs_reference_dense": {"max_abs": ed_ref[0], "rms": ed_ref[1]},
+           "decoder_chunks_not_bit_exact": dec_bad,
+           "confident_identity": {"qmin": 20, "matched": cg, "confident_ref_bases": ct, "identity": cg / max(ct, 1)},
+           "identity_vs_reference": {"median": float(np.median(id_ref)), "mean": float(id_ref.mean())}}
+    print(json.dumps(rep))
+    try:
+        os.makedirs(DUMP, exist_ok=True)
+        with open(os.path.join(DUMP, "parity_base_hac_q8.json"), "w") as f:
+            json.dump(rep, f, indent=1)
+    except OSError:
+        pass
+    assert dec_bad == 0
+    assert ed_ref[1] <= 0.25 and e_ref[1] <= 0.25, (e_ref, ed_ref)
+    assert ct == 0 or cg / ct >= 0.97, (cg, ct)
