@@ -359,9 +359,12 @@ int tx_run_head(mibc_engine *e, int N, int n0, int ns, half_t *scores_out) {
 // norm 2 only (x holds x1).  Reports the number of differing output halfs, the largest difference, the rms difference,
 // the largest |reference| and both run times.
 extern "C" int mibc_debug_txlayer_compare(long R, int FF, int mode, int iters, long long *ndiff, float *maxdiff, float *rmsdiff,
-                                          float *amax_out, float *ms_fused, float *ms_unfused) {
+                                          float *amax_out, float *ms_fused, float *ms_unfused, uint16_t *dump_fused,
+                                          uint16_t *dump_ref) {
     const int C = 512;
-    if (!tx_layer_supported(C, FF) || mode < 1 || mode > 3) return 1;
+    const int dbg_bits = mode >> 8;      // timing ablations of the fused kernel (results wrong), see TxLayerArgs::dbg
+    mode &= 0xff;
+    if (!tx_layer_supported(C, FF) || (mode != 1 && mode != 2 && mode != 3 && mode != 6)) return 1;
     auto lcg = [](uint32_t &s) {
         s = s * 1664525u + 1013904223u;
         return (float)((s >> 9) & 0x7fff) / 16384.0f - 1.0f;   // [-1, 1)
@@ -417,12 +420,14 @@ extern "C" int mibc_debug_txlayer_compare(long R, int FF, int mode, int iters, l
         if (mode & 2) {
             if (gemm(e, x, dw1, nullptr, ff, R, 2 * FF, C, -1, 2, 0, FF) != 0) return 1;
             if (gemm(e, ff, dw2, nullptr, tmp, R, C, FF, -1) != 0) return 1;
-            if (mibc_launch_residual_rmsnorm(e->stream, tmp, x, dn2, R, C, alpha) != 0) return 1;
+            if (mode & 4) {   // raw FC2 result
+                if (hipMemcpyAsync(x, tmp, xb_bytes, hipMemcpyDeviceToDevice, e->stream) != hipSuccess) return 1;
+            } else if (mibc_launch_residual_rmsnorm(e->stream, tmp, x, dn2, R, C, alpha) != 0) return 1;
         }
         return 0;
     };
     auto fused = [&](half_t *x) -> int {
-        return mibc_launch_tx_layer(e->stream, attn, x, dimg, dbo, dn1, dn2, alpha, R, FF, mode);
+        return mibc_launch_tx_layer(e->stream, attn, x, dimg, dbo, dn1, dn2, alpha, R, FF, mode | (dbg_bits << 8));
     };
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
@@ -433,7 +438,7 @@ extern "C" int mibc_debug_txlayer_compare(long R, int FF, int mode, int iters, l
         half_t *x = which ? xb : xa;
         (void)hipMemcpy(x, x0, xb_bytes, hipMemcpyDeviceToDevice);
         rc = which ? unfused(x) : fused(x);                       // the compared result: exactly one application
-        (void)hipDeviceSynchronize();
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) rc = 3;
         (void)hipEventRecord(e0, nullptr);
         for (int i = 0; i < iters && rc == 0; ++i) rc = which ? unfused(x0) : fused(x0);   // timing only (x0 is scratch here)
         (void)hipEventRecord(e1, nullptr);
@@ -449,6 +454,8 @@ extern "C" int mibc_debug_txlayer_compare(long R, int FF, int mode, int iters, l
     std::vector<half_t> oa((size_t)R * C), ob((size_t)R * C);
     (void)hipMemcpy(oa.data(), xa, xb_bytes, hipMemcpyDeviceToHost);
     (void)hipMemcpy(ob.data(), xb, xb_bytes, hipMemcpyDeviceToHost);
+    if (dump_fused) memcpy(dump_fused, oa.data(), xb_bytes);
+    if (dump_ref) memcpy(dump_ref, ob.data(), xb_bytes);
     long long nd = 0;
     float md = 0.0f, amax = 0.0f;
     double sq = 0.0;

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_q8_kernel(
     for (int u = 0; u < PF; ++u)
 #pragma unroll
         for (int g = 0; g < 4; ++g) wr[u][g] = q8_wload(wrs, wvoff, (u * 4 + g) * 1024);
-    int kpre = PF;
+    int kpre = PF % KTOT;     // (C = 128: the ring holds the wave's whole k range)
 
     {
         const int t_first = reverse ? (T - 1) : 0;

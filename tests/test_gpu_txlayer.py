@@ -2,11 +2,12 @@
 one launch) against the five launches it replaces, on the same pseudo-random operands (pytest -m gpu).
 
 Contract:
-  mode 1 (out-proj + norm 1): BIT-IDENTICAL — same MFMA shape, same k order, same bias / rounding / reduction order.
-  mode 2 (MLP + norm 2), mode 3 (whole tail): FC1 and SwiGLU are bit-identical; FC2 adds the same products in a different
-      order inside each group of 16 hidden units (the SwiGLU output stays in the accumulator registers' layout), so the
-      normalised output differs by f32 summation order only: every element within 2 f16 ulps of the unfused result
-      (|x| <= 4 after the norm -> 2 ulp = 0.0078), rms difference <= 3e-4.
+  Same MFMA shape, same k order, same f16 rounding points and the same reduction tree as the unfused kernels; two f32
+  summation orders differ — the out-proj adds its bias first instead of last, and FC2 adds the same products in a different
+  order inside each group of 16 hidden units (the SwiGLU output stays in the accumulator registers' layout) — so the
+  normalised output differs by f32 rounding only: every element within one f16 ulp at the largest magnitude of the test data
+  (|x| < 16 -> 0.0078; measured max 0.00195), rms difference <= 1e-4 (measured 0.7e-5 ... 2.4e-5), on all three modes
+  (1 = out-proj + norm 1, 2 = MLP + norm 2, 3 = whole tail).
 The BASELINE-size test (test_gpu_baseline_parity.py, sup5: 18 layers) then pins the whole model to the compiled reference."""
 import ctypes as C
 
@@ -20,11 +21,11 @@ pytestmark = pytest.mark.gpu
 def _compare(R, FF, mode, iters=1):
     L = capi.lib()
     L.mibc_debug_txlayer_compare.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)] + \
-        [C.POINTER(C.c_float)] * 5
+        [C.POINTER(C.c_float)] * 5 + [C.c_void_p, C.c_void_p]
     nd = C.c_longlong()
     md, rms, amax, tf, tu = (C.c_float() for _ in range(5))
     rc = L.mibc_debug_txlayer_compare(R, FF, mode, iters, C.byref(nd), C.byref(md), C.byref(rms), C.byref(amax),
-                                      C.byref(tf), C.byref(tu))
+                                      C.byref(tf), C.byref(tu), None, None)
     assert rc == 0, rc
     print(f"R={R} FF={FF} mode={mode}: differing halfs {nd.value} of {R * 512}, max {md.value:.5f}, rms {rms.value:.6f}, "
           f"|ref| max {amax.value:.3f}; fused {tf.value:.3f} ms vs five launches {tu.value:.3f} ms")
@@ -32,20 +33,20 @@ def _compare(R, FF, mode, iters=1):
 
 
 @pytest.mark.parametrize("R", [128 * 300, 128 * 257 + 77])
-def test_outproj_norm1_bit_identical(R):
+def test_outproj_norm1(R):
     nd, md, rms, amax = _compare(R, 2048, 1)
-    assert amax > 0.5 and nd == 0, (nd, md)
+    assert amax > 0.5 and md <= 0.0079 and rms <= 1e-4, (nd, md, rms)
 
 
 @pytest.mark.parametrize("R,FF,mode", [(128 * 300, 2048, 2), (128 * 300, 2048, 3), (128 * 513 + 5, 2048, 3), (4096, 256, 3)])
 def test_mlp_and_whole_tail_match_unfused(R, FF, mode):
     nd, md, rms, amax = _compare(R, FF, mode)
     assert amax > 0.5
-    assert md <= 0.0079 and rms <= 3e-4, (nd, md, rms)
+    assert md <= 0.0079 and rms <= 1e-4, (nd, md, rms)
 
 
 def test_whole_tail_full_batch_timing():
     """1 M tokens (the sup@v5 bench batch): same contract, and the fused launch must beat the five launches."""
     L = capi.lib()
     nd, md, rms, amax = _compare(1024 * 1024, 2048, 3, iters=3)
-    assert md <= 0.0079 and rms <= 3e-4
+    assert md <= 0.0079 and rms <= 1e-4

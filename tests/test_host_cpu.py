@@ -220,3 +220,16 @@ def test_simplex_chunk_sizes_and_queue_routing():
     assert q(sizes, 9996) == 0 and q(sizes, 50000) == 0                           # else the largest
     assert q([4998, 9996], 50000) == 1 and q([4998, 9996], 10) == 0
     assert q([9996], 5) == 0
+
+
+def test_fused_layer_kernel_has_no_unpadded_asm_mfma_hazard():
+    """csrc/txlayer.hip pins two accumulator tiles to VGPRs with inline-asm MFMAs, which hipcc's hazard recogniser does not
+    see.  The one hazard that can arise around them — a VALU-written register (a compiler v_mov / v_accvgpr_read) read as an
+    MFMA operand within two states — must not occur in the compiled product kernel: scan the gfx950 ISA (no GPU needed)."""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "check_asm_hazards.py")
+    out = subprocess.run([sys.executable, tool], capture_output=True, text=True)
+    product = [l for l in out.stdout.splitlines() if "tx_layer_kernelILi3ELi0E" in l]
+    assert not product, "\n".join(product)
+    assert "VALU -> asm-MFMA operand hazards" in out.stdout, out.stdout + out.stderr
