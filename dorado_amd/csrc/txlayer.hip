@@ -20,16 +20,27 @@
 //          k index inside a 16-group is permuted — 0-3, 8-11 | 4-7, 12-15 — and W2's image is stored with the same
 //          permutation): the [tokens][FF] intermediate never leaves the register file, not even to LDS;
 //   * weights are the only operand that moves: the layer's 6.5 MB stream through a 4-slot LDS ring of 32 KB stages by direct
-//     LDS DMA (global_load_lds_dwordx4), in CONSUMPTION order and in MFMA-fragment order (the host lays the image out:
-//     every ds_read_b128 is lane-linear, conflict-free, no swizzle), three stages ahead, counted vmcnt + one raw barrier
-//     per stage (= 32 MFMAs per wave); every stage is read by all four waves (LDS fragment traffic: 1 KB per MFMA and
-//     wave = 128 B/clk/CU at the matrix pipe's peak, half of what the 256 x 256 GEMM tile needs per flop once its
-//     activation operand is counted);
-//   * SwiGLU of slab j runs inside the FC2 stage of slab j - 1 (VALU beside MFMAs of the same wave);
-//   * both residual RMSNorms run on the accumulators: 8 rows at a time go through a per-wave 8 KB LDS patch (XOR-swizzled
-//     16-byte slots) into row-per-wave form, where a lane owns the same 8 columns as in residual_rmsnorm_kernel and the
-//     reduction is the same xor tree; the out-proj adds its bias first instead of last and FC2 sums the same products in a
-//     different order inside each 16-group, so x differs from the unfused path by f32 rounding only.
+//     LDS DMA (buffer_load_dwordx4 ... lds: resource + scalar stage offset + one per-lane VGPR offset), in CONSUMPTION order
+//     and in MFMA-fragment order (the host lays the image out: every ds_read_b128 is lane-linear, conflict-free, no
+//     swizzle), two stages ahead, counted vmcnt + one raw barrier per stage (= 32 MFMAs per wave); every stage is read by
+//     all four waves (LDS fragment traffic: 1 KB per MFMA and wave = 128 B/clk/CU at the matrix pipe's peak);
+//   * ONE wave per SIMD issues in order, so everything that is not an MFMA has to fit into the ~28 issue cycles an MFMA
+//     leaves: each MFMA slot carries one fragment read (TL_FD slots ahead of its use), at most one of the eight 1 KB DMA
+//     pieces of a stage (a burst of eight stalls the wave 100-185 cycles per piece), and a third of a SwiGLU element.  A
+//     sched_barrier per slot keeps hipcc from regrouping that (left alone it batched 8-12 LDS reads and put whole SwiGLU
+//     slabs between two MFMAs: 68 cycles per MFMA over the MLP; slot-scheduled: 45);
+//   * SwiGLU of slab j is cut into 48 parts that ride the 96 MFMA slots after the slab's FC1 (the FC2 stage of slab j - 1
+//     and FC1 of slab j + 1); the FC1 outputs are first packed to f16 pairs so that FC1 of the next slab can reuse ay / ag;
+//   * both residual RMSNorms run on the accumulators, in registers: a lane holds half of ONE token row (quads of columns
+//     32 c + 8 q + 4 lhi + 0..3) and lane ^ 32 the other half, so a row's sum of squares is a register sum and one exchange;
+//     the residual and the result move as 8-byte quads; x1 becomes the MLP's input fragments by one v_permlane32_swap per
+//     dword (and the fragments turn back into residual quads the same way): x1 is stored for the next layer's residual but
+//     never read back.  The out-proj adds its bias first instead of last, FC2 sums the same products in a different order
+//     inside each 16-group, and the norm sums squares in a different order, so x differs from the unfused path by f32
+//     rounding only (tests/test_gpu_txlayer.py: max 0.004, rms 2e-5 at |x| <= 2.2).
+// Cycle stamps at 1 M tokens (tools/txlayer_time.py, DBG 64, workgroup 0 tile 1, 128 rows):
+//      out-proj 40 k | norm 1 44 k | MLP 287 k (6144 MFMAs: 47 cycles each, 32 = matrix-pipe peak) | norm 2 31 k
+// 7.16 ms per layer against 9.2-9.4 ms for the five launches.
 #include "common.h"
 #include "cluster_util.h"
 #include "engine.h"
@@ -42,7 +53,6 @@
 #define TL_OFF_SIDE (TL_NS * TL_STAGE_BYTES)           // 4 waves x 8 KB
 #define TL_LDS_BYTES (TL_OFF_SIDE + 4 * 8192)
 #define TL_D 512
-#define TL_PITCH 1056                // bytes per row of the epilogue patch (1024 + 32: conflict-free quads, see norm_rows)
 #define TL_FD 4                      // fragment look-ahead in MFMAs (8 x 32 cycles of LDS latency cover)
 
 // FC1's two accumulator tiles must live in VGPRs: the 16 tiles of the FC2 / out-proj result fill the AGPR half of the
@@ -74,12 +84,17 @@ struct TxLayerArgs {
     float alpha;
     long R;
     int FF;
-    // DBG template parameter = timing ablations (wrong results; instantiated for MODE 2 only): 1 = every request fetches
-    // stage 0 (always L2-hot), 2 = no requests at all, 4 = no epilogues (no norm, no stores), 8 = no input-fragment loads
+    unsigned long long *trace;   // test-only: cycle stamps of workgroup 0 / wave 0 on its second tile (nullptr in production)
+    // DBG template parameter = timing ablations (wrong results): 1 = every request fetches stage 0 (always L2-hot), 2 = no
+    // requests at all; 64 = cycle stamps into trace (results unchanged)
 };
 
 // MODE 3 = whole tail; 1 = out-proj + norm 1 only (x <- x1); 2 = MLP + norm 2 only (x holds x1); 6 = MLP only, x <- the raw
 // FC2 result   [test decomposition]
+typedef half_t tl_half2 __attribute__((ext_vector_type(2)));
+typedef unsigned tl_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned tl_u4 __attribute__((ext_vector_type(4)));
+
 template <int MODE, int DBG = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tx_layer_kernel(TxLayerArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -99,21 +114,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (my_tiles == 0) return;
 
     // ---- weight stream: stage g of this workgroup = stage (g % stages_per_tile) of the image -> ring slot g & 3 ----
-    const unsigned long long wbase = (unsigned long long)p.wimg + (unsigned long long)first_stage * TL_STAGE_BYTES +
-                                     (unsigned)(wave * 8 * 1024 + lane * 16);
+    // buffer addressing: resource in SGPRs, one per-lane VGPR offset for the whole kernel, stage / piece offsets scalar —
+    // a 64-bit per-lane address got spilled, and every reload in the loop came with an s_waitcnt vmcnt(0), i.e. a drain of
+    // all requests in flight
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)((const char *)p.wimg + (size_t)first_stage * TL_STAGE_BYTES), 0, 0x7ffffffe, 0x00020000);
+    const int voff_w = wave * 8 * 1024 + lane * 16;
     const unsigned dma_dst = lds0 + (unsigned)(wave * 8 * 1024);
     int g_issue = 0;        // next stage to request (ring slot g_issue & 3)
     int st_issue = 0;       // g_issue % stages_per_tile: stage of the image (past the last tile the stream simply wraps:
                             // two stages nobody reads — the waits are counted, so the request count per stage is constant)
-    auto issue_stage = [&]() __attribute__((always_inline)) {
-        const unsigned long long src = wbase + (unsigned long long)(unsigned)((DBG & 1) ? 0 : st_issue) * TL_STAGE_BYTES;
-        const unsigned dst = dma_dst + (unsigned)(g_issue & 3) * TL_STAGE_BYTES;
-        if (!(DBG & 2)) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) cl_dma16((ghalf_p)(src + q * 1024), dst + q * 1024);
+    // one 1 KB piece per call: a burst of eight stalls the issuing wave for 100-185 cycles per piece (the request queue
+    // backs up), one piece behind an MFMA costs about 60, half of it in the MFMA's shadow
+    auto issue_piece = [&](int q) __attribute__((always_inline)) {
+        const int soff = ((DBG & 1) ? 0 : st_issue) * TL_STAGE_BYTES + q * 1024;
+        const unsigned dst = dma_dst + (unsigned)(g_issue & 3) * TL_STAGE_BYTES + q * 1024;
+        if (!(DBG & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_vptr)(size_t)dst, 16, voff_w, soff, 0, 0);
+        if (q == 7) {
+            ++g_issue;
+            st_issue = (st_issue + 1 == stages_per_tile) ? 0 : st_issue + 1;
         }
-        ++g_issue;
-        st_issue = (st_issue + 1 == stages_per_tile) ? 0 : st_issue + 1;
+    };
+    auto issue_stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) issue_piece(q);
     };
     // ---- stage protocol.  Boundary B(s) (executed inside stage s - 1, TL_FD MFMAs before its end; B(0) up front):
     //   wait until my requests for stage s have landed (the 8 of stage s + 1 stay in flight), barrier (everybody's have;
@@ -127,13 +151,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         fnext = (LDSP(const half8_t))(smem3 + (unsigned)(g_use & 3) * TL_STAGE_BYTES) + lane;
-        issue_stage();
         ++g_use;
     };
     half8_t fr[TL_FD];
     issue_stage();
     issue_stage();
     boundary();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_piece(q);     // the other four go out behind the first four MFMAs
     fcur = fnext;
 #pragma unroll
     for (int i = 0; i < TL_FD; ++i) fr[i] = fcur[i * 64];
@@ -142,16 +167,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         cl_static_for<32>([&](auto i_c) __attribute__((always_inline)) {
             constexpr int i = decltype(i_c)::value;
             const half8_t a = fr[i % TL_FD];
+            mf(i_c, a);                                              // everything below runs in this MFMA's shadow
             if (i == 32 - TL_FD) boundary();
+            if (i >= 32 - TL_FD) issue_piece(i - (32 - TL_FD));      // the request for stage s + 2, one piece per MFMA slot:
+            if (i < 8 - TL_FD) issue_piece(i + TL_FD);               // TL_FD pieces here, the rest in the next stage
             fr[i % TL_FD] = (i + TL_FD < 32) ? fcur[(i + TL_FD) * 64] : fnext[(i + TL_FD - 32) * 64];
-            mf(i_c, a);
+            __builtin_amdgcn_sched_barrier(0);      // one fragment read per MFMA slot: hipcc otherwise batches 8-12 reads
         });
         fcur = fnext;
     };
 
     half8_t xf[32];          // this wave's 32 token rows x 512 as B fragments: xf[ks] = row l31, k = 16 ks + 8 lhi + 0..7
     float16_t out[16];       // 32 x 512 f32: out[c][r] = column 32 c + (r&3) + 8 (r>>2) + 4 lhi of token row l31
-    LDSP(unsigned char) side = smem3 + TL_OFF_SIDE + wave * 8192;
+    LDSP(unsigned char) side = smem3 + TL_OFF_SIDE + wave * 8192;      // this wave's patch: the two norm weight vectors
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ((LDSP(float))side)[lane * 8 + e] = p.n1[lane * 8 + e];
+        ((LDSP(float))side)[512 + lane * 8 + e] = p.n2[lane * 8 + e];
+    }
+    asm volatile("" ::: "memory");
     // rows of attn / x through buffer descriptors: address = descriptor + SGPR row offset + one lane-constant VGPR offset
     // (+ immediate), rows past R read as zero and their stores are dropped by the bounds check — no per-row address
     // registers, no tail branches
@@ -168,76 +202,95 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         });
     };
 
-    // residual RMSNorm of this wave's 32 rows on the accumulators: 4 rows per pass through the wave's LDS patch (rows of
-    // TL_PITCH = 1056 bytes: every access below is base + immediate, and the 16 lanes of a pass that write 8-byte quads hit
-    // 16 different bank groups), then row-per-wave form: a lane owns columns 8 lane .. 8 lane + 7 as in
-    // residual_rmsnorm_kernel and the reduction is the same xor tree.
-    //   v = f16(out) + alpha * res ;  y = f16((v * rsqrt(mean(v^2) + eps)) * w) -> p.x
-    // The 32 residual rows (res[], load_res) are already in registers: beside LDS-DMA traffic hipcc drains vmcnt(0) for every
-    // VGPR-returning load, so loads inside the passes — or register spills, which are scratch loads — would each cost a
-    // full memory round trip behind the stores of the pass before.
-    half8_t res[32];   // residual rows of this wave in row-per-wave form (lane: columns 8 lane .. 8 lane + 7), see load_res
-    // fresh: rows this wave stored earlier in the launch (x1) -> sc1: served by L2, never by a stale L1 line.
-    // (Requesting the rows earlier — under the last MFMA stages, into registers the input fragments no longer need — was
-    // tried: hipcc then parks fragments in accumulator registers and reads them back right in front of the asm MFMAs, the
-    // hazard tools/check_asm_hazards.py rejects.)
-    auto load_res = [&](auto r_c, long row0, auto fresh) __attribute__((always_inline)) {
-        constexpr int r = decltype(r_c)::value;
-        res[r] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff_row, (int)(row0 * row_bytes) + r * (int)row_bytes,
-                                                                                  decltype(fresh)::value ? 16 : 0));
-    };
-    auto norm_rows = [&](long row0, const float *wn, auto fresh) __attribute__((always_inline)) {
-        if (DBG & 4) return;
-        float w[8];   // norm weights of this lane's 8 columns
-#pragma unroll
-        for (int e = 0; e < 8; ++e) w[e] = wn[lane * 8 + e];
+    // residual RMSNorm of this wave's 32 rows, on the accumulators: a lane holds 256 of the 512 columns of ONE token row (l31) —
+    // quads of columns 32 c + 8 q + 4 lhi + 0..3 — and lane ^ 32 holds the other 256, so the row sum is a register sum plus
+    // one exchange; nothing goes through LDS.  (Rounds 1-2 of this kernel transposed the accumulators through an LDS patch to
+    // reuse residual_rmsnorm_kernel's row-per-wave form: 45-50 k cycles per 32 rows, a quarter of the kernel.)
+    //   v = f16(out) + alpha * res ;  y = f16((v * rsqrt(mean(v^2) + eps)) * w) -> p.x        (nn/TxModules.cpp:41-56, 478-486)
+    // Residual: from p.x (8-byte quads), or from the input fragments xf[] when those ARE the residual rows (the MLP's input).
+    // A fragment (k = 16 ks + 8 lhi + 0..7 of row l31) is the quad pair {q = 2 m, 2 m + 1} of column tile c (ks = 2 c + m)
+    // after one v_permlane32_swap per dword: lanes l31 / l31 + 32 hold quads A0 B0 / A1 B1 and need fragments A0 A1 / B0 B1.
+    // The swap is its own inverse, so the same two instructions turn fragments back into quads — and turn the y quads of the
+    // first norm into the MLP's input fragments without a trip through memory.
+    // Norm weights: f32 in this wave's 8 KB LDS patch (n1 at 0, n2 at 2048), read as broadcast float4s.
+    const int voff_quad = l31 * (int)row_bytes + 8 * lhi;
+    auto norm_rows = [&](long row0, int which, auto from_xf, auto to_xf) __attribute__((always_inline)) {
         const int soff0 = (int)(row0 * row_bytes);
-        cl_static_for<32>([&](auto r_c) __attribute__((always_inline)) { load_res(r_c, row0, fresh); });
-        const int i_own = l31 & 3;
-        LDSP(unsigned char) own_row = side + i_own * TL_PITCH + 8 * lhi;
-        LDSP(const unsigned char) my_slot = side + lane * 16;
+        int vq = voff_quad;
+        asm volatile("" : "+v"(vq));     // opaque per call: offsets stay immediates
+        LDSP(const unsigned char) wrow = side + which * 2048 + 16 * (vq & 8 ? 1 : 0);
+        constexpr bool RAW = (MODE & 4) != 0;     // test decomposition: the raw GEMM result (no residual, no norm)
+        tl_u2 rq[decltype(from_xf)::value || RAW ? 1 : 64];
+        if (!decltype(from_xf)::value && !RAW) {
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-            if ((l31 >> 2) == ps) {
+            for (int c = 0; c < 16; ++c)
 #pragma unroll
-                for (int c = 0; c < 16; ++c)
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        half4_t q;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) q[e] = (half_t)out[c][4 * rq + e];
-                        // columns 32 c + 8 rq + 4 lhi + 0..3 of token row l31
-                        *(LDSP(half4_t))(own_row + (4 * c + rq) * 16) = q;
-                    }
-            }
-            // the rows are read back as half8: a different vector type than the half4 stores above — without the fence
-            // hipcc's type-based alias analysis lets the first row read overtake them
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const half8_t a = *(LDSP(const half8_t))(my_slot + i * TL_PITCH);
-                const int soff = soff0 + (4 * ps + i) * (int)row_bytes;
-                if (MODE & 4) {   // test decomposition: the raw GEMM result (no residual, no norm)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, a), rs_x, voff_row, soff, 0);
-                    continue;
-                }
-                float v[8];
-                float ss = 0.0f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    v[e] = (float)a[e] + (float)res[4 * ps + i][e] * p.alpha;
-                    ss += v[e] * v[e];
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-                const float rstd = rsqrtf(ss / (float)TL_D + 1e-5f);
-                half8_t y;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = (half_t)((v[e] * rstd) * w[e]);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, y), rs_x, voff_row, soff, 0);
-            }
-            asm volatile("" ::: "memory");
+                for (int q = 0; q < 4; ++q) rq[4 * c + q] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, vq + 64 * c + 16 * q, soff0, 0);
         }
+        float ss = 0.0f;
+        if (!RAW) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    tl_u2 ra, rb;
+                    if (decltype(from_xf)::value) {
+                        const tl_u4 f = __builtin_bit_cast(tl_u4, xf[2 * c + m]);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(f[0], f[2], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(f[1], f[3], false, false);
+                        ra[0] = s0[0]; ra[1] = s1[0]; rb[0] = s0[1]; rb[1] = s1[1];
+                    } else {
+                        ra = rq[4 * c + 2 * m];
+                        rb = rq[4 * c + 2 * m + 1];
+                    }
+                    const half4_t ha4 = __builtin_bit_cast(half4_t, ra), hb4 = __builtin_bit_cast(half4_t, rb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float va = (float)(half_t)out[c][8 * m + e] + (float)ha4[e] * p.alpha;
+                        const float vb = (float)(half_t)out[c][8 * m + 4 + e] + (float)hb4[e] * p.alpha;
+                        ss += va * va;
+                        ss += vb * vb;
+                        out[c][8 * m + e] = va;          // v replaces the accumulator (same register: read, then written)
+                        out[c][8 * m + 4 + e] = vb;
+                    }
+                }
+            ss += __shfl_xor(ss, 32, 64);
+        }
+        const float rstd = rsqrtf(ss / (float)TL_D + 1e-5f);
+        // 8-byte stores: with 16-byte (fragment-form) stores the results were wrong in rows 12-15 / 28-31 of every tile — the
+        // swap below writes BOTH its operands, and a register that still is the data of a > 8-byte store in flight must not
+        // be written for a wait state hipcc does not insert for the swap's source operand
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                half4_t ya, yb;
+                if (RAW) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ya[e] = (half_t)out[c][8 * m + e];
+                        yb[e] = (half_t)out[c][8 * m + 4 + e];
+                    }
+                } else {
+                    const float4_t wa = *(LDSP(const float4_t))(wrow + 128 * c + 64 * m);
+                    const float4_t wb = *(LDSP(const float4_t))(wrow + 128 * c + 64 * m + 32);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ya[e] = (half_t)((out[c][8 * m + e] * rstd) * wa[e]);
+                        yb[e] = (half_t)((out[c][8 * m + 4 + e] * rstd) * wb[e]);
+                    }
+                }
+                const tl_u2 ua = __builtin_bit_cast(tl_u2, ya), ub = __builtin_bit_cast(tl_u2, yb);
+                __builtin_amdgcn_raw_buffer_store_b64(ua, rs_x, vq + 64 * c + 32 * m, soff0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(ub, rs_x, vq + 64 * c + 32 * m + 16, soff0, 0);
+                if (decltype(to_xf)::value) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
+                    tl_u4 f;
+                    f[0] = s0[0]; f[1] = s1[0]; f[2] = s0[1]; f[3] = s1[1];
+                    xf[2 * c + m] = __builtin_bit_cast(half8_t, f);
+                }
+            }
     };
     // this wave's 32 token rows as B fragments; fresh: rows this wave stored earlier in the launch (after a vmcnt(0))
     auto load_frags = [&](__amdgpu_buffer_rsrc_t rs, long row0, auto fresh) __attribute__((always_inline)) {
@@ -256,12 +309,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     do {                                                                  \
         _Pragma("unroll") for (int i_ = 0; i_ < TL_FD; ++i_) asm volatile("" : "+v"(fr[i_])); \
     } while (0)
+    // After an epilogue the ring is read again (the stage has long landed): the copies requested at the end of the stage
+    // before it are then dead instead of living — spilled, and reloaded between the stores — through the epilogue.
+#define TL_REPRIME_FR()                                                   \
+    do {                                                                  \
+        asm volatile("" ::: "memory");                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < TL_FD; ++i_) fr[i_] = fcur[i_ * 64]; \
+        TL_PIN_FR();                                                      \
+    } while (0)
 
+#define TL_STAMP(k_)                                                                        \
+    do {                                                                                    \
+        if ((DBG & 64) && p.trace != nullptr && blockIdx.x == 0 && tid == 0 && ti == 1) p.trace[k_] = __builtin_readcyclecounter(); \
+    } while (0)
     for (long ti = 0; ti < my_tiles; ++ti) {
         const long tile = blockIdx.x + ti * (long)gridDim.x;
+        TL_STAMP(0);
         const long row0 = tile * 128 + wave * 32;       // first row of this wave
         // B fragments of the tile's input rows (attn, or x1 in the MLP-only mode)
-        if (!(DBG & 8) || ti == 0) load_frags((MODE & 1) ? rs_attn : rs_x, row0, std::false_type{});
+        load_frags((MODE & 1) ? rs_attn : rs_x, row0, std::false_type{});
         TL_PIN_FR();
         if (MODE & 1) {
             // the out-proj accumulators start from the bias (column 32 c + 8 rq + 4 lhi + e of every token row)
@@ -286,12 +352,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 constexpr int st = decltype(st_c)::value;
                 stage_512(xf[2 * st], xf[2 * st + 1]);
             });
-            norm_rows(row0, p.n1, std::false_type{});     // p.x <- x1
-            if (MODE == 1) continue;
-            // x1 becomes the MLP's input fragments: re-read the rows this wave has just stored, once the stores are in L2
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            load_frags(rs_x, row0, std::true_type{});
-            TL_PIN_FR();
+            TL_STAMP(1);
+            // p.x <- x1, and x1 becomes the MLP's input fragments in place
+            if (MODE == 1) {
+                norm_rows(row0, 0, std::false_type{}, std::false_type{});
+                TL_REPRIME_FR();
+                continue;
+            }
+            norm_rows(row0, 0, std::false_type{}, std::true_type{});
+            TL_STAMP(2);
+            TL_REPRIME_FR();
+            TL_STAMP(3);
 #pragma unroll
             for (int c = 0; c < 16; ++c)
 #pragma unroll
@@ -301,51 +372,95 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // ---- phase B: gated MLP, slabs of 32 hidden units ----
         float16_t ay, ag;
         half8_t ha[2], hb[2];
-        // FC1 of one slab: two stages of 256 k each
-        auto fc1_slab = [&]() __attribute__((always_inline)) {
+        // SwiGLU of a slab (nn/TxModules.cpp:171-175 on the f16-rounded FC1 outputs) -> FC2 B fragments.  One wave per SIMD
+        // issues in order, and an MFMA's shadow holds about 28 cycles of other work; a SwiGLU element costs about 60 (v_exp and
+        // v_rcp are quarter rate).  The sixteen elements of a slab are therefore cut into 48 parts and spread over the 96 MFMA
+        // slots that follow the slab's FC1: its outputs are first packed to f16 pairs (which frees ay / ag for the next slab's
+        // FC1), then part A = exp, B = reciprocal, C = products + store into the fragment.  (All sixteen between the MFMAs of
+        // the one FC2 stage: 64 cycles per MFMA there.)
+        tl_half2 yg[16];
+        float sw_t = 0.0f;
+        auto sw_pack = [&](int r) __attribute__((always_inline)) {
+            tl_half2 v;
+            v[0] = (half_t)ay[r];
+            v[1] = (half_t)ag[r];
+            asm volatile("" : "+v"(v));
+            yg[r] = v;
+        };
+        auto sw_part = [&](half8_t (&hn)[2], int n) __attribute__((always_inline)) {
+            const int e = n / 3, ph = n % 3;
+            if (ph == 0) {
+                sw_t = __expf(-(float)yg[e][1]);
+            } else if (ph == 1) {
+                sw_t = __builtin_amdgcn_rcpf(1.0f + sw_t);
+            } else {
+                const float gt = (float)yg[e][1], y = (float)yg[e][0];
+                sw_t = gt * sw_t * y;
+            }
+            asm volatile("" : "+v"(sw_t));      // computed in this MFMA slot (hipcc otherwise sinks the lot to the first use)
+            if (ph == 2) hn[e >> 3][e & 7] = (half_t)sw_t;
+        };
+        // FC1 of one slab: two stages of 256 k each; parts 16 .. 47 of the previous slab's SwiGLU behind every other MFMA
+        auto fc1_slab = [&](half8_t (&hn)[2], auto with_swiglu) __attribute__((always_inline)) {
             cl_static_for<2>([&](auto h_c) __attribute__((always_inline)) {
                 constexpr int h = decltype(h_c)::value;
                 run_stage([&](auto i_c, half8_t a) __attribute__((always_inline)) {
-                    constexpr int i = decltype(i_c)::value;      // fragment (s = i / 2, t = i % 2)
-                    if (h == 0 && i == 0) tl_mfma_v_first(ay, a, xf[0]);
-                    else if (h == 0 && i == 1) tl_mfma_v_first(ag, a, xf[0]);
-                    else if (h == 1 && i == 30) tl_mfma_v_last(ay, a, xf[31]);
-                    else if (h == 1 && i == 31) tl_mfma_v_last(ag, a, xf[31]);
-                    else if ((i & 1) == 0) tl_mfma_v(ay, a, xf[16 * h + (i >> 1)]);
-                    else tl_mfma_v(ag, a, xf[16 * h + (i >> 1)]);
+                    constexpr int i = decltype(i_c)::value;      // fragment (s = i / 2, t = i % 2), k-step ks = 16 h + s
+                    if (h == 0 && i < 2) {
+                        if ((i & 1) == 0) tl_mfma_v_first(ay, a, xf[0]);
+                        else tl_mfma_v_first(ag, a, xf[0]);
+                    } else if (h == 1 && i >= 30) {
+                        if ((i & 1) == 0) tl_mfma_v_last(ay, a, xf[31]);
+                        else tl_mfma_v_last(ag, a, xf[31]);
+                    } else {
+                        if ((i & 1) == 0) tl_mfma_v(ay, a, xf[16 * h + (i >> 1)]);
+                        else tl_mfma_v(ag, a, xf[16 * h + (i >> 1)]);
+                    }
+                    if (decltype(with_swiglu)::value && (i & 1) == 0) sw_part(hn, 16 + 16 * h + (i >> 1));
                 });
             });
         };
-        // SwiGLU of the finished slab (nn/TxModules.cpp:171-175 on the f16-rounded FC1 outputs) -> FC2 B fragments
-        auto swiglu_elem = [&](half8_t (&hn)[2], int r) __attribute__((always_inline)) {
-            const float y = (float)(half_t)ay[r], gt = (float)(half_t)ag[r];
-            hn[r >> 3][r & 7] = (half_t)(gt * fast_sigmoid(gt) * y);
-        };
-        // FC2 stage of the previous slab (fragments hp) with the SwiGLU of the current one (-> hn) between its MFMAs
+        // FC2 stage of slab j - 1 (fragments hp); with_swiglu: the FC1 outputs in ay / ag (slab j) are packed behind the first
+        // sixteen MFMAs, parts 0 .. 15 of their SwiGLU (-> hn) behind the other sixteen
         auto fc2_stage = [&](const half8_t (&hp)[2], half8_t (&hn)[2], auto with_swiglu) __attribute__((always_inline)) {
             run_stage([&](auto i_c, half8_t a) __attribute__((always_inline)) {
                 constexpr int i = decltype(i_c)::value;
                 out[i & 15] = mfma32x32x16(a, hp[i >> 4], out[i & 15]);
-                if (decltype(with_swiglu)::value && (i & 1) == 0) swiglu_elem(hn, i >> 1);
+                if (decltype(with_swiglu)::value) {
+                    if (i < 16) sw_pack(i);
+                    else sw_part(hn, i - 16);
+                }
             });
         };
         // slab 0: FC1, SwiGLU alone
-        fc1_slab();
+        fc1_slab(ha, std::false_type{});
 #pragma unroll
-        for (int r = 0; r < 16; ++r) swiglu_elem(ha, r);
-        // slabs 1 .. NJ-1 in pairs (static fragment registers): odd slab -> hb, even slab -> ha
+        for (int r = 0; r < 16; ++r) sw_pack(r);
+#pragma unroll
+        for (int n = 0; n < 48; ++n) sw_part(ha, n);
+        fc1_slab(ha, std::false_type{});
+        // invariant: ay / ag = FC1 of slab j (odd), ha = SwiGLU of slab j - 1
         for (int j = 1; j + 1 < NJ; j += 2) {
-            fc1_slab();
-            fc2_stage(ha, hb, std::true_type{});
-            fc1_slab();
-            fc2_stage(hb, ha, std::true_type{});
+            if (j == 9) TL_STAMP(8);
+            fc2_stage(ha, hb, std::true_type{});      // FC2 of slab j - 1
+            if (j == 9) TL_STAMP(9);
+            fc1_slab(hb, std::true_type{});           // FC1 of slab j + 1
+            if (j == 9) TL_STAMP(10);
+            fc2_stage(hb, ha, std::true_type{});      // FC2 of slab j
+            if (j == 9) TL_STAMP(11);
+            fc1_slab(ha, std::true_type{});           // FC1 of slab j + 2 (the last one = the last reader of the input fragments)
+            if (j == 9) TL_STAMP(12);
         }
-        fc1_slab();                    // slab NJ-1 (odd): the last reader of the input fragments
-        fc2_stage(ha, hb, std::true_type{});       // FC2 of slab NJ-2, SwiGLU of slab NJ-1
-        fc2_stage(hb, ha, std::false_type{});      // FC2 of slab NJ-1
+        fc2_stage(ha, hb, std::true_type{});          // FC2 of slab NJ - 2, first parts of the SwiGLU of slab NJ - 1
+#pragma unroll
+        for (int n = 16; n < 48; ++n) sw_part(hb, n);
+        fc2_stage(hb, ha, std::false_type{});         // FC2 of slab NJ - 1
 
-        // residual = x1 = the rows in p.x (stored by this wave in phase A, or the launch's input in the MLP-only mode)
-        norm_rows(row0, p.n2, std::true_type{});
+        TL_STAMP(4);
+        // residual = x1 = the MLP's input fragments
+        norm_rows(row0, 1, std::true_type{}, std::false_type{});
+        TL_REPRIME_FR();
+        TL_STAMP(5);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -405,10 +520,13 @@ std::vector<half_t> tx_layer_image(const float *wo, const float *w1, const float
 bool tx_layer_supported(int d_model, int ff) { return d_model == TL_D && ff >= 128 && ff % 64 == 0; }
 
 // mode: 3 whole layer tail, 1 out-proj + norm 1 only, 2 MLP + norm 2 only (tests).  0 = launched, 1 = shape not covered.
+static unsigned long long *g_tl_trace = nullptr;   // test hook (mibc_debug_txlayer_trace)
+extern "C" void mibc_debug_txlayer_trace(unsigned long long *dev_buf) { g_tl_trace = dev_buf; }
+
 extern "C" int mibc_launch_tx_layer(hipStream_t s, const half_t *attn, half_t *x, const half_t *wimg, const float *bo,
                                     const float *n1, const float *n2, float alpha, long R, int FF, int mode) {
     if (!tx_layer_supported(TL_D, FF) || R <= 0) return 1;
-    TxLayerArgs a{attn, x, wimg, bo, n1, n2, alpha, R, FF};
+    TxLayerArgs a{attn, x, wimg, bo, n1, n2, alpha, R, FF, g_tl_trace};
     const int dbg = mode >> 8;
     mode &= 0xff;
     const long ntiles = (R + 127) / 128;
@@ -419,17 +537,17 @@ extern "C" int mibc_launch_tx_layer(hipStream_t s, const half_t *attn, half_t *x
         MIBC_LDS_ATTR_ONCE((tx_layer_kernel<M_>), TL_LDS_BYTES);                                        \
         hipLaunchKernelGGL((tx_layer_kernel<M_>), dim3((unsigned)grid), dim3(256), TL_LDS_BYTES, s, a); \
     } while (0)
-#define TL_LAUNCH_DBG(D_)                                                                                  \
+#define TL_LAUNCH_DBG(M_, D_)                                                                              \
     do {                                                                                                   \
-        MIBC_LDS_ATTR_ONCE((tx_layer_kernel<2, D_>), TL_LDS_BYTES);                                        \
-        hipLaunchKernelGGL((tx_layer_kernel<2, D_>), dim3((unsigned)grid), dim3(256), TL_LDS_BYTES, s, a); \
+        MIBC_LDS_ATTR_ONCE((tx_layer_kernel<M_, D_>), TL_LDS_BYTES);                                        \
+        hipLaunchKernelGGL((tx_layer_kernel<M_, D_>), dim3((unsigned)grid), dim3(256), TL_LDS_BYTES, s, a); \
         return 0;                                                                                          \
     } while (0)
-    if (mode == 2 && dbg == 1) TL_LAUNCH_DBG(1);
-    if (mode == 2 && dbg == 2) TL_LAUNCH_DBG(2);
-    if (mode == 2 && dbg == 4) TL_LAUNCH_DBG(4);
-    if (mode == 2 && dbg == 12) TL_LAUNCH_DBG(12);
-    if (mode == 2 && dbg == 14) TL_LAUNCH_DBG(14);
+    if (mode == 2 && dbg == 1) TL_LAUNCH_DBG(2, 1);
+    if (mode == 2 && dbg == 2) TL_LAUNCH_DBG(2, 2);
+    if (mode == 2 && dbg == 64) TL_LAUNCH_DBG(2, 64);
+    if (mode == 2 && dbg == 66) TL_LAUNCH_DBG(2, 66);
+    if (mode == 3 && dbg == 64) TL_LAUNCH_DBG(3, 64);
     if (dbg != 0) return 1;
 #undef TL_LAUNCH_DBG
     if (mode == 1) TL_LAUNCH(1);

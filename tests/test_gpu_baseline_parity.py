@@ -161,7 +161,7 @@ def test_baseline_size_vs_reference(name):
     assert q_off <= 1, f"qstring off by {q_off}"
     assert e_ref[1] <= tol_ref[0] and e_ref[0] <= tol_ref[1], f"scores vs reference: {e_ref}"
     assert e_f16[1] <= tol_f16[0] and e_f16[0] <= tol_f16[1], f"scores vs f16 emulation: {e_f16}"
-    # quantisation of the dense fixture (int16 fixed point) adds <= 1.3e-4
+    # quantisation of the dense fixture (int16 fixed point) adds <= 1.6e-4
     assert ed_ref[1] <= tol_ref[0] and ed_ref[0] <= tol_ref[1] + 2e-4, f"dense scores vs reference: {ed_ref}"
     assert ed_f16[1] <= tol_f16[0] and ed_f16[0] <= tol_f16[1] + 2e-4, f"dense scores vs f16 emulation: {ed_f16}"
     assert ct == 0 or cg / ct >= 0.999, f"identity on the reference's confident bases (q >= {qmin}): {cg} / {ct}"
