@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     issue_stage();
     boundary();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) issue_piece(q);     // the other four go out behind the first four MFMAs
+    for (int q = 0; q < TL_FD; ++q) issue_piece(q);     // the others go out behind the first MFMAs of the first stage
     fcur = fnext;
 #pragma unroll
     for (int i = 0; i < TL_FD; ++i) fr[i] = fcur[i * 64];
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
         // ---- phase B: gated MLP, slabs of 32 hidden units ----
         float16_t ay, ag;
-        half8_t ha[2], hb[2];
+        half8_t hh[2];
         // SwiGLU of a slab (nn/TxModules.cpp:171-175 on the f16-rounded FC1 outputs) -> FC2 B fragments.  One wave per SIMD
         // issues in order, and an MFMA's shadow holds about 28 cycles of other work; a SwiGLU element costs about 60 (v_exp and
         // v_rcp are quarter rate).  The sixteen elements of a slab are therefore cut into 48 parts and spread over the 96 MFMA
@@ -432,29 +432,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             });
         };
+        // One fragment buffer hh is enough: the FC2 stage of slab j - 1 reads hh[0] behind its first sixteen MFMAs and hh[1]
+        // behind the others, and the first SwiGLU parts of slab j that complete there (elements 0-4, all in hh[0]) start at
+        // MFMA sixteen; the remaining elements complete during FC1 of slab j + 1, after the stage.
         // slab 0: FC1, SwiGLU alone
-        fc1_slab(ha, std::false_type{});
+        fc1_slab(hh, std::false_type{});
 #pragma unroll
         for (int r = 0; r < 16; ++r) sw_pack(r);
 #pragma unroll
-        for (int n = 0; n < 48; ++n) sw_part(ha, n);
-        fc1_slab(ha, std::false_type{});
-        // invariant: ay / ag = FC1 of slab j (odd), ha = SwiGLU of slab j - 1
-        for (int j = 1; j + 1 < NJ; j += 2) {
+        for (int n = 0; n < 48; ++n) sw_part(hh, n);
+        fc1_slab(hh, std::false_type{});
+        // invariant: ay / ag = FC1 of slab j, hh = SwiGLU of slab j - 1
+        for (int j = 1; j + 1 < NJ; ++j) {
             if (j == 9) TL_STAMP(8);
-            fc2_stage(ha, hb, std::true_type{});      // FC2 of slab j - 1
+            fc2_stage(hh, hh, std::true_type{});      // FC2 of slab j - 1
             if (j == 9) TL_STAMP(9);
-            fc1_slab(hb, std::true_type{});           // FC1 of slab j + 1
+            fc1_slab(hh, std::true_type{});           // FC1 of slab j + 1 (the last one = the last reader of the input fragments)
             if (j == 9) TL_STAMP(10);
-            fc2_stage(hb, ha, std::true_type{});      // FC2 of slab j
-            if (j == 9) TL_STAMP(11);
-            fc1_slab(ha, std::true_type{});           // FC1 of slab j + 2 (the last one = the last reader of the input fragments)
-            if (j == 9) TL_STAMP(12);
         }
-        fc2_stage(ha, hb, std::true_type{});          // FC2 of slab NJ - 2, first parts of the SwiGLU of slab NJ - 1
+        fc2_stage(hh, hh, std::true_type{});          // FC2 of slab NJ - 2, first parts of the SwiGLU of slab NJ - 1
 #pragma unroll
-        for (int n = 16; n < 48; ++n) sw_part(hb, n);
-        fc2_stage(hb, ha, std::false_type{});         // FC2 of slab NJ - 1
+        for (int n = 16; n < 48; ++n) sw_part(hh, n);
+        fc2_stage(hh, hh, std::false_type{});         // FC2 of slab NJ - 1
 
         TL_STAMP(4);
         // residual = x1 = the MLP's input fragments

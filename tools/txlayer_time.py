@@ -29,5 +29,5 @@ for mode in [int(a, 0) for a in sys.argv[2:]] or [3, 3 | 0x4000, 1, 2, 2 | 0x200
     hip.hipMemcpy(st.ctypes.data_as(C.c_void_p), dbuf, 128, 2)
     d = [int(st[i + 1]) - int(st[i]) if st[i + 1] and st[i] else None for i in range(5)]
     print("   cycle stamps (tile 1 of workgroup 0): out-proj", d[0], " norm 1", d[1], " fragment ring", d[2], " MLP", d[3] if d[3] else (int(st[4]) - int(st[0]) if st[4] else None), " norm 2", d[4])
-    print("   slab pair 9: fc2", int(st[9]) - int(st[8]), " fc1", int(st[10]) - int(st[9]), " fc2", int(st[11]) - int(st[10]), " fc1", int(st[12]) - int(st[11]))
+    print("   slab 9: fc2 stage", int(st[9]) - int(st[8]), " fc1 (2 stages)", int(st[10]) - int(st[9]))
     print(f"mode {mode & 0xff} dbg {mode >> 8}: rc {rc} fused {f[3].value:.3f} ms ({fl / f[3].value / 1e9:.0f} TF)  five launches {f[4].value:.3f} ms  maxdiff {f[0].value:.4f}")
