@@ -220,12 +220,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("" : "+v"(vq));     // opaque per call: offsets stay immediates
         LDSP(const unsigned char) wrow = side + which * 2048 + 16 * (vq & 8 ? 1 : 0);
         constexpr bool RAW = (MODE & 4) != 0;     // test decomposition: the raw GEMM result (no residual, no norm)
-        tl_u2 rq[decltype(from_xf)::value || RAW ? 1 : 64];
-        if (!decltype(from_xf)::value && !RAW) {
+        // residual rows from memory: in fragment form (16 bytes per lane, 32 contiguous bytes per row and instruction — the
+        // 8-byte quad gathers cost 13 k cycles more per 32 rows), turned into quads by the same swap as the from_xf path
+        constexpr bool FROM_MEM = !decltype(from_xf)::value && !RAW;
+        tl_u4 rf[FROM_MEM ? 32 : 1];
+        if (FROM_MEM) {
+            int vf = voff_frag;
+            asm volatile("" : "+v"(vf));
 #pragma unroll
-            for (int c = 0; c < 16; ++c)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rq[4 * c + q] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, vq + 64 * c + 16 * q, soff0, 0);
+            for (int ks = 0; ks < 32; ++ks) rf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vf + 32 * ks, soff0, 0);
         }
         float ss = 0.0f;
         if (!RAW) {
@@ -234,14 +237,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     tl_u2 ra, rb;
-                    if (decltype(from_xf)::value) {
-                        const tl_u4 f = __builtin_bit_cast(tl_u4, xf[2 * c + m]);
+                    {
+                        const tl_u4 f = FROM_MEM ? rf[FROM_MEM ? 2 * c + m : 0] : __builtin_bit_cast(tl_u4, xf[2 * c + m]);
                         const auto s0 = __builtin_amdgcn_permlane32_swap(f[0], f[2], false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(f[1], f[3], false, false);
                         ra[0] = s0[0]; ra[1] = s1[0]; rb[0] = s0[1]; rb[1] = s1[1];
-                    } else {
-                        ra = rq[4 * c + 2 * m];
-                        rb = rq[4 * c + 2 * m + 1];
                     }
                     const half4_t ha4 = __builtin_bit_cast(half4_t, ra), hb4 = __builtin_bit_cast(half4_t, rb);
 #pragma unroll
@@ -260,6 +260,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // 8-byte stores: with 16-byte (fragment-form) stores the results were wrong in rows 12-15 / 28-31 of every tile — the
         // swap below writes BOTH its operands, and a register that still is the data of a > 8-byte store in flight must not
         // be written for a wait state hipcc does not insert for the swap's source operand
+        float4_t wa_n = {0, 0, 0, 0}, wb_n = {0, 0, 0, 0};
+        if (!RAW) {
+            wa_n = *(LDSP(const float4_t))(wrow);
+            wb_n = *(LDSP(const float4_t))(wrow + 32);
+        }
 #pragma unroll
         for (int c = 0; c < 16; ++c)
 #pragma unroll
@@ -272,8 +277,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         yb[e] = (half_t)out[c][8 * m + 4 + e];
                     }
                 } else {
-                    const float4_t wa = *(LDSP(const float4_t))(wrow + 128 * c + 64 * m);
-                    const float4_t wb = *(LDSP(const float4_t))(wrow + 128 * c + 64 * m + 32);
+                    const float4_t wa = wa_n, wb = wb_n;
+                    if (2 * c + m + 1 < 32) {      // the next pair's norm weights: one pair ahead of their use
+                        wa_n = *(LDSP(const float4_t))(wrow + 64 * (2 * c + m + 1));
+                        wb_n = *(LDSP(const float4_t))(wrow + 64 * (2 * c + m + 1) + 32);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         ya[e] = (half_t)((out[c][8 * m + e] * rstd) * wa[e]);
