@@ -233,3 +233,27 @@ def test_fused_layer_kernel_has_no_unpadded_asm_mfma_hazard():
     product = [l for l in out.stdout.splitlines() if "tx_layer_kernelILi3ELi0E" in l]
     assert not product, "\n".join(product)
     assert "VALU -> asm-MFMA operand hazards" in out.stdout, out.stdout + out.stderr
+
+
+def test_asm_hazard_checker_detects_and_clears(tmp_path):
+    """The gate itself: a VALU write one / two states in front of an asm MFMA that reads the register is reported, three
+    states (or an s_nop 1 in between) is not; loads and builtin (non-asm) MFMAs are not its business."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_asm_hazards", os.path.join(ROOT, "tools", "check_asm_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def listing(body):
+        p = tmp_path / "k.s"
+        p.write_text("_Z1kv:\n" + body)
+        return mod.scan(str(p))
+
+    mf = "\t;;#ASMSTART\n\tv_mfma_f32_32x32x16_f16 v[0:15], v[20:23], v[24:27], v[0:15]\n\t;;#ASMEND\n"
+    assert len(listing("\tv_mov_b32_e32 v21, v40\n" + mf)) == 1                       # one state
+    assert len(listing("\tv_accvgpr_read_b32 v24, a3\n\ts_add_i32 s1, s1, 1\n" + mf)) == 1   # two states
+    assert len(listing("\tv_permlane32_swap_b32_e32 v50, v26\n" + mf)) == 1           # the swap writes its source too
+    assert listing("\tv_mov_b32_e32 v21, v40\n\ts_nop 1\n" + mf) == []              # padded
+    assert listing("\tv_mov_b32_e32 v21, v40\n\ts_add_i32 s1, s1, 1\n\ts_add_i32 s2, s2, 1\n" + mf) == []
+    assert listing("\tv_mov_b32_e32 v99, v40\n" + mf) == []                           # unrelated register
+    assert listing("\tds_read_b128 v[20:23], v60\n\ts_waitcnt lgkmcnt(0)\n" + mf) == []   # a load, waited for
+    assert listing("\tv_mov_b32_e32 v21, v40\n\tv_mfma_f32_32x32x16_f16 a[0:15], v[20:23], v[24:27], a[0:15]\n") == []

@@ -53,6 +53,8 @@ def scan(path):
         wr = set()
         if op.startswith('v_') and not op.startswith('v_mfma') and not op.startswith('v_cmp'):
             wr = regs(args[0]) if args else set()
+            if op.startswith('v_permlane') and 'swap' in op and len(args) > 1:
+                wr |= regs(args[1])       # the swaps write both operands
         if op == 's_nop':
             k = int(args[0]) + 1 if args and args[0].isdigit() else 1
             recent += [("s_nop", set())] * k
