@@ -16,8 +16,16 @@ struct Roctx {
     int (*push)(const char *) = nullptr;
     int (*pop)() = nullptr;
     Roctx() {
-        void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        // whatever the process already carries first (a profiler may preload its own), then rocprofv3's implementation
+        // (rocprofiler-sdk: the only one its --marker-trace records), then roctracer's
+        push = (int (*)(const char *))dlsym(RTLD_DEFAULT, "roctxRangePushA");
+        pop = (int (*)())dlsym(RTLD_DEFAULT, "roctxRangePop");
+        if (push && pop) return;
+        void *h = nullptr;
+        for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
         if (h) {
             push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
             pop = (int (*)())dlsym(h, "roctxRangePop");

@@ -17,6 +17,7 @@ ap.add_argument("--batch", type=int, default=16384)
 ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--model", default="hac")
 ap.add_argument("--tin", type=int, default=0)
+ap.add_argument("--profile-level", type=int, default=1, help="2 = also roctx ranges around the stages (rocprofv3 --marker-trace)")
 ap.add_argument("--lib", default="", help="'dbg' = dorado_amd/libmibc_dbg.so (make -C dorado_amd/csrc debug): MIBC_* switches")
 a = ap.parse_args()
 if a.lib == "dbg":
@@ -32,7 +33,7 @@ x = np.tile(base, ((n + base.shape[0] - 1) // base.shape[0], 1))[:n]
 d_in = eng.device_alloc(x.nbytes)
 d_out = eng.device_alloc(3 * n * T)
 eng.h2d(d_in, x)
-eng.set_profile(1)
+eng.set_profile(a.profile_level)
 res = None
 for _ in range(a.steps):
     eng.call_device(d_in, n, t_in, d_out)
