@@ -53,6 +53,14 @@
 #define TL_OFF_SIDE (TL_NS * TL_STAGE_BYTES)           // 4 waves x 8 KB
 #define TL_LDS_BYTES (TL_OFF_SIDE + 4 * 8192)
 #define TL_D 512
+#ifndef TL_NORM_STORE16
+#define TL_NORM_STORE16 0            // 1 = the norms store 16-byte fragments (experimental, see norm_rows)
+#endif
+#ifndef TL_SWAP_STORE_NOPS
+#define TL_SWAP_STORE_NOPS 7
+#endif
+#define TL_STR2(x) #x
+#define TL_STR(x) TL_STR2(x)
 #define TL_FD 4                      // fragment look-ahead in MFMAs (8 x 32 cycles of LDS latency cover)
 
 // FC1's two accumulator tiles must live in VGPRs: the 16 tiles of the FC2 / out-proj result fill the AGPR half of the
@@ -257,6 +265,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             ss += __shfl_xor(ss, 32, 64);
         }
         const float rstd = rsqrtf(ss / (float)TL_D + 1e-5f);
+#if TL_NORM_STORE16
+        int voff_frag_o = voff_frag;
+        asm volatile("" : "+v"(voff_frag_o));
+        constexpr int TL_HOLD = 4;
+        tl_u4 hold[TL_HOLD];
+#endif
         // 8-byte stores: with 16-byte (fragment-form) stores the results were wrong in rows 12-15 / 28-31 of every tile — the
         // swap below writes BOTH its operands, and a register that still is the data of a > 8-byte store in flight must not
         // be written for a wait state hipcc does not insert for the swap's source operand
@@ -289,6 +303,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 }
                 const tl_u2 ua = __builtin_bit_cast(tl_u2, ya), ub = __builtin_bit_cast(tl_u2, yb);
+#if TL_NORM_STORE16
+                {
+                    unsigned a0 = ua[0], a1 = ua[1], b0 = ub[0], b1 = ub[1];
+                    asm volatile("s_nop " TL_STR(TL_SWAP_STORE_NOPS) : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    unsigned f0 = s0[0], f1 = s1[0], f2 = s0[1], f3 = s1[1];
+                    // wait states between the swaps and the store that reads their results as data (see TL_NORM_STORE16)
+                    asm volatile("s_nop " TL_STR(TL_SWAP_STORE_NOPS) : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3));
+                    tl_u4 f;
+                    f[0] = f0; f[1] = f1; f[2] = f2; f[3] = f3;
+                    __builtin_amdgcn_raw_buffer_store_b128(f, rs_x, voff_frag_o + 32 * (2 * c + m), soff0, 0);
+                    if (decltype(to_xf)::value) xf[2 * c + m] = __builtin_bit_cast(half8_t, f);
+                    // keep the data registers of the last TL_HOLD stores allocated (nothing may overwrite them yet)
+                    if (2 * c + m >= TL_HOLD) asm volatile("" :: "v"(hold[(2 * c + m) % TL_HOLD]));
+                    hold[(2 * c + m) % TL_HOLD] = f;
+                }
+#else
                 __builtin_amdgcn_raw_buffer_store_b64(ua, rs_x, vq + 64 * c + 32 * m, soff0, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(ub, rs_x, vq + 64 * c + 32 * m + 16, soff0, 0);
                 if (decltype(to_xf)::value) {
@@ -298,6 +330,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     f[0] = s0[0]; f[1] = s1[0]; f[2] = s0[1]; f[3] = s1[1];
                     xf[2 * c + m] = __builtin_bit_cast(half8_t, f);
                 }
+#endif
             }
     };
     // this wave's 32 token rows as B fragments; fresh: rows this wave stored earlier in the launch (after a vmcnt(0))
