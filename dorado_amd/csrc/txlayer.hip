@@ -268,8 +268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #if TL_NORM_STORE16
         int voff_frag_o = voff_frag;
         asm volatile("" : "+v"(voff_frag_o));
-        constexpr int TL_HOLD = 4;
-        tl_u4 hold[TL_HOLD];
+        tl_u4 hold[32];
 #endif
         // 8-byte stores: with 16-byte (fragment-form) stores the results were wrong in rows 12-15 / 28-31 of every tile — the
         // swap below writes BOTH its operands, and a register that still is the data of a > 8-byte store in flight must not
@@ -306,19 +305,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #if TL_NORM_STORE16
                 {
                     unsigned a0 = ua[0], a1 = ua[1], b0 = ub[0], b1 = ub[1];
-                    asm volatile("s_nop " TL_STR(TL_SWAP_STORE_NOPS) : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
                     const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
                     const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                     unsigned f0 = s0[0], f1 = s1[0], f2 = s0[1], f3 = s1[1];
-                    // wait states between the swaps and the store that reads their results as data (see TL_NORM_STORE16)
-                    asm volatile("s_nop " TL_STR(TL_SWAP_STORE_NOPS) : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3));
                     tl_u4 f;
                     f[0] = f0; f[1] = f1; f[2] = f2; f[3] = f3;
                     __builtin_amdgcn_raw_buffer_store_b128(f, rs_x, voff_frag_o + 32 * (2 * c + m), soff0, 0);
                     if (decltype(to_xf)::value) xf[2 * c + m] = __builtin_bit_cast(half8_t, f);
-                    // keep the data registers of the last TL_HOLD stores allocated (nothing may overwrite them yet)
-                    if (2 * c + m >= TL_HOLD) asm volatile("" :: "v"(hold[(2 * c + m) % TL_HOLD]));
-                    hold[(2 * c + m) % TL_HOLD] = f;
+                    hold[2 * c + m] = f;     // see below: nothing may overwrite a store's data registers before the store is done
                 }
 #else
                 __builtin_amdgcn_raw_buffer_store_b64(ua, rs_x, vq + 64 * c + 32 * m, soff0, 0);
@@ -332,6 +326,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
 #endif
             }
+#if TL_NORM_STORE16
+        // Correct by construction: every store's data registers stay allocated (hold[], or xf[] when the fragments are the
+        // MLP's input) until all stores of the epilogue have completed — v_permlane32_swap writes both its operands and
+        // nothing holds such a write back while a > 8-byte store still has to read its data.
+        if (!decltype(to_xf)::value) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 32; k += 4) asm volatile("" :: "v"(hold[k]), "v"(hold[k + 1]), "v"(hold[k + 2]), "v"(hold[k + 3]));
+        }
+#endif
     };
     // this wave's 32 token rows as B fragments; fresh: rows this wave stored earlier in the launch (after a vmcnt(0))
     auto load_frags = [&](__amdgpu_buffer_rsrc_t rs, long row0, auto fresh) __attribute__((always_inline)) {
