@@ -47,7 +47,7 @@ EXPORTS = [
     "mibc_reserve", "mibc_output_steps", "mibc_batch_granularity", "mibc_host_alloc",
     "mibc_host_free", "mibc_device_alloc", "mibc_device_free", "mibc_memcpy_h2d",
     "mibc_memcpy_d2h", "mibc_forward", "mibc_decode", "mibc_call_device", "mibc_call",
-    "mibc_sync", "mibc_time_forward", "mibc_get_stage_ms", "mibc_set_profile", "mibc_debug_tap",
+    "mibc_sync", "mibc_quantize_lstm_weights", "mibc_time_forward", "mibc_get_stage_ms", "mibc_set_profile", "mibc_debug_tap",
     "mibc_forward_i16", "mibc_call_device_i16", "mibc_call_i16", "mibc_scaler_stats", "mibc_scale_reads",
     "mibc_svb16_decode", "mibc_forward_var", "mibc_call_device_var", "mibc_call_var",
     "mibc_call_async", "mibc_call_wait", "mibc_call_poll",
@@ -108,6 +108,7 @@ def lib():
         L.mibc_time_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.mibc_get_stage_ms.argtypes = [C.c_void_p, C.POINTER(StageMsC)]
         L.mibc_set_profile.argtypes = [C.c_void_p, C.c_int]
+        L.mibc_quantize_lstm_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.mibc_debug_tap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.mibc_forward_i16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.mibc_call_device_i16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -528,3 +529,17 @@ def unpack_planes(out3: np.ndarray):
         res.append((seq[i, :nb].tobytes().decode("ascii"), qs[i, :nb].tobytes().decode("ascii"),
                     moves[i].astype(np.uint8)))
     return res
+
+
+def quantize_lstm_weights(w_ih: np.ndarray, w_hh: np.ndarray):
+    """Host-only: the lstm_quant weight quantisation (mibc_quantize_lstm_weights) -> (int8 [4C][2C], f32 scale [4C])."""
+    C4, Cc = w_ih.shape
+    assert C4 == 4 * Cc and w_hh.shape == (C4, Cc)
+    a = np.ascontiguousarray(w_ih, np.float32)
+    b = np.ascontiguousarray(w_hh, np.float32)
+    q = np.zeros((C4, 2 * Cc), np.int8)
+    sc = np.zeros(C4, np.float32)
+    rc = lib().mibc_quantize_lstm_weights(a.ctypes.data, b.ctypes.data, Cc, q.ctypes.data, sc.ctypes.data)
+    if rc != 0:
+        raise MibcError(f"mibc_quantize_lstm_weights: status {rc}")
+    return q, sc

@@ -37,6 +37,30 @@ Roctx &roctx() {
     return r;
 }
 }  // namespace
+// utils::quantize_tensor(cat(W_ih, W_hh, 1).half(), 1) (torch_utils/tensor_utils.cpp:293-300 as called by
+// nn/LSTMStack.cpp:160-168), with the reference's arithmetic: everything happens on f16 tensors, i.e. every elementwise
+// result is rounded to f16 — scale = f16(128 / max|row|), q = clip(round_half_even(f16(w * scale)), +-127).  Host only (no
+// device needed): pinned bit for bit against the compiled reference in tests/test_oracle_pinned.py.
+extern "C" int mibc_quantize_lstm_weights(const float *wih, const float *whh, int C, int8_t *q, float *scale) {
+    if (!wih || !whh || !q || !scale || C <= 0) return MIBC_ERR_ARG;
+    for (int row = 0; row < 4 * C; ++row) {
+        float amax = 0.0f;
+        for (int k = 0; k < C; ++k) {
+            amax = fmaxf(amax, fabsf((float)(half_t)wih[(size_t)row * C + k]));
+            amax = fmaxf(amax, fabsf((float)(half_t)whh[(size_t)row * C + k]));
+        }
+        const float s = amax > 0.0f ? (float)(half_t)(128.0f / amax) : 1.0f;
+        scale[row] = s;
+        for (int k = 0; k < 2 * C; ++k) {
+            const float w = (float)(half_t)((k < C) ? wih[(size_t)row * C + k] : whh[(size_t)row * C + (k - C)]);
+            float v = nearbyintf((float)(half_t)(w * s));
+            v = fminf(127.0f, fmaxf(-127.0f, v));
+            q[(size_t)row * 2 * C + k] = (int8_t)v;
+        }
+    }
+    return MIBC_OK;
+}
+
 MibcRange::MibcRange(const mibc_engine *e, const char *name) : on(false) {
     if (e && e->profile >= 2 && roctx().push && roctx().pop) {
         (void)roctx().push(name);
@@ -272,14 +296,8 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
             // per output row scale = 128 / max|row|, round to nearest even, clip +-127
             const int KS64 = 2 * C / 64;
             std::vector<float> scale((size_t)4 * C);
-            for (int row = 0; row < 4 * C; ++row) {
-                float amax = 0.0f;
-                for (int k = 0; k < C; ++k) {
-                    amax = fmaxf(amax, fabsf((float)(half_t)Wih[(size_t)row * C + k]));
-                    amax = fmaxf(amax, fabsf((float)(half_t)Whh[(size_t)row * C + k]));
-                }
-                scale[row] = amax > 0.0f ? 128.0f / amax : 1.0f;
-            }
+            std::vector<int8_t> qrow((size_t)4 * C * 2 * C);      // [4C][2C], k < C: W_ih, else W_hh
+            mibc_quantize_lstm_weights(Wih, Whh, C, qrow.data(), scale.data());
             std::vector<int8_t> wq((size_t)4 * C * 2 * C);
             for (int j = 0; j < C / 16; ++j)
                 for (int ks = 0; ks < KS64; ++ks)
@@ -288,10 +306,7 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
                             for (int i = 0; i < 16; ++i) {
                                 const int row = g * C + 16 * j + (lane & 15);
                                 const int k = ks * 64 + 16 * (lane >> 4) + i;
-                                const float w = (float)(half_t)((k < C) ? Wih[(size_t)row * C + k] : Whh[(size_t)row * C + (k - C)]);
-                                float q = nearbyintf(w * scale[row]);
-                                q = fminf(127.0f, fmaxf(-127.0f, q));
-                                wq[((((size_t)j * KS64 + ks) * 4 + g) * 64 + lane) * 16 + i] = (int8_t)q;
+                                wq[((((size_t)j * KS64 + ks) * 4 + g) * 64 + lane) * 16 + i] = qrow[(size_t)row * 2 * C + k];
                             }
             std::vector<float> deq((size_t)4 * C);
             for (int j = 0; j < C / 32; ++j)

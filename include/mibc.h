@@ -96,6 +96,10 @@ int mibc_query_memory(const mibc_engine *e, int T_in, size_t *bytes_per_chunk, s
 int mibc_reserve(mibc_engine *e, int N_max, int T_in); /* (re)allocates the device workspace */
 int mibc_output_steps(const mibc_engine *e, int T_in); /* T = number of output steps */
 int mibc_batch_granularity(const mibc_engine *e);      /* N must be a multiple of this */
+/* The weight quantisation of the lstm_quant path, host only (no device): utils::quantize_tensor(cat(W_ih, W_hh, 1).half(), 1)
+ * (torch_utils/tensor_utils.cpp:293-300 as called by nn/LSTMStack.cpp:160-168), bit for bit — f16 arithmetic included.
+ * wih, whh: [4C][C] f32 (module.parameters() layout); q: [4C][2C] int8 (columns < C from W_ih); scale: [4C]. */
+int mibc_quantize_lstm_weights(const float *wih, const float *whh, int C, int8_t *q, float *scale);
 
 void *mibc_host_alloc(size_t bytes); /* pinned host memory (CudaCaller.cpp:289-314) */
 void mibc_host_free(void *p);

@@ -339,6 +339,23 @@ int ref_med_mad_expr(const int16_t *x, long n, float *med_out, float *mad_out) {
     }
 }
 
+// utils::quantize_tensor(t, 1) (tensor_utils.cpp:293-300) exactly as LSTMStack.cpp:160-168 calls it: on the f16 copy of
+// the [rows][cols] weight matrix.  q = int8 values, scale = the per-row float scales.
+int ref_quantize_tensor_f16_rows(const float *w, int rows, int cols, int8_t *q, float *scale) {
+    try {
+        auto t = at::from_blob(const_cast<float *>(w), {rows, cols}, at::kFloat).clone().to(at::kHalf);
+        auto st = utils::quantize_tensor(t, 1);
+        auto qt = st.t.contiguous();
+        auto sc = st.scale.contiguous();
+        std::memcpy(q, qt.data_ptr(), size_t(rows) * size_t(cols));
+        std::memcpy(scale, sc.data_ptr(), size_t(rows) * sizeof(float));
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 // The input signal of tests/TrimTest.cpp:31-42 ("Test trim signal"): mt19937{42}, N(0,1), +5 on [1,55).
 void ref_trimtest_signal(float *out, int n) {
     std::mt19937 gen{42};

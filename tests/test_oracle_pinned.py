@@ -263,3 +263,44 @@ def test_dense_baseline_fixture_consistent_with_sampled_fixture(golden_dir, name
     e = (d["f16_q"].astype(np.float64) - d["ref_q"]) / scale
     rms = float(np.sqrt((e ** 2).mean()))
     assert abs(rms - float(g["f16_vs_ref_rms"])) <= 0.25 * float(g["f16_vs_ref_rms"]), (rms, float(g["f16_vs_ref_rms"]))
+
+
+# ---------------------------------------------------------------- lstm_quant weight quantisation (host only)
+def _quant_case():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_quant", os.path.join(os.path.dirname(__file__), "golden", "make_golden_quant.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_lstm_weight_quantisation_equals_reference_fixture(golden_dir):
+    """mibc_quantize_lstm_weights == utils::quantize_tensor on the f16 weights (tensor_utils.cpp:293-300, LSTMStack.cpp:160-168):
+    int8 values and per-row scales bit for bit, incl. rows with an outlier, tiny rows and products that land on k + 0.5
+    (round half to even).  Fixture made by the compiled reference (tests/golden/make_golden_quant.py)."""
+    import zlib
+    from dorado_amd import capi
+    mod = _quant_case()
+    g = np.load(os.path.join(golden_dir, "lstm_quant.npz"))
+    w_ih, w_hh = mod.weights(int(g["seed"]), int(g["C"]))
+    assert zlib.crc32(w_ih.tobytes() + w_hh.tobytes()) == int(g["crc_w"])
+    q, sc = capi.quantize_lstm_weights(w_ih, w_hh)
+    assert np.isfinite(sc).all()
+    assert (sc == g["scale"]).all()
+    assert (q == g["q"]).all(), int((q != g["q"]).sum())
+    assert q[2, :8].tolist() == [0, 2, 2, 0, -2, 64, 0, 64]       # products 0.5 1.5 2.5 -0.5 -1.5 64 0 63.5: half to even
+    assert np.abs(q).max() == 127
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_lstm_weight_quantisation_live_against_compiled_reference():
+    from dorado_amd import capi
+    mod = _quant_case()
+    for seed, c in ((1, 128), (2, 384), (3, 64)):
+        rng = np.random.default_rng(seed)
+        w_ih = (rng.standard_normal((4 * c, c)) * rng.uniform(0.05, 0.6)).astype(np.float32)
+        w_hh = (rng.standard_normal((4 * c, c)) * rng.uniform(0.05, 0.6)).astype(np.float32)
+        q, sc = capi.quantize_lstm_weights(w_ih, w_hh)
+        qr, scr = mod.ref_quantize(w_ih, w_hh)
+        assert (sc == scr).all()
+        assert (q == qr).all(), int((q != qr).sum())
