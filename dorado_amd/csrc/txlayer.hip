@@ -561,6 +561,17 @@ std::vector<half_t> tx_layer_image(const float *wo, const float *w1, const float
     return img;
 }
 
+// test hook (host only): the image as f16 bit patterns; returns the number of halfs (or that number alone if out == nullptr)
+extern "C" long mibc_debug_tx_layer_image(const float *wo, const float *w1, const float *w2, int FF, uint16_t *out, long cap) {
+    if (FF < 64 || FF % 64 != 0) return -1;
+    const std::vector<half_t> img = tx_layer_image(wo, w1, w2, FF);
+    if (out) {
+        if ((long)img.size() > cap) return -2;
+        memcpy(out, img.data(), img.size() * sizeof(half_t));
+    }
+    return (long)img.size();
+}
+
 bool tx_layer_supported(int d_model, int ff) { return d_model == TL_D && ff >= 128 && ff % 64 == 0; }
 
 // mode: 3 whole layer tail, 1 out-proj + norm 1 only, 2 MLP + norm 2 only (tests).  0 = launched, 1 = shape not covered.

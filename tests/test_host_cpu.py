@@ -257,3 +257,44 @@ def test_asm_hazard_checker_detects_and_clears(tmp_path):
     assert listing("\tv_mov_b32_e32 v99, v40\n" + mf) == []                           # unrelated register
     assert listing("\tds_read_b128 v[20:23], v60\n\ts_waitcnt lgkmcnt(0)\n" + mf) == []   # a load, waited for
     assert listing("\tv_mov_b32_e32 v21, v40\n\tv_mfma_f32_32x32x16_f16 a[0:15], v[20:23], v[24:27], a[0:15]\n") == []
+
+
+def test_fused_layer_weight_image_layout():
+    """csrc/txlayer.hip streams one weight image per layer in consumption order (host function tx_layer_image, no device):
+    (16 + 3 FF/32) stages of 32 KB; 16 x Wo | W1(0) | W1(1) W2(0) | ... | W2(NJ-1); every weight exactly once."""
+    import ctypes as C
+    from dorado_amd import capi
+    L = capi.lib()
+    L.mibc_debug_tx_layer_image.restype = C.c_long
+    L.mibc_debug_tx_layer_image.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+    FF, D = 256, 512
+    NJ = FF // 32
+    rng = np.random.default_rng(5)
+    wo = rng.standard_normal((D, D)).astype(np.float32)
+    w1 = rng.standard_normal((2 * FF, D)).astype(np.float32)
+    w2 = rng.standard_normal((D, FF)).astype(np.float32)
+    w1[0:32] = 7.0            # y rows of slab 0
+    w1[FF:FF + 32] = 9.0      # gate rows of slab 0
+    w2[:, FF - 32:] = 11.0    # slab NJ - 1 of W2
+    n = L.mibc_debug_tx_layer_image(wo.ctypes.data, w1.ctypes.data, w2.ctypes.data, FF, None, 0)
+    assert n == (16 + 3 * NJ) * 16384
+    img = np.zeros(n, np.uint16)
+    assert L.mibc_debug_tx_layer_image(wo.ctypes.data, w1.ctypes.data, w2.ctypes.data, FF, img.ctypes.data, n) == n
+    img = img.view(np.float16).reshape(16 + 3 * NJ, 32, 64, 8)       # [stage][fragment][lane][e]
+    want = np.sort(np.concatenate([wo.ravel(), w1.ravel(), w2.ravel()]).astype(np.float16))
+    assert (np.sort(img.ravel()) == want).all()                      # a permutation of the f16-rounded weights
+    # Wo: stage st, fragment (s, c), lane, e  ->  Wo[32 c + l31][32 st + 16 s + 8 lhi + e]
+    l = np.arange(64)
+    for st, s, c in ((0, 0, 0), (5, 1, 9), (15, 1, 15)):
+        k0 = 32 * st + 16 * s
+        ref = np.stack([wo[32 * c + (ln & 31), k0 + 8 * (ln >> 5):k0 + 8 * (ln >> 5) + 8] for ln in l])
+        assert (img[st, s * 16 + c] == ref.astype(np.float16)).all()
+    # stages 16, 17 = W1 of slab 0: fragments alternate y (7) / gate (9)
+    assert (img[16:18, 0::2] == np.float16(7.0)).all() and (img[16:18, 1::2] == np.float16(9.0)).all()
+    assert (img[18:20] != np.float16(7.0)).all()                     # stage 18, 19: W1 of slab 1
+    # W2(0) follows W1(1); the last stage is W2(NJ - 1)
+    assert (img[-1] == np.float16(11.0)).all() and (img[-2] != np.float16(11.0)).all()
+    # W2(j) fragment (s, c): k index permuted inside a 16-group: 4 lhi + (e & 3) + 8 (e >> 2)
+    j, s, c = 0, 1, 3
+    ref = np.stack([[w2[32 * c + (ln & 31), 32 * j + 16 * s + 4 * (ln >> 5) + (e & 3) + 8 * (e >> 2)] for e in range(8)] for ln in l])
+    assert (img[20, s * 16 + c] == ref.astype(np.float16)).all()     # stage 20 = W2(0)
