@@ -5,6 +5,9 @@ import sys
 sys.path.insert(0, ".")
 from dorado_amd import capi
 
+import os
+if os.environ.get("MIBC_LIB"):      # A/B of an alternative build (tools/txlayer_store16_ab.sh); a tool switch, not a product one
+    capi.LIB_PATH = os.path.abspath(os.environ["MIBC_LIB"])
 L = capi.lib()
 L.mibc_debug_txlayer_compare.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)] + \
     [C.POINTER(C.c_float)] * 5 + [C.c_void_p, C.c_void_p]
