@@ -636,6 +636,22 @@ HipModelRunner::~HipModelRunner() {
     mibc_host_free(m_ss);
 }
 
+bool HipModelRunner::place_variable_chunk(std::vector<int> &fill, int &cur_row, size_t n, size_t chunk_size, size_t gap,
+                                          int &row, int &start) {
+    const int nrows = int(fill.size());
+    row = -1;
+    for (int r = std::max(0, cur_row - 7); r <= cur_row && r < nrows; ++r)
+        if (size_t(fill[size_t(r)]) + n <= chunk_size) {
+            row = r;
+            break;
+        }
+    if (row < 0 && cur_row + 1 < nrows) row = ++cur_row;
+    if (row < 0) return false;
+    start = fill[size_t(row)];
+    fill[size_t(row)] = int(size_t(start) + n + gap);
+    return true;
+}
+
 void HipModelRunner::accept_chunk(int idx, const uint16_t *f16, size_t n) {
     if (m_mode == 2) throw std::runtime_error("accept_chunk: this batch already holds raw int16 chunks");
     if (variable_chunk_sizes()) {
@@ -646,18 +662,9 @@ void HipModelRunner::accept_chunk(int idx, const uint16_t *f16, size_t n) {
             throw std::runtime_error("accept_chunk: a variable chunk must be a stride multiple of at most chunk_size samples");
         m_mode = 1;
         if (m_var_overflow.empty()) {
-            const int nrows = int(batch_size());
-            int row = -1;
-            for (int r = std::max(0, m_var_row - 7); r <= m_var_row && r < nrows; ++r)
-                if (size_t(m_var_fill[size_t(r)]) + n <= cs) {
-                    row = r;
-                    break;
-                }
-            if (row < 0 && m_var_row + 1 < nrows) row = ++m_var_row;
-            if (row >= 0) {
-                const int start = m_var_fill[size_t(row)];
+            int row = -1, start = 0;
+            if (place_variable_chunk(m_var_fill, m_var_row, n, cs, gap, row, start)) {
                 std::memcpy(m_in + size_t(row) * cs + size_t(start), f16, n * 2);
-                m_var_fill[size_t(row)] = int(size_t(start) + n + gap);
                 m_var_table.push_back({row, start, int(n)});
                 return;
             }
@@ -1401,4 +1408,26 @@ int mibch_basecall_reads(const mibc_model_desc *desc, const float *const *weight
     }
 }
 
+
+// test hook (CPU, no device): place `n` chunk lengths (samples) with HipModelRunner's packer into `rows` batch rows of
+// `chunk_size` samples, `gap` samples between the chunks of a row; out_row / out_start per chunk (-1 = did not fit).
+int mibch_debug_pack_rows(const int *lens, int n, int rows, int chunk_size, int gap, int *out_row, int *out_start) {
+    std::vector<int> fill(size_t(rows), 0);
+    int cur = 0, placed = 0;
+    bool overflow = false;
+    for (int i = 0; i < n; ++i) {
+        int row = -1, start = 0;
+        // as in accept_chunk: once one chunk has overflowed, everything behind it follows it (result order)
+        if (!overflow && HipModelRunner::place_variable_chunk(fill, cur, size_t(lens[i]), size_t(chunk_size), size_t(gap), row, start)) {
+            out_row[i] = row;
+            out_start[i] = start;
+            ++placed;
+        } else {
+            overflow = true;
+            out_row[i] = -1;
+            out_start[i] = -1;
+        }
+    }
+    return placed;
+}
 }  // extern "C"

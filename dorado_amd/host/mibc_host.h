@@ -265,6 +265,14 @@ private:
     int m_id;
     std::atomic<int64_t> m_batches{0};
     // variable-chunk packing state of the batch being filled
+  public:
+    // Row placement of one variable-length chunk (pure; tests/test_host_cpu.py drives it through mibch_debug_pack_rows):
+    // next-fit over the current row and the seven before it, else the next empty row; fill[] = samples used per row incl.
+    // the `gap` behind its last chunk.  Returns false when no row can take n samples (the caller's overflow path).
+    static bool place_variable_chunk(std::vector<int> &fill, int &cur_row, size_t n, size_t chunk_size, size_t gap, int &row,
+                                     int &start);
+
+  private:
     std::vector<mibc_var_chunk> m_var_table, m_var_overflow;
     std::vector<std::vector<uint16_t>> m_var_overflow_data;
     std::vector<int> m_var_fill;   // samples used per row (incl. the gap behind the last chunk)

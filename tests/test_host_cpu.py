@@ -298,3 +298,39 @@ def test_fused_layer_weight_image_layout():
     j, s, c = 0, 1, 3
     ref = np.stack([[w2[32 * c + (ln & 31), 32 * j + 16 * s + 4 * (ln >> 5) + (e & 3) + 8 * (e >> 2)] for e in range(8)] for ln in l])
     assert (img[20, s * 16 + c] == ref.astype(np.float16)).all()     # stage 20 = W2(0)
+
+
+def test_variable_chunk_row_packer_properties():
+    """HipModelRunner's placement of variable-length chunks (the role of CudaModelRunner.cpp:21-32 + the step budget of
+    BasecallerNode.cpp:408-430), CPU only: chunks never overlap, at least `gap` samples (2 output steps) lie between the
+    chunks of a row, no chunk crosses a row end, placement order is accept order, and once a chunk does not fit every later
+    one is deferred too (the second engine batch keeps result order trivial)."""
+    import ctypes as C
+    from dorado_amd import hostapi
+    L = hostapi.lib()
+    L.mibch_debug_pack_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    stride, cs = 6, 9996
+    gap = 2 * stride
+    rng = np.random.default_rng(9)
+    for rows, n in ((64, 300), (8, 40), (4, 4), (1, 3)):
+        lens = (rng.integers(2, cs // stride + 1, n) * stride).astype(np.int32)
+        lens[0] = cs                                    # a full-size chunk owns its row
+        out_row = np.zeros(n, np.int32)
+        out_start = np.zeros(n, np.int32)
+        placed = L.mibch_debug_pack_rows(lens.ctypes.data, n, rows, cs, gap, out_row.ctypes.data, out_start.ctypes.data)
+        ok = out_row >= 0
+        assert placed == int(ok.sum()) and placed >= 1
+        first_bad = int(np.argmin(ok)) if not ok.all() else n
+        assert ok[:first_bad].all() and not ok[first_bad:].any()          # a prefix is placed, the rest deferred
+        assert out_row[0] == 0 and out_start[0] == 0
+        for r in range(rows):
+            idx = np.nonzero(out_row[:first_bad] == r)[0]
+            spans = sorted((int(out_start[i]), int(out_start[i] + lens[i])) for i in idx)
+            for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+                assert b0 - a1 >= gap                                      # >= 2 output steps between chunks of a row
+            assert all(a1 <= cs and a0 % stride == 0 for a0, a1 in spans)
+        # next-fit with look-back: a chunk never lands more than 7 rows behind the newest row in use at its time
+        newest = np.maximum.accumulate(out_row[:first_bad]) if first_bad else np.zeros(0)
+        assert ((newest - out_row[:first_bad]) <= 7).all()
+        if first_bad < n:                                                  # it really did not fit anywhere allowed
+            assert newest[-1] == rows - 1
