@@ -581,6 +581,17 @@ extern "C" void mibc_debug_txlayer_trace(unsigned long long *dev_buf) { g_tl_tra
 extern "C" int mibc_launch_tx_layer(hipStream_t s, const half_t *attn, half_t *x, const half_t *wimg, const float *bo,
                                     const float *n1, const float *n2, float alpha, long R, int FF, int mode) {
     if (!tx_layer_supported(TL_D, FF) || R <= 0) return 1;
+    // The kernel addresses rows through 32-bit buffer offsets (row * 1024 bytes): rows are independent, so a call with more
+    // than 2^20 rows (sup@v5 batches over 1024 chunks) is issued as consecutive launches of at most 2^20 rows each.
+    constexpr long RMAX = 1L << 20;
+    if (R > RMAX) {
+        for (long r0 = 0; r0 < R; r0 += RMAX) {
+            const long rp = (R - r0 < RMAX) ? (R - r0) : RMAX;
+            const int rc = mibc_launch_tx_layer(s, attn + r0 * TL_D, x + r0 * TL_D, wimg, bo, n1, n2, alpha, rp, FF, mode);
+            if (rc != 0) return rc;
+        }
+        return 0;
+    }
     TxLayerArgs a{attn, x, wimg, bo, n1, n2, alpha, R, FF, g_tl_trace};
     const int dbg = mode >> 8;
     mode &= 0xff;

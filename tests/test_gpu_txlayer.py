@@ -50,3 +50,11 @@ def test_whole_tail_full_batch_timing():
     L = capi.lib()
     nd, md, rms, amax = _compare(1024 * 1024, 2048, 3, iters=3)
     assert md <= 0.0079 and rms <= 1e-4
+
+
+def test_more_rows_than_one_launch_addresses():
+    """The kernel addresses rows with 32-bit buffer offsets (1 KB per row): above 2^20 rows (sup@v5 batches over 1024 chunks)
+    mibc_launch_tx_layer issues consecutive launches of at most 2^20 rows.  Same contract across the seam and in the tail."""
+    nd, md, rms, amax = _compare(1024 * 1024 + 128 * 5 + 7, 2048, 3)
+    assert amax > 0.5
+    assert md <= 0.0079 and rms <= 1e-4, (nd, md, rms)
