@@ -57,9 +57,31 @@ SCALE_QUANTILE = 0
 SCALE_MED_MAD = 1
 
 
+DBG_LIB_PATH = os.path.join(HERE, "libmibc_dbg.so")
+
+
 def build() -> None:
-    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
-    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(HERE, "csrc")])
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU): the product library libmibc.so (exports
+    exactly include/mibc.h) and the debug library libmibc_dbg.so (same sources + the mibc_debug_* test hooks and the
+    ablation kernels; only tests/ and tools/ load it)."""
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(HERE, "csrc"), "all", "debug"])
+
+
+_dbg_lib = None
+
+
+def dbg_lib():
+    """libmibc_dbg.so: the kernel-vs-kernel comparison / timing hooks (mibc_debug_*).  Test infrastructure only."""
+    global _dbg_lib
+    if _dbg_lib is None:
+        if not os.path.exists(DBG_LIB_PATH):
+            raise MibcError(f"{DBG_LIB_PATH} is missing: run `make -C dorado_amd/csrc debug`")
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover
+            pass
+        _dbg_lib = C.CDLL(DBG_LIB_PATH)
+    return _dbg_lib
 
 
 _lib = None

@@ -21,6 +21,10 @@ typedef float float16_t __attribute__((ext_vector_type(16)));
 #else
 #define MIBC_ENV_INT(name, dflt) (dflt)
 #endif
+// libmibc.so is compiled with -fvisibility=hidden and exports exactly include/mibc.h (MIBC_API).  Test / timing hooks
+// (kernel-vs-kernel comparisons, microbenchmarks, cycle stamps: mibc_debug_*) are compiled and exported only in the debug
+// library libmibc_dbg.so (`make debug`), which tests/ and tools/ load when they need them (capi.dbg_lib()).
+#define MIBC_HOOK extern "C" __attribute__((visibility("default")))
 
 // ---- per-DEVICE launch state (host side).  Function attributes (hipFuncAttributeMaxDynamicSharedMemorySize) and
 // the CU count belong to a device, and one process drives every GPU of the node (one HipCaller per device on its own

@@ -1334,8 +1334,9 @@ extern "C" int mibc_debug_tap(mibc_engine *e, int tap, void *host_dst, size_t by
 }
 
 
-// Microbenchmark (not part of the public ABI): C[M][N] = A[M][K] . B[N][K]^T, avg ms over `iters`.
-extern "C" int mibc_debug_gemm(int M, int N, int K, int dbg, int iters, float *ms_out) {
+#ifdef MIBC_DEBUG_KERNELS
+// Microbenchmark (debug library only): C[M][N] = A[M][K] . B[N][K]^T, avg ms over `iters`.
+MIBC_HOOK int mibc_debug_gemm(int M, int N, int K, int dbg, int iters, float *ms_out) {
     half_t *A = nullptr, *B = nullptr, *C = nullptr;
     if (hipMalloc((void **)&A, (size_t)M * K * 2) != hipSuccess) return -1;
     if (hipMalloc((void **)&B, (size_t)N * K * 2) != hipSuccess) return -1;
@@ -1364,7 +1365,7 @@ extern "C" int mibc_debug_gemm(int M, int N, int K, int dbg, int iters, float *m
 // Test entry (not part of the public ABI): runs one GEMM shape through gemm256_kernel and through gemm_dma_kernel on
 // the same pseudo-random operands and reports how many output halfs differ (contract: none — same arithmetic) and
 // both run times.  epi: 0 plain (act, optional bias), 1 rotary + transposed V (N = 3 * d_model, T = rope_T), 2 SwiGLU.
-extern "C" int mibc_debug_gemm_compare(int M, int N, int K, int epi, int act, int use_bias, int rope_T, int iters,
+MIBC_HOOK int mibc_debug_gemm_compare(int M, int N, int K, int epi, int act, int use_bias, int rope_T, int iters,
                                        long long *ndiff, float *maxdiff, float *ms_256, float *ms_128) {
     auto lcg = [](uint32_t &s) {
         s = s * 1664525u + 1013904223u;
@@ -1449,3 +1450,4 @@ extern "C" int mibc_debug_gemm_compare(int M, int N, int K, int epi, int act, in
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return 0;
 }
+#endif   // MIBC_DEBUG_KERNELS

@@ -353,12 +353,13 @@ int tx_run_head(mibc_engine *e, int N, int n0, int ns, half_t *scores_out) {
     return MIBC_OK;
 }
 
-// Test entry (not part of the public ABI): the fused layer tail (txlayer.hip) against the five-launch path it replaces
+#ifdef MIBC_DEBUG_KERNELS
+// Test entry (debug library only): the fused layer tail (txlayer.hip) against the five-launch path it replaces
 // (gemm256 out-proj -> residual_rmsnorm -> gemm256 FC1 + SwiGLU -> gemm256 FC2 -> residual_rmsnorm) on the same
 // pseudo-random attn / x / weights.  mode 3 = whole tail, 1 = out-proj + norm 1 only (contract: bit-identical), 2 = MLP +
 // norm 2 only (x holds x1).  Reports the number of differing output halfs, the largest difference, the rms difference,
 // the largest |reference| and both run times.
-extern "C" int mibc_debug_txlayer_compare(long R, int FF, int mode, int iters, long long *ndiff, float *maxdiff, float *rmsdiff,
+MIBC_HOOK int mibc_debug_txlayer_compare(long R, int FF, int mode, int iters, long long *ndiff, float *maxdiff, float *rmsdiff,
                                           float *amax_out, float *ms_fused, float *ms_unfused, uint16_t *dump_fused,
                                           uint16_t *dump_ref) {
     const int C = 512;
@@ -480,3 +481,4 @@ extern "C" int mibc_debug_txlayer_compare(long R, int FF, int mode, int iters, l
     cleanup();
     return 0;
 }
+#endif   // MIBC_DEBUG_KERNELS

@@ -666,11 +666,12 @@ extern "C" int mibc_launch_residual_rmsnorm(hipStream_t s, const half_t *in, hal
     return 0;
 }
 
-// Test-only: run the windowed attention on random q | k, vT with the ring kernel (v3) and with the re-staging kernel
+#ifdef MIBC_DEBUG_KERNELS
+// Test-only (debug library): run the windowed attention on random q | k, vT with the ring kernel (v3) and with the re-staging kernel
 // (v2); the two perform the same operations per (query, key tile), so their outputs must be bit-identical.
 // Returns 0 and the number of differing output halfs, the two timings (ms per launch).
 #include <vector>
-extern "C" int mibc_debug_attention_compare(int N, int T, int H, int win_upper, int win_lower, int iters,
+MIBC_HOOK int mibc_debug_attention_compare(int N, int T, int H, int win_upper, int win_lower, int iters,
                                             long long *ndiff, float *ms_ring, float *ms_restage) {
     const int C = H * 64, ld = 2 * C;
     uint32_t seed = 777u + (uint32_t)(N + 3 * T + 7 * H);
@@ -723,3 +724,4 @@ extern "C" int mibc_debug_attention_compare(int N, int T, int H, int win_upper, 
     if (ms_restage) *ms_restage = ms[1];
     return rc;
 }
+#endif   // MIBC_DEBUG_KERNELS

@@ -22,6 +22,13 @@
 extern "C" {
 #endif
 
+/* libmibc.so is built with -fvisibility=hidden: exactly the entry points declared in this header are exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#define MIBC_API __attribute__((visibility("default")))
+#else
+#define MIBC_API
+#endif
+
 #define MIBC_OK 0
 #define MIBC_NOT_SUPPORTED 1
 #define MIBC_ERR_ARG (-1)
@@ -79,34 +86,34 @@ typedef struct mibc_stage_ms {
 typedef struct mibc_engine mibc_engine;
 
 /* ---- devices (replaces torch_utils/cuda_utils.cpp:224-248,364-384 device discovery) ---- */
-int mibc_device_count(void);
-int mibc_device_memory(int device_id, size_t *free_bytes, size_t *total_bytes); /* cuda_utils.cpp:250-262 */
-const char *mibc_last_error(const mibc_engine *e); /* e may be NULL: last global error */
+MIBC_API int mibc_device_count(void);
+MIBC_API int mibc_device_memory(int device_id, size_t *free_bytes, size_t *total_bytes); /* cuda_utils.cpp:250-262 */
+MIBC_API const char *mibc_last_error(const mibc_engine *e); /* e may be NULL: last global error */
 
 /* ---- lifetime (replaces CudaCaller ctor: basecall/CudaCaller.cpp:149-200) ----
  * weights: host f32 tensors in module.parameters() order (basecall/crf_utils.cpp:34-88):
  * conv{1..3}.{weight[Cout,Cin,W],bias}, rnn{1..L}.{weight_ih,weight_hh,bias_ih,bias_hh},
  * linear1.weight [,linear1.bias] [,linear2.weight].  Converted to f16 device layouts once. */
-int mibc_create(int device_id, const mibc_model_desc *desc, const float *const *weights,
+MIBC_API int mibc_create(int device_id, const mibc_model_desc *desc, const float *const *weights,
                 int n_weights, mibc_engine **out);
-void mibc_destroy(mibc_engine *e);
+MIBC_API void mibc_destroy(mibc_engine *e);
 
 /* ---- memory (replaces CudaCaller memory model :323-369 and WorkingMemory arena) ---- */
-int mibc_query_memory(const mibc_engine *e, int T_in, size_t *bytes_per_chunk, size_t *bytes_fixed);
-int mibc_reserve(mibc_engine *e, int N_max, int T_in); /* (re)allocates the device workspace */
-int mibc_output_steps(const mibc_engine *e, int T_in); /* T = number of output steps */
-int mibc_batch_granularity(const mibc_engine *e);      /* N must be a multiple of this */
+MIBC_API int mibc_query_memory(const mibc_engine *e, int T_in, size_t *bytes_per_chunk, size_t *bytes_fixed);
+MIBC_API int mibc_reserve(mibc_engine *e, int N_max, int T_in); /* (re)allocates the device workspace */
+MIBC_API int mibc_output_steps(const mibc_engine *e, int T_in); /* T = number of output steps */
+MIBC_API int mibc_batch_granularity(const mibc_engine *e);      /* N must be a multiple of this */
 /* The weight quantisation of the lstm_quant path, host only (no device): utils::quantize_tensor(cat(W_ih, W_hh, 1).half(), 1)
  * (torch_utils/tensor_utils.cpp:293-300 as called by nn/LSTMStack.cpp:160-168), bit for bit — f16 arithmetic included.
  * wih, whh: [4C][C] f32 (module.parameters() layout); q: [4C][2C] int8 (columns < C from W_ih); scale: [4C]. */
-int mibc_quantize_lstm_weights(const float *wih, const float *whh, int C, int8_t *q, float *scale);
+MIBC_API int mibc_quantize_lstm_weights(const float *wih, const float *whh, int C, int8_t *q, float *scale);
 
-void *mibc_host_alloc(size_t bytes); /* pinned host memory (CudaCaller.cpp:289-314) */
-void mibc_host_free(void *p);
-void *mibc_device_alloc(mibc_engine *e, size_t bytes);
-void mibc_device_free(mibc_engine *e, void *p);
-int mibc_memcpy_h2d(mibc_engine *e, void *dst_dev, const void *src_host, size_t bytes); /* sync */
-int mibc_memcpy_d2h(mibc_engine *e, void *dst_host, const void *src_dev, size_t bytes); /* sync */
+MIBC_API void *mibc_host_alloc(size_t bytes); /* pinned host memory (CudaCaller.cpp:289-314) */
+MIBC_API void mibc_host_free(void *p);
+MIBC_API void *mibc_device_alloc(mibc_engine *e, size_t bytes);
+MIBC_API void mibc_device_free(mibc_engine *e, void *p);
+MIBC_API int mibc_memcpy_h2d(mibc_engine *e, void *dst_dev, const void *src_host, size_t bytes); /* sync */
+MIBC_API int mibc_memcpy_d2h(mibc_engine *e, void *dst_host, const void *src_dev, size_t bytes); /* sync */
 
 /* ---- the hot path ----
  * in:     f16 [N, 1, T_in]                (what BasecallerNode hands accept_chunk)
@@ -114,28 +121,28 @@ int mibc_memcpy_d2h(mibc_engine *e, void *dst_host, const void *src_dev, size_t 
  * out:    int8 [3][N][T] = moves | bases (ASCII, packed at the front, NUL padded) | qstring
  *         (identical to the reference's CUDADecoder buffer: decode/CUDADecoder.cpp:66-71,153-168)
  */
-int mibc_forward(mibc_engine *e, const uint16_t *in_dev, int N, int T_in,
+MIBC_API int mibc_forward(mibc_engine *e, const uint16_t *in_dev, int N, int T_in,
                  uint16_t *scores_dev); /* (async) network only; replaces CRFModelImpl::run_koi */
-int mibc_decode(mibc_engine *e, const uint16_t *scores_dev, int N, int T,
+MIBC_API int mibc_decode(mibc_engine *e, const uint16_t *scores_dev, int N, int T,
                 const mibc_decode_opts *opts,
                 int8_t *out_dev); /* (async) replaces CUDADecoder::beam_search_part_1 */
-int mibc_call_device(mibc_engine *e, const uint16_t *in_dev, int N, int T_in,
+MIBC_API int mibc_call_device(mibc_engine *e, const uint16_t *in_dev, int N, int T_in,
                      const mibc_decode_opts *opts, int8_t *out_dev); /* (async) forward+decode */
-int mibc_call(mibc_engine *e, const uint16_t *in_host, int N, int T_in,
+MIBC_API int mibc_call(mibc_engine *e, const uint16_t *in_host, int N, int T_in,
               const mibc_decode_opts *opts,
               int8_t *out_host); /* H2D + forward + decode + D2H, synchronous
                                     (CudaCaller::call_chunks, CudaCaller.cpp:224-271) */
-int mibc_sync(mibc_engine *e);
+MIBC_API int mibc_sync(mibc_engine *e);
 /* Two-phase form of mibc_call (the overlap CudaCaller gets from its runners' own streams, CudaCaller.cpp:645-719 +
  * decode/CUDADecoder.h:13-15): mibc_call_async enqueues H2D (copy stream) -> network + decode (engine stream) ->
  * D2H (second copy stream) for `slot` (0 or 1) and returns; mibc_call_wait blocks until that slot's output has
  * arrived in out_host.  Two slots in flight: the copies of one batch run beside the kernels of the other.  A slot
  * must be waited for before it is submitted again; in_host / out_host must be pinned (mibc_host_alloc) and stay
  * valid until the wait returns.  shift_scale_host: NULL (in_host holds scaled f16) or float [N][2] (raw int16). */
-int mibc_call_async(mibc_engine *e, int slot, const void *in_host, const float *shift_scale_host, int N, int T_in,
+MIBC_API int mibc_call_async(mibc_engine *e, int slot, const void *in_host, const float *shift_scale_host, int N, int T_in,
                     const mibc_decode_opts *opts, int8_t *out_host);
-int mibc_call_wait(mibc_engine *e, int slot);
-int mibc_call_poll(mibc_engine *e, int slot); /* 1 = finished (then call mibc_call_wait), 0 = still running */
+MIBC_API int mibc_call_wait(mibc_engine *e, int slot);
+MIBC_API int mibc_call_poll(mibc_engine *e, int slot); /* 1 = finished (then call mibc_call_wait), 0 = still running */
 
 /* ---- signal scaling in front of the path (the device side of ScalerNode,
  *      dorado/read_pipeline/nodes/ScalerNode.cpp:144-269) ----
@@ -146,11 +153,11 @@ int mibc_call_poll(mibc_engine *e, int slot); /* 1 = finished (then call mibc_ca
  * shift_scale: float [N][2]. */
 #define MIBC_SCALE_QUANTILE 0 /* ScalerNode.cpp:42-52 (normalisation), utils::quantile_counting */
 #define MIBC_SCALE_MED_MAD 1  /* ScalerNode.cpp:32-40 (med_mad) */
-int mibc_forward_i16(mibc_engine *e, const int16_t *in_dev, const float *shift_scale_dev, int N, int T_in,
+MIBC_API int mibc_forward_i16(mibc_engine *e, const int16_t *in_dev, const float *shift_scale_dev, int N, int T_in,
                      uint16_t *scores_dev);
-int mibc_call_device_i16(mibc_engine *e, const int16_t *in_dev, const float *shift_scale_dev, int N, int T_in,
+MIBC_API int mibc_call_device_i16(mibc_engine *e, const int16_t *in_dev, const float *shift_scale_dev, int N, int T_in,
                          const mibc_decode_opts *opts, int8_t *out_dev);
-int mibc_call_i16(mibc_engine *e, const int16_t *in_host, const float *shift_scale_host, int N, int T_in,
+MIBC_API int mibc_call_i16(mibc_engine *e, const int16_t *in_host, const float *shift_scale_host, int N, int T_in,
                   const mibc_decode_opts *opts, int8_t *out_host);
 /* Per-read (shift, scale) of the two data-driven strategies.  Reads are concatenated in sig_dev;
  * read r = [offsets_dev[r], offsets_dev[r+1]) (n_reads + 1 offsets).  params4 (quantile only) =
@@ -158,12 +165,12 @@ int mibc_call_i16(mibc_engine *e, const int16_t *in_host, const float *shift_sca
  * raw_dev (optional, [n_reads][2]) receives (q_a, q_b) resp. (median, median |x - median|).
  * Integer work, bit-exact with the reference.  (The PA strategy, ScalerNode.cpp:186-215, is a closed
  * formula of the read's calibration and needs no pass over the samples: host side.) */
-int mibc_scaler_stats(mibc_engine *e, const int16_t *sig_dev, const int64_t *offsets_dev, int n_reads,
+MIBC_API int mibc_scaler_stats(mibc_engine *e, const int16_t *sig_dev, const int64_t *offsets_dev, int n_reads,
                       int strategy, const float *params4, float *shift_scale_dev, float *raw_dev);
 /* Whole reads: out[i] = f16((float(x[i]) - shift_r) / scale_r); replaces
  * utils::shift_scale_tensor_i16_to_f16_inplace for callers that want the scaled read back
  * (e.g. for the signal trim, torch_utils/trim.cpp). */
-int mibc_scale_reads(mibc_engine *e, const int16_t *sig_dev, const int64_t *offsets_dev, int n_reads,
+MIBC_API int mibc_scale_reads(mibc_engine *e, const int16_t *sig_dev, const int64_t *offsets_dev, int n_reads,
                      const float *shift_scale_dev, uint16_t *out_f16_dev);
 
 /* ---- variable chunk sizes ----
@@ -183,12 +190,12 @@ typedef struct mibc_var_chunk {
     int sample_start;
     int n_samples;
 } mibc_var_chunk;
-int mibc_forward_var(mibc_engine *e, const void *in_dev, const float *shift_scale_dev, int N, int T_in,
+MIBC_API int mibc_forward_var(mibc_engine *e, const void *in_dev, const float *shift_scale_dev, int N, int T_in,
                      const mibc_var_chunk *chunks_host, int n_chunks, uint16_t *scores_dev);
-int mibc_call_device_var(mibc_engine *e, const void *in_dev, const float *shift_scale_dev, int N, int T_in,
+MIBC_API int mibc_call_device_var(mibc_engine *e, const void *in_dev, const float *shift_scale_dev, int N, int T_in,
                          const mibc_var_chunk *chunks_host, int n_chunks, const mibc_decode_opts *opts,
                          int8_t *out_dev);
-int mibc_call_var(mibc_engine *e, const void *in_host, const float *shift_scale_host, int N, int T_in,
+MIBC_API int mibc_call_var(mibc_engine *e, const void *in_host, const float *shift_scale_host, int N, int T_in,
                   const mibc_var_chunk *chunks_host, int n_chunks, const mibc_decode_opts *opts, int8_t *out_host);
 
 /* ---- POD5 signal decode ----
@@ -199,13 +206,13 @@ int mibc_call_var(mibc_engine *e, const void *in_host, const float *shift_scale_
  * so the samples are born in HBM, next to mibc_scaler_stats / mibc_*_i16.
  * streams_dev: concatenated inflated rows; stream_off_dev / sample_off_dev: n_rows + 1 prefix offsets
  * (bytes / samples); status_dev[r] = 0 ok, 1 = row not consumed exactly (corrupt). */
-int mibc_svb16_decode(mibc_engine *e, const uint8_t *streams_dev, const int64_t *stream_off_dev,
+MIBC_API int mibc_svb16_decode(mibc_engine *e, const uint8_t *streams_dev, const int64_t *stream_off_dev,
                       const int64_t *sample_off_dev, int n_rows, int16_t *out_dev, int *status_dev);
 
 /* ---- measurement (replaces CudaCaller.cpp:552-569 timing + gpu_profiling.h ranges) ---- */
-int mibc_time_forward(mibc_engine *e, int N, int T_in, float *ms); /* min of 2 runs, like :552-569 */
-int mibc_get_stage_ms(mibc_engine *e, mibc_stage_ms *out);         /* hipEvent times, last call */
-int mibc_set_profile(mibc_engine *e, int level);                   /* 0 off, 1 per-stage events, 2 + roctx ranges around the
+MIBC_API int mibc_time_forward(mibc_engine *e, int N, int T_in, float *ms); /* min of 2 runs, like :552-569 */
+MIBC_API int mibc_get_stage_ms(mibc_engine *e, mibc_stage_ms *out);         /* hipEvent times, last call */
+MIBC_API int mibc_set_profile(mibc_engine *e, int level);                   /* 0 off, 1 per-stage events, 2 + roctx ranges around the
                                                                       stages (utils::ScopedProfileRange,
                                                                       torch_utils/gpu_profiling.h:32-99) for rocprofv3
                                                                       --marker-trace */
@@ -214,7 +221,7 @@ int mibc_set_profile(mibc_engine *e, int level);                   /* 0 off, 1 p
  * tap: 0 conv1 out [N,T_in,16] f16 | 1 conv2 out (padded rows) | 2 conv3 out [T,N,C] f16
  *      3 LSTM stack out [T,N,C] f16 | 4 back-guides [N,T+1,S] f32 (first decode sub-batch)
  *      5 per-block quality prob [N,T] f32 */
-int mibc_debug_tap(mibc_engine *e, int tap, void *host_dst, size_t bytes);
+MIBC_API int mibc_debug_tap(mibc_engine *e, int tap, void *host_dst, size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("N,T,H", [(3, 1024, 8), (2, 256, 2), (5, 640, 4)])
 def test_ring_attention_bit_identical_to_restaging_kernel(N, T, H):
-    L = capi.lib()
+    L = capi.dbg_lib()
     L.mibc_debug_attention_compare.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_longlong), C.POINTER(C.c_float),
                                                                C.POINTER(C.c_float)]
     nd, t3, t2 = C.c_longlong(-1), C.c_float(), C.c_float()

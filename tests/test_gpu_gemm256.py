@@ -25,7 +25,7 @@ SHAPES = [
 
 @pytest.mark.parametrize("M,N,K,epi,act,bias,rope_T", SHAPES)
 def test_gemm256_bit_identical_to_gemm_dma(M, N, K, epi, act, bias, rope_T):
-    L = capi.lib()
+    L = capi.dbg_lib()
     L.mibc_debug_gemm_compare.argtypes = [C.c_int] * 8 + [C.POINTER(C.c_longlong), C.POINTER(C.c_float),
                                                             C.POINTER(C.c_float), C.POINTER(C.c_float)]
     nd, md, t256, t128 = C.c_longlong(), C.c_float(), C.c_float(), C.c_float()

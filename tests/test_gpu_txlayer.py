@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _compare(R, FF, mode, iters=1):
-    L = capi.lib()
+    L = capi.dbg_lib()
     L.mibc_debug_txlayer_compare.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)] + \
         [C.POINTER(C.c_float)] * 5 + [C.c_void_p, C.c_void_p]
     nd = C.c_longlong()
@@ -47,7 +47,7 @@ def test_mlp_and_whole_tail_match_unfused(R, FF, mode):
 
 def test_whole_tail_full_batch_timing():
     """1 M tokens (the sup@v5 bench batch): same contract, and the fused launch must beat the five launches."""
-    L = capi.lib()
+    L = capi.dbg_lib()
     nd, md, rms, amax = _compare(1024 * 1024, 2048, 3, iters=3)
     assert md <= 0.0079 and rms <= 1e-4
 

@@ -23,6 +23,14 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     missing = [n for n in declared if not hasattr(L, n)]
     assert not missing, missing
     assert set(declared) == set(capi.EXPORTS)
+    # ... and NOTHING else leaves the product library (-fvisibility=hidden + csrc/mibc.map): no mibc_launch_* internals,
+    # no mibc_debug_* test hooks (those live in libmibc_dbg.so only), no kernel handles, no libstdc++ instantiations
+    nm = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in nm.splitlines() if l.strip())
+    assert exported == declared, sorted(set(exported) ^ set(declared))
+    nm = subprocess.run(["nm", "-D", "--defined-only", capi.DBG_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    dbg = sorted(l.split()[-1] for l in nm.splitlines() if l.strip())
+    assert set(declared) <= set(dbg) and all(n.startswith("mibc_debug_") for n in set(dbg) - set(declared))
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -264,7 +272,7 @@ def test_fused_layer_weight_image_layout():
     (16 + 3 FF/32) stages of 32 KB; 16 x Wo | W1(0) | W1(1) W2(0) | ... | W2(NJ-1); every weight exactly once."""
     import ctypes as C
     from dorado_amd import capi
-    L = capi.lib()
+    L = capi.dbg_lib()
     L.mibc_debug_tx_layer_image.restype = C.c_long
     L.mibc_debug_tx_layer_image.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_long]
     FF, D = 256, 512

@@ -3,7 +3,7 @@
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dorado_amd import capi
-L = capi.lib()
+L = capi.dbg_lib()
 L.mibc_debug_gemm.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float)]
 shapes = [(1 << 20, 1536, 512), (1 << 20, 512, 512), (1 << 20, 4096, 512), (1 << 20, 512, 2048), (1 << 21, 4096, 512), (1 << 22, 1024, 384),
           (4096 * 1666, 4096, 1024)]   # dbg 0 = production path (gemm256 where it applies), 256 = gemm_dma_kernel

@@ -7,7 +7,7 @@ import numpy as np
 sys.path.insert(0, ".")
 from dorado_amd import capi
 
-L = capi.lib()
+L = capi.dbg_lib()
 L.mibc_debug_txlayer_compare.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)] + \
     [C.POINTER(C.c_float)] * 5 + [C.c_void_p, C.c_void_p]
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 3
