@@ -117,19 +117,20 @@ def host_free_ram_gb():
     return 64.0
 
 
-def cpu_baseline(cfg, ws, t_in, kind_model, full=False):
-    """Reference CPU basecaller on this host.  R runner threads by the reference's own rule
+def cpu_baseline(cfg, ws, t_in, kind_model, full=False, budget_s=20.0):
+    """Reference CPU basecaller on this host, SURVEY.md §8d configuration: R runner threads by the reference's own rule
     (dorado/basecall/crf_utils.cpp:208-233: clamp(free_RAM / (GB_per_runner * batch / 128), 1, hardware_concurrency)
-    with 4.5 GB (hac) / 12.5 GB (sup) per runner at batch 128 and the CPU batch of SURVEY.md §8d, 64 / 16), one
-    torch intra-op thread per runner (torch_utils.cpp:20).  Bounded sample (~10-20 s): every runner calls ONE short
-    batch — hac: 2 full chunks; sup: 1 chunk cut to 606 samples (sup@v5: 1536) (256 concurrent sup runners stream 84 MB of f32
-    weights per time step each and run at ~40 samples/s/thread: a full chunk would take minutes) — forward + decode;
-    what was run is stated in `sample`.  Every runner thread first makes an untimed warm-up call (a 300-sample chunk:
-    its libtorch workspaces and the weights are paged in), the clock starts when all runners are warm.  The per-step
-    cost of the reference's CPU path does not depend on the chunk length (LSTM: one step at a time; the convolutions are
-    linear in T), so the short sup chunks change the rate by edge effects only.  full=True (--cpu-baseline-full) runs the
-    exact SURVEY §8d configuration instead — real T_in, batch 64 / 16 per runner, 1 warm-up + 1 timed batch — which takes
-    10 min (hac) to hours (sup) on 256 cores and is therefore not the default."""
+    with 4.5 GB (hac) / 12.5 GB (sup) per runner at batch 128), every runner calling batches of the §8d CPU batch size
+    (64 hac / 16 sup) with one torch intra-op thread (torch_utils.cpp:20), forward + decode.
+    Bounded sample: a time box.  Every runner first makes one untimed warm-up call (a 300-sample chunk: libtorch workspaces
+    and the weights are paged in); the clock starts when all runners are warm; each runner then calls batch after batch
+    until `budget_s` has passed and finishes the batch it is in; value = samples of all completed batches / time until the
+    last runner is done.  So that a batch takes seconds, not minutes, the chunks of the sample are SHORTENED (hac 1200,
+    sup@v4.3 402, sup@v5 768 samples): the reference's CPU path costs the same per time step whatever the chunk length
+    (LSTM: one step at a time over the whole batch; convolutions, attention window and decoder are linear in T), so this
+    changes the rate by edge effects only, whereas a batch of ONE chunk per runner (rounds 1-3) turned the recurrent GEMMs
+    into matrix-vector products and under-reported the CPU.  What was run is stated in `sample`.
+    full=True (--cpu-baseline-full): real T_in, exactly one timed batch per runner (10 min hac ... an hour sup on 256 cores)."""
     from oracle import oracle_py as O
     from dorado_amd import synth
 
@@ -138,44 +139,60 @@ def cpu_baseline(cfg, ws, t_in, kind_model, full=False):
     per_runner_gb, rule_batch = (12.5, 16) if kind_model == "sup" else (4.5, 64)
     R = int(host_free_ram_gb() / (per_runner_gb * rule_batch / 128.0))
     R = max(1, min(R, cores))
-    n_per = 1 if kind_model == "sup" else 2          # chunks per runner in the sample (<= rule_batch)
-    if full:
-        n_per = rule_batch
-    elif kind_model == "sup":
-        t_in = min(t_in, 606 if cfg.tx is None else 1536)
-    x = synth.make_signal(n_per, t_in, seed=99).astype(np.float32)[:, None, :]
-    done = []
     if kind == "port":
         R = 1  # the C port parallelises internally with OpenMP
     gran = 192 if cfg.tx is not None else 6
+    if not full:
+        short = 1200 if kind_model != "sup" else (402 if cfg.tx is None else 768)
+        t_in = max(gran, min(t_in, short) // gran * gran)
+    x = synth.make_signal(rule_batch, t_in, seed=99).astype(np.float32)[:, None, :]
     xs = np.ascontiguousarray(x[:1, :, : max(gran, 300 // gran * gran)])
     warm = threading.Barrier(R + 1)
-    tstart = [0.0]
+    done, ends, errors = [], [], []
+    deadline = [0.0]
 
     def runner():
-        O.decode(O.forward(cfg, ws, xs, use_ref=(kind == "reference")), use_ref=(kind == "reference"))   # warm-up
-        warm.wait()
-        warm.wait()      # main thread has stamped the start time
-        s = O.forward(cfg, ws, x, use_ref=(kind == "reference"))
-        O.decode(s, q_shift=cfg.qbias, q_scale=cfg.qscale, use_ref=(kind == "reference"))
-        done.append(n_per)
+        try:
+            O.decode(O.forward(cfg, ws, xs, use_ref=(kind == "reference")), use_ref=(kind == "reference"))   # warm-up
+            warm.wait(timeout=600)
+            warm.wait(timeout=600)      # main thread has stamped the start time
+            while True:
+                s = O.forward(cfg, ws, x, use_ref=(kind == "reference"))
+                O.decode(s, q_shift=cfg.qbias, q_scale=cfg.qscale, use_ref=(kind == "reference"))
+                done.append(rule_batch)
+                if full or time.time() >= deadline[0]:
+                    break
+            ends.append(time.time())
+        except threading.BrokenBarrierError:
+            pass
+        except Exception as exc:   # a failing runner must not leave the others (and the bench line) parked on the barrier
+            errors.append(repr(exc))
+            warm.abort()
 
-    th = [threading.Thread(target=runner) for _ in range(R)]
+    th = [threading.Thread(target=runner, daemon=True) for _ in range(R)]
     for t in th:
         t.start()
-    warm.wait()
-    t0 = time.time()
-    warm.wait()
+    try:
+        warm.wait(timeout=600)
+        t0 = time.time()
+        deadline[0] = t0 + budget_s
+        warm.wait(timeout=600)
+    except threading.BrokenBarrierError:
+        return {"error": "cpu_baseline runner failed: " + (errors[0] if errors else "warm-up barrier broken / timed out"),
+                "kind": kind, "cores": R}
     for t in th:
         t.join()
-    el = time.time() - t0
+    if errors or not ends:
+        return {"error": "cpu_baseline runner failed: " + (errors[0] if errors else "no batch completed"), "kind": kind, "cores": R}
+    el = max(ends) - t0
     samples = sum(done) * t_in
     return {"value": samples / el, "unit": "samples/s", "cores": R if kind == "reference" else cores,
             "kind": kind,
-            "sample": f"{sum(done)} chunks x {t_in} samples = {R} runner threads (crf_utils.cpp:208-233 rule: batch "
-                      f"{rule_batch}, {per_runner_gb} GB/runner at batch 128, {host_free_ram_gb():.0f} GB free, "
-                      f"{cores} logical cores) x {n_per} chunks each, 1 torch thread per runner, 1 untimed warm-up "
-                      f"call per runner, forward+decode, {el:.1f}s wall"}
+            "sample": f"{sum(done)} chunks x {t_in} samples in {el:.1f}s wall: {R} runner threads (crf_utils.cpp:208-233 rule: "
+                      f"{per_runner_gb} GB/runner at batch 128, {host_free_ram_gb():.0f} GB free, {cores} logical cores), each "
+                      f"calling batches of {rule_batch} chunks (SURVEY 8d CPU batch) for a {budget_s:.0f}s time box"
+                      f"{' (full: real T_in, one batch per runner)' if full else ' (chunks shortened from the real T_in: per-step cost is length-independent)'}, "
+                      f"1 torch thread per runner, 1 untimed warm-up call per runner, forward+decode"}
 
 
 def bench_scale_parity(eng, out, d_in, n, t_in, T, period):
@@ -474,6 +491,30 @@ def main():
                 extra["hac_int8_lstm"] = {"error": repr(ex)}
         if rank == 0:
             line["extra"] = extra
+    # north_star's multi-GPU shape is ONE process driving every device (one HipCaller per device fed from shared chunk
+    # queues, api/runner_creation.cpp:85-124), not one process per GPU: at N > 1 rank 0 measures exactly that over all N
+    # devices AFTER the per-rank weak-scaling lines above (every rank has released its engine; the other ranks wait in the
+    # barrier below), with 5-chunk reads through both chunk-size queues.  Reported beside `value`, never as it.
+    if world > 1 and args.model in ("hac", "sup", "sup5"):
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 0:
+            try:
+                from dorado_amd import hostapi
+                k, nb = 5, 8
+                rl = t_in + (k - 1) * (t_in - cfg.overlap)
+                reads5 = synth.make_signal(64, rl, seed=78)
+                nr = (nb * n * world) // k
+                sp = hostapi.bench_through_host(cfg, ws, reads5, n_warm=(2 * n * world) // k, n_reads=nr, device="hip:all",
+                                                num_runners=2, batch_size=n, two_queues=True)
+                sp["vs_per_process_value_incl_overlap"] = sp["samples_incl_padding_per_s"] / line["value"]
+                sp["what"] = (f"ONE process, hip:all = {sp['devices']} devices, one HipCaller per device, 2 runners per device and "
+                              f"chunk-size queue, {nr} reads of {rl} samples ({k} chunks, overlap {cfg.overlap}) through both "
+                              f"chunk-size queues, PCIe + slicing + stitching included; `value` above is {world} processes")
+                line.setdefault("extra", {})["single_process_hip_all"] = sp
+            except Exception as ex:
+                line.setdefault("extra", {})["single_process_hip_all"] = {"error": repr(ex)}
+        dist.barrier()
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

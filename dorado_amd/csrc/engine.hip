@@ -521,8 +521,20 @@ static int set_geometry(mibc_engine *e, int T_in) {
         const int rc = tx_set_geometry(e, T_in);
         if (rc != MIBC_OK) return rc;
     } else {
-        // on the engine's stream: a null-stream memset is not ordered with this non-blocking stream
-        HIP_OK(e, hipMemsetAsync(e->a2p, 0, e->a2p_bytes, e->stream));
+        // on the engine's stream: a null-stream memset is not ordered with this non-blocking stream.  First geometry of a
+        // workspace: everything.  Later switches (the two chunk-size queues of a device alternate on one engine): only the
+        // rows that are padding in the NEW pitch — row n's data is rewritten by conv12 on every call, its pad rows
+        // [n Tp, +pad) and [n Tp + pad + T_in, (n + 1) Tp) never are — i.e. N strips of 2 pad + 2 rows (back pad of n +
+        // front pad of n + 1 are adjacent) plus the 64 slack rows behind the last chunk: 0.2 % of the buffer.
+        const size_t Tp = (size_t)T_in + 2 * e->pad3 + 2, rowb = 16 * sizeof(half_t), pad = (size_t)e->pad3;
+        if (e->T_in_res == 0) {
+            HIP_OK(e, hipMemsetAsync(e->a2p, 0, e->a2p_bytes, e->stream));
+        } else {
+            char *base = (char *)e->a2p;
+            HIP_OK(e, hipMemsetAsync(base, 0, pad * rowb, e->stream));
+            HIP_OK(e, hipMemset2DAsync(base + (pad + (size_t)T_in) * rowb, Tp * rowb, 0, (2 * pad + 2) * rowb, (size_t)e->N_res, e->stream));
+            HIP_OK(e, hipMemsetAsync(base + (size_t)e->N_res * Tp * rowb, 0, 64 * rowb, e->stream));
+        }
     }
     e->Tpitch = T_in + 2 * e->pad3 + 2;
     e->T_in_res = T_in;

@@ -183,7 +183,7 @@ size_t tx_bytes_per_chunk(const mibc_engine *e, int T_in) {
         }
     }
     const size_t R = (size_t)T;
-    b += R * (3 * tx.D + tx.D + tx.D + tx.FF + tx.sf * tx.D) * 2;
+    b += R * (tx.D /* x */ + 3 * tx.D /* qkv */ + tx.D /* vT */ + tx.D /* attn */ + tx.D /* tmp */ + tx.FF + tx.sf * tx.D) * 2;   // == tx_reserve
     b += 3 * R * tx.sf;
     return b;
 }
@@ -231,8 +231,19 @@ int tx_set_geometry(mibc_engine *e, int T_in) {
         tx.ctp.push_back(T + 2 * tx.convs[i].pad);
         tx.ct.push_back(T);
         T = (T + 2 * tx.convs[i].pad - tx.convs[i].w) / tx.convs[i].stride + 1;
-        // the pad rows sit where this chunk length puts them: zero the whole buffer, in stream order
-        HIP_OK(e, hipMemsetAsync(tx.cbuf[i], 0, tx.cbuf_bytes[i], e->stream));
+        // the pad rows sit where this chunk length puts them, in stream order: the whole buffer the first time, afterwards
+        // only the rows that are padding in the new pitch (N strips of 2 pad rows + the slack rows; the data rows are
+        // rewritten by every call) — see set_geometry in engine.hip
+        const size_t Tc = (size_t)tx.ct[i], pad = (size_t)tx.convs[i].pad, tp = Tc + 2 * pad;
+        const size_t rowb = (size_t)(i == 0 ? e->d.conv_size[0] : tx.convs[i - 1].cout) * sizeof(half_t);
+        if (e->T_in_res == 0 || pad == 0) {
+            HIP_OK(e, hipMemsetAsync(tx.cbuf[i], 0, tx.cbuf_bytes[i], e->stream));
+        } else {
+            char *base = (char *)tx.cbuf[i];
+            HIP_OK(e, hipMemsetAsync(base, 0, pad * rowb, e->stream));
+            HIP_OK(e, hipMemset2DAsync(base + (pad + Tc) * rowb, tp * rowb, 0, 2 * pad * rowb, (size_t)e->N_res, e->stream));
+            HIP_OK(e, hipMemsetAsync(base + (size_t)e->N_res * tp * rowb, 0, 64 * rowb, e->stream));
+        }
     }
     if (T > (e->d.tx_max_seq_len > 0 ? e->d.tx_max_seq_len : 2048))
         return fail(e, MIBC_ERR_ARG, "RotE - maximum sequence length exceeded - chunksize too large");

@@ -180,9 +180,13 @@ int HipCaller::choose_batch_size(int chunk_size, int requested) {
         throw std::runtime_error(std::string("auto batch size: ") + mibc_last_error(m_engine));
     const double budget = double(m_params.memory_limit_fraction) * double(free_b) - double(1ull << 30) - double(fixed);
     const long cap = budget > 0 ? long(budget / double(per_chunk)) / g * g : 0;
-    if (cap < g)
-        throw std::runtime_error("auto batch size: less than one batch granule fits into the memory limit (" +
-                                 std::to_string(m_params.memory_limit_fraction) + " of " + std::to_string(free_b >> 20) + " MB free)");
+    if (cap < g) {
+        // the reference warns and falls back to its default batch instead of failing (CudaCaller.cpp:441-445); here the
+        // smallest batch the engine accepts — mibc_reserve still fails loudly if even that does not fit
+        fprintf(stderr, "[mibc] hip:%d auto batch size: less than one batch granule fits into the memory limit (%.2f of %zu MB free); "
+                "falling back to batch %d\n", m_device, double(m_params.memory_limit_fraction), free_b >> 20, g);
+        return g;
+    }
     const long want = (m_desc.tx_d_model > 0) ? 1024 : 256L * g;
     long n = std::min(want, cap);
     if (m_params.run_batchsize_benchmarks || requested < 0) {

@@ -20,17 +20,13 @@ def _cfg(C, state_len, layers=3):
     return cfg
 
 
-@pytest.mark.parametrize("C,state_len,N,t_in", [(128, 4, 128, 606), (512, 5, 512, 306)])
-def test_engines_created_and_run_concurrently_from_two_threads(C, state_len, N, t_in):
-    """Two threads each create an engine and call it in a loop (C = 512: the CU-cluster LSTM kernel, whose launches
-    from different streams must not overlap on one device — cluster_util.h MibcClusterLaunch).  Results must equal the
-    sequential ones, call after call."""
+def _two_engines_concurrently(C, state_len, N, t_in, devices):
     cfg = _cfg(C, state_len)
     ws = [synth.make_weights(cfg, seed=10 + i) for i in range(2)]
     xs = [synth.make_signal(N, t_in, seed=20 + i) for i in range(2)]
     want = []
-    for w, x in zip(ws, xs):
-        e = capi.Engine(cfg, w)
+    for w, x, dev in zip(ws, xs, devices):
+        e = capi.Engine(cfg, w, device=dev)
         want.append(e.call(x))
         e.close()
     got = [None, None]
@@ -40,7 +36,7 @@ def test_engines_created_and_run_concurrently_from_two_threads(C, state_len, N, 
     def work(i):
         try:
             barrier.wait()
-            e = capi.Engine(cfg, ws[i])          # concurrent mibc_create: weight uploads, attribute set-up
+            e = capi.Engine(cfg, ws[i], device=devices[i])   # concurrent mibc_create: weight uploads, attribute set-up
             barrier.wait()
             for _ in range(4):                   # concurrent launches on two streams of one device
                 got[i] = e.call(xs[i])
@@ -60,6 +56,37 @@ def test_engines_created_and_run_concurrently_from_two_threads(C, state_len, N, 
     for t in th:
         t.join()
     assert not errs, errs
+
+
+@pytest.mark.parametrize("C,state_len,N,t_in", [(128, 4, 128, 606), (512, 5, 512, 306)])
+def test_engines_created_and_run_concurrently_from_two_threads(C, state_len, N, t_in):
+    """Two threads each create an engine and call it in a loop (C = 512: the CU-cluster LSTM kernel, whose launches
+    from different streams must not overlap on one device — cluster_util.h MibcClusterLaunch).  Results must equal the
+    sequential ones, call after call."""
+    _two_engines_concurrently(C, state_len, N, t_in, (0, 0))
+
+
+@pytest.mark.parametrize("C,state_len,N,t_in", [(128, 4, 128, 606), (512, 5, 512, 306)])
+def test_engines_on_two_devices_concurrently(C, state_len, N, t_in):
+    """The same on devices 0 AND 1 (skipped on a 1-GPU box): the first exercise of the per-device state with dev != 0 —
+    MIBC_LDS_ATTR_ONCE's per-device bit (the > 64 KB LDS opt-in is a per-device function attribute), mibc_ncu()'s per-device
+    cache and the per-device cluster gate (two cluster launches on DIFFERENT devices must not serialise on each other)."""
+    if capi.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _two_engines_concurrently(C, state_len, N, t_in, (0, 1))
+
+
+def test_single_process_host_layer_over_all_devices():
+    """hip:all through the C++ host layer (one HipCaller per device, shared chunk queues): calls must equal device 0's alone
+    (skipped on a 1-GPU box)."""
+    if capi.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    cfg = _cfg(128, 4)
+    ws = synth.make_weights(cfg, seed=3)
+    reads = [synth.make_signal(1, 3000 + 37 * i, seed=40 + i)[0] for i in range(48)]
+    want, _ = hostapi.basecall_reads(cfg, ws, reads, device="hip:0", num_runners=2, batch_size=64)
+    got, _ = hostapi.basecall_reads(cfg, ws, reads, device="hip:all", num_runners=2, batch_size=64)
+    assert [g[0] for g in got] == [w[0] for w in want] and [g[1] for g in got] == [w[1] for w in want]
 
 
 @pytest.mark.parametrize("model", ["lstm", "tx"])
