@@ -50,7 +50,7 @@ EXPORTS = [
     "mibc_sync", "mibc_quantize_lstm_weights", "mibc_time_forward", "mibc_get_stage_ms", "mibc_set_profile", "mibc_debug_tap",
     "mibc_forward_i16", "mibc_call_device_i16", "mibc_call_i16", "mibc_scaler_stats", "mibc_scale_reads",
     "mibc_svb16_decode", "mibc_forward_var", "mibc_call_device_var", "mibc_call_var",
-    "mibc_call_async", "mibc_call_wait", "mibc_call_poll",
+    "mibc_call_async", "mibc_call_wait", "mibc_call_poll", "mibc_call_var_async",
 ]
 
 SCALE_QUANTILE = 0

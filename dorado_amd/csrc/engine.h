@@ -163,6 +163,8 @@ struct mibc_engine {
         hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
         size_t in_bytes = 0, out_bytes = 0;
         int n = 0;
+        char *var_dev = nullptr, *var_host = nullptr;   // mibc_call_var_async: masks + decoder table (device / pinned host)
+        size_t var_bytes = 0;
     } aslot[2];
     hipStream_t s_in = nullptr, s_out = nullptr;
     // last call

@@ -444,6 +444,8 @@ extern "C" void mibc_destroy(mibc_engine *e) {
         if (a.in) (void)hipFree(a.in);
         if (a.ss) (void)hipFree(a.ss);
         if (a.out3) (void)hipFree(a.out3);
+        if (a.var_dev) (void)hipFree(a.var_dev);
+        if (a.var_host) (void)hipHostFree(a.var_host);
         if (a.ev_in) (void)hipEventDestroy(a.ev_in);
         if (a.ev_done) (void)hipEventDestroy(a.ev_done);
         if (a.ev_out) (void)hipEventDestroy(a.ev_out);
@@ -1109,17 +1111,35 @@ extern "C" int mibc_svb16_decode(mibc_engine *e, const uint8_t *streams_dev, con
 // Builds the masks and the decoder's chunk table of a variable-chunk call.  The decoder runs per decode sub-batch of
 // e->Nd rows like the fixed path: the table is ordered by sub-batch (stable), sub_begin[k] .. sub_begin[k+1] are the
 // chunks of sub-batch k, score offsets are relative to the sub-batch's first row and back-guide rows restart at 0.
-static int var_setup(mibc_engine *e, int N, int T_in, const mibc_var_chunk *ch, int n_chunks, int *Tmax_out,
-                     std::vector<int> *sub_begin) {
-    if (!ch || n_chunks <= 0) return fail(e, MIBC_ERR_ARG, "no chunks");
+struct VarPlan {
+    size_t b0 = 0, b1 = 0, b2 = 0, off1 = 0, off2 = 0, need = 0;   // smask | tmask | idx blob layout (16-byte aligned parts)
+    int Tmax = 0;
+    std::vector<int> sub_begin;
+};
+static int var_layout(mibc_engine *e, int N, int T_in, int n_chunks, VarPlan *vp) {
+    if (n_chunks <= 0) return fail(e, MIBC_ERR_ARG, "no chunks");
     if (e->is_tx) return fail(e, MIBC_NOT_SUPPORTED, "variable chunks: LSTM models only");
     const int stride = e->stride, T = mibc_output_steps(e, T_in);
     if (T_in % stride != 0 || T != T_in / stride) return fail(e, MIBC_ERR_ARG, "variable chunks: T_in must be a stride multiple");
+    const size_t mw = (size_t)(T_in + 31) / 32, G = (size_t)N / 64;
+    vp->b0 = (size_t)N * mw * 4;
+    vp->b1 = (size_t)T * G * 8;
+    vp->b2 = (size_t)3 * n_chunks * 4;
+    vp->off1 = (vp->b0 + 15) & ~size_t(15);
+    vp->off2 = vp->off1 + ((vp->b1 + 15) & ~size_t(15));
+    vp->need = vp->off2 + vp->b2;
+    return MIBC_OK;
+}
+// Fills the blob (host memory of vp->need bytes, laid out by var_layout): sample bitmap, row-mask words, decoder table.
+static int var_build(mibc_engine *e, int N, int T_in, const mibc_var_chunk *ch, int n_chunks, VarPlan *vp, char *blob) {
+    if (!ch) return fail(e, MIBC_ERR_ARG, "no chunks");
+    const int stride = e->stride, T = mibc_output_steps(e, T_in);
     const int mw = (T_in + 31) / 32, G = N / 64;
     const int nsub = (N + e->Nd - 1) / e->Nd;
-    std::vector<uint32_t> smask((size_t)N * mw, 0u);
-    std::vector<unsigned long long> tmask((size_t)T * G, 0ull);
-    std::vector<int> idx((size_t)3 * n_chunks);
+    memset(blob, 0, vp->off2);
+    uint32_t *smask = (uint32_t *)blob;
+    unsigned long long *tmask = (unsigned long long *)(blob + vp->off1);
+    int *idx = (int *)(blob + vp->off2);
     std::vector<int> row_end((size_t)N, -2);   // last occupied step per row (chunks of a row must come in order)
     std::vector<int> count((size_t)nsub + 1, 0);
     for (int c = 0; c < n_chunks; ++c) {
@@ -1129,7 +1149,7 @@ static int var_setup(mibc_engine *e, int N, int T_in, const mibc_var_chunk *ch, 
         ++count[(size_t)(r / e->Nd) + 1];
     }
     for (int k = 0; k < nsub; ++k) count[(size_t)k + 1] += count[(size_t)k];
-    if (sub_begin) *sub_begin = count;
+    vp->sub_begin = count;
     std::vector<int> next(count.begin(), count.end() - 1);
     std::vector<long> brow((size_t)nsub, 0);
     int Tmax = 0;
@@ -1139,8 +1159,20 @@ static int var_setup(mibc_engine *e, int N, int T_in, const mibc_var_chunk *ch, 
         if (t0 < row_end[r] + 3 && row_end[r] >= 0)
             return fail(e, MIBC_ERR_ARG, "variable chunks: chunks of a row must be ordered and >= 2 steps apart");
         row_end[r] = t0 + Tc - 1;
-        for (int p = s0; p < s0 + L; ++p) smask[(size_t)r * mw + (p >> 5)] |= 1u << (p & 31);
-        for (int t = t0; t < t0 + Tc; ++t) tmask[(size_t)t * G + (r >> 6)] |= 1ull << (r & 63);
+        // bits [s0, s0 + L) of the row's sample bitmap, a word at a time
+        uint32_t *sm = smask + (size_t)r * mw;
+        const int p1 = s0 + L, w0 = s0 >> 5, w1 = (p1 - 1) >> 5;
+        const uint32_t first = 0xffffffffu << (s0 & 31), last = 0xffffffffu >> (31 - ((p1 - 1) & 31));
+        if (w0 == w1) {
+            sm[w0] |= first & last;
+        } else {
+            sm[w0] |= first;
+            for (int w = w0 + 1; w < w1; ++w) sm[w] = 0xffffffffu;
+            sm[w1] |= last;
+        }
+        const unsigned long long rbit = 1ull << (r & 63);
+        unsigned long long *tm = tmask + (size_t)t0 * G + (r >> 6);
+        for (int t = 0; t < Tc; ++t) tm[(size_t)t * G] |= rbit;
         const int k = r / e->Nd, slot = next[(size_t)k]++;
         idx[slot] = (r - k * e->Nd) * T + t0;
         idx[n_chunks + slot] = (int)brow[(size_t)k];
@@ -1151,27 +1183,7 @@ static int var_setup(mibc_engine *e, int N, int T_in, const mibc_var_chunk *ch, 
     for (int k = 0; k < nsub; ++k)
         if (brow[(size_t)k] > (long)e->Nd * (T + 1))
             return fail(e, MIBC_ERR_ARG, "variable chunks: too many chunks for the decode workspace");
-    const size_t b0 = smask.size() * 4, b1 = tmask.size() * 8, b2 = idx.size() * 4;
-    const size_t need = ((b0 + 15) & ~size_t(15)) + ((b1 + 15) & ~size_t(15)) + b2;
-    if (need > e->var_scratch_bytes) {
-        HIP_OK(e, hipStreamSynchronize(e->stream));
-        if (e->var_scratch) (void)hipFree(e->var_scratch);
-        e->var_scratch = nullptr;
-        HIP_OK(e, hipMalloc(&e->var_scratch, need));
-        e->var_scratch_bytes = need;
-    }
-    char *base = (char *)e->var_scratch;
-    char *p1 = base + ((b0 + 15) & ~size_t(15));
-    char *p2 = p1 + ((b1 + 15) & ~size_t(15));
-    // pageable sources: hipMemcpyAsync stages them before returning, so the vectors may die with this frame
-    HIP_OK(e, hipMemcpyAsync(base, smask.data(), b0, hipMemcpyHostToDevice, e->stream));
-    HIP_OK(e, hipMemcpyAsync(p1, tmask.data(), b1, hipMemcpyHostToDevice, e->stream));
-    HIP_OK(e, hipMemcpyAsync(p2, idx.data(), b2, hipMemcpyHostToDevice, e->stream));
-    HIP_OK(e, hipStreamSynchronize(e->stream));
-    e->in_smask = (const uint32_t *)base;
-    e->in_tmask = (const unsigned long long *)p1;
-    e->var_idx = (const int *)p2;
-    *Tmax_out = Tmax;
+    vp->Tmax = Tmax;
     return MIBC_OK;
 }
 
@@ -1181,33 +1193,52 @@ static void var_clear(mibc_engine *e) {
     e->var_idx = nullptr;
     e->in_ss = nullptr;
 }
+static void var_point(mibc_engine *e, const VarPlan &vp, const char *dev_blob, const float *shift_scale_dev) {
+    e->in_smask = (const uint32_t *)dev_blob;
+    e->in_tmask = (const unsigned long long *)(dev_blob + vp.off1);
+    e->var_idx = (const int *)(dev_blob + vp.off2);
+    e->in_ss = shift_scale_dev;
+}
+
+// Synchronous set-up on the engine's stream (mibc_forward_var / mibc_call_device_var / mibc_call_var).
+static int var_setup(mibc_engine *e, int N, int T_in, const mibc_var_chunk *ch, int n_chunks, VarPlan *vp) {
+    int rc = var_layout(e, N, T_in, n_chunks, vp);
+    if (rc != MIBC_OK) return rc;
+    std::vector<char> blob(vp->need);
+    rc = var_build(e, N, T_in, ch, n_chunks, vp, blob.data());
+    if (rc != MIBC_OK) return rc;
+    if (vp->need > e->var_scratch_bytes) {
+        HIP_OK(e, hipStreamSynchronize(e->stream));
+        if (e->var_scratch) (void)hipFree(e->var_scratch);
+        e->var_scratch = nullptr;
+        HIP_OK(e, hipMalloc(&e->var_scratch, vp->need));
+        e->var_scratch_bytes = vp->need;
+    }
+    HIP_OK(e, hipMemcpyAsync(e->var_scratch, blob.data(), vp->need, hipMemcpyHostToDevice, e->stream));
+    HIP_OK(e, hipStreamSynchronize(e->stream));   // pageable source: it dies with this frame
+    return MIBC_OK;
+}
 
 extern "C" int mibc_forward_var(mibc_engine *e, const void *in_dev, const float *shift_scale_dev, int N, int T_in,
                                 const mibc_var_chunk *chunks, int n_chunks, uint16_t *scores_dev) {
     int rc = check_call(e, N, T_in);
     if (rc != MIBC_OK) return rc;
-    int Tmax = 0;
-    rc = var_setup(e, N, T_in, chunks, n_chunks, &Tmax, nullptr);
+    VarPlan vp;
+    rc = var_setup(e, N, T_in, chunks, n_chunks, &vp);
     if (rc != MIBC_OK) return rc;
-    e->in_ss = shift_scale_dev;
+    var_point(e, vp, (const char *)e->var_scratch, shift_scale_dev);
     rc = mibc_forward(e, (const uint16_t *)in_dev, N, T_in, scores_dev);
     var_clear(e);
     return rc;
 }
 
-extern "C" int mibc_call_device_var(mibc_engine *e, const void *in_dev, const float *shift_scale_dev, int N, int T_in,
-                                    const mibc_var_chunk *chunks, int n_chunks, const mibc_decode_opts *o,
-                                    int8_t *out_dev) {
-    if (!o) return MIBC_ERR_ARG;
-    int rc = check_call(e, N, T_in);
-    if (rc != MIBC_OK) return rc;
+// Network + per-chunk decode of a variable-chunk batch whose masks / decoder table are already on their way to dev_blob
+// (in stream order).  (async)
+static int var_run(mibc_engine *e, const void *in_dev, const float *shift_scale_dev, int N, int T_in, int n_chunks,
+                   const VarPlan &vp, const char *dev_blob, const mibc_decode_opts *o, int8_t *out_dev) {
     const int T = mibc_output_steps(e, T_in);
-    int Tmax = 0;
-    std::vector<int> sub_begin;
-    rc = var_setup(e, N, T_in, chunks, n_chunks, &Tmax, &sub_begin);
-    if (rc != MIBC_OK) return rc;
-    e->in_ss = shift_scale_dev;
-    rc = run_encoder(e, (const half_t *)in_dev, N, T_in);
+    var_point(e, vp, dev_blob, shift_scale_dev);
+    int rc = run_encoder(e, (const half_t *)in_dev, N, T_in);
     if (rc == MIBC_OK) {
         // gaps of the output planes stay zero
         if (hipMemsetAsync(out_dev, 0, (size_t)3 * N * T, e->stream) != hipSuccess) rc = MIBC_ERR_HIP;
@@ -1216,11 +1247,11 @@ extern "C" int mibc_call_device_var(mibc_engine *e, const void *in_dev, const fl
     int si = 0;
     for (int n0 = 0; n0 < N && rc == MIBC_OK; n0 += e->Nd, ++si) {
         const int ns = (N - n0 < e->Nd) ? (N - n0) : e->Nd;
-        const int c0 = sub_begin[(size_t)si], nc = sub_begin[(size_t)si + 1] - c0;
+        const int c0 = vp.sub_begin[(size_t)si], nc = vp.sub_begin[(size_t)si + 1] - c0;
         if (nc == 0) continue;
         rc = run_head(e, N, T, n0, ns, e->scores);
         if (rc == MIBC_OK &&
-            mibc_launch_decode_var(e->stream, e->scores, nc, Tmax, e->S, o->beam_width, o->beam_cut, o->blank_score,
+            mibc_launch_decode_var(e->stream, e->scores, nc, vp.Tmax, e->S, o->beam_width, o->beam_cut, o->blank_score,
                                    clamp_value(e), o->q_shift, o->q_scale, e->bwd, e->trace, e->path_state,
                                    out_dev + (size_t)n0 * T, (size_t)N * T, nullptr, e->var_idx + c0,
                                    e->var_idx + n_chunks + c0, e->var_idx + 2 * n_chunks + c0) != 0)
@@ -1234,6 +1265,18 @@ extern "C" int mibc_call_device_var(mibc_engine *e, const void *in_dev, const fl
     e->timed = false;
     HIP_OK(e, hipGetLastError());
     return MIBC_OK;
+}
+
+extern "C" int mibc_call_device_var(mibc_engine *e, const void *in_dev, const float *shift_scale_dev, int N, int T_in,
+                                    const mibc_var_chunk *chunks, int n_chunks, const mibc_decode_opts *o,
+                                    int8_t *out_dev) {
+    if (!o) return MIBC_ERR_ARG;
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    VarPlan vp;
+    rc = var_setup(e, N, T_in, chunks, n_chunks, &vp);
+    if (rc != MIBC_OK) return rc;
+    return var_run(e, in_dev, shift_scale_dev, N, T_in, n_chunks, vp, (const char *)e->var_scratch, o, out_dev);
 }
 
 extern "C" int mibc_call_var(mibc_engine *e, const void *in_host, const float *shift_scale_host, int N, int T_in,
@@ -1251,6 +1294,54 @@ extern "C" int mibc_call_var(mibc_engine *e, const void *in_host, const float *s
     HIP_OK(e, hipMemcpyAsync(out_host, e->out3, (size_t)3 * N * T, hipMemcpyDeviceToHost, e->stream));
     HIP_OK(e, hipStreamSynchronize(e->stream));
     return check_cluster_error(e);
+}
+
+// Two-phase form of mibc_call_var on the slot machinery of mibc_call_async (CudaModelRunner's variable-chunk batches run
+// on the same stream pipeline as fixed ones: basecall/CudaModelRunner.cpp:21-49, CudaCaller.cpp:645-719): the chunk table
+// is turned into the masks / decoder table in a PER-SLOT pinned buffer and copied on the copy stream next to the input
+// rows, so a variable batch overlaps its copies with the kernels of the batch in front of it exactly like a fixed one and
+// two variable batches can be in flight.  chunks_host need not outlive the call.  Completion: mibc_call_poll / _wait.
+extern "C" int mibc_call_var_async(mibc_engine *e, int slot, const void *in_host, const float *shift_scale_host, int N,
+                                   int T_in, const mibc_var_chunk *chunks_host, int n_chunks, const mibc_decode_opts *o,
+                                   int8_t *out_host) {
+    if (!e || !in_host || !out_host || !o || slot < 0 || slot > 1) return MIBC_ERR_ARG;
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    rc = async_prepare(e, slot, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    auto &a = e->aslot[slot];
+    VarPlan vp;
+    rc = var_layout(e, N, T_in, n_chunks, &vp);
+    if (rc != MIBC_OK) return rc;
+    if (a.var_bytes < vp.need) {
+        // (the slot was waited for before this re-submission: nothing of it is in flight)
+        if (a.var_dev) (void)hipFree(a.var_dev);
+        if (a.var_host) (void)hipHostFree(a.var_host);
+        a.var_dev = nullptr; a.var_host = nullptr; a.var_bytes = 0;
+        const size_t cap = vp.need + vp.need / 4;       // the table grows with the number of chunks
+        HIP_OK(e, hipMalloc((void **)&a.var_dev, cap));
+        HIP_OK(e, hipHostMalloc((void **)&a.var_host, cap, hipHostMallocDefault));
+        a.var_bytes = cap;
+    }
+    rc = var_build(e, N, T_in, chunks_host, n_chunks, &vp, a.var_host);
+    if (rc != MIBC_OK) return rc;
+    const int T = mibc_output_steps(e, T_in);
+    HIP_OK(e, hipMemcpyAsync(a.var_dev, a.var_host, vp.need, hipMemcpyHostToDevice, e->s_in));
+    HIP_OK(e, hipMemcpyAsync(a.in, in_host, (size_t)N * T_in * 2, hipMemcpyHostToDevice, e->s_in));
+    if (shift_scale_host)
+        HIP_OK(e, hipMemcpyAsync(a.ss, shift_scale_host, (size_t)N * 2 * sizeof(float), hipMemcpyHostToDevice, e->s_in));
+    HIP_OK(e, hipEventRecord(a.ev_in, e->s_in));
+    HIP_OK(e, hipStreamWaitEvent(e->stream, a.ev_in, 0));
+    e->err_slot = slot;
+    rc = var_run(e, a.in, shift_scale_host ? a.ss : nullptr, N, T_in, n_chunks, vp, a.var_dev, o, a.out3);
+    e->err_slot = 2;
+    if (rc != MIBC_OK) return rc;
+    HIP_OK(e, hipEventRecord(a.ev_done, e->stream));
+    HIP_OK(e, hipStreamWaitEvent(e->s_out, a.ev_done, 0));
+    HIP_OK(e, hipMemcpyAsync(out_host, a.out3, (size_t)3 * N * T, hipMemcpyDeviceToHost, e->s_out));
+    HIP_OK(e, hipEventRecord(a.ev_out, e->s_out));
+    a.n = N;
+    return MIBC_OK;
 }
 
 extern "C" int mibc_get_stage_ms(mibc_engine *e, mibc_stage_ms *out) {

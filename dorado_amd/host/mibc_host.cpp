@@ -412,7 +412,7 @@ void HipCaller::gpu_thread_fn() {
         }
         f.task->cv.notify_one();
     };
-    auto run_sync = [&](NNTask &t) {   // whole call on the engine's stream (variable chunks; retries)
+    auto run_sync = [&](NNTask &t) {   // whole call on the engine's stream (the one synchronous retry of a failed batch)
         std::lock_guard<std::mutex> elk(m_engine_mutex);
         const BatchDims &bd = m_dims.at(t.dims);
         if (t.var)
@@ -445,30 +445,29 @@ void HipCaller::gpu_thread_fn() {
             }
             while (front_is_mine() && (!slot_busy[0] || !slot_busy[1])) {
                 std::shared_ptr<NNTask> task = dq.q.front();
-                if (task->var && !inflight.empty()) break;       // synchronous path: drain first
                 dq.q.pop_front();
                 dq.owner = this;
                 lk.unlock();
                 InFlight f{task, -1, MIBC_OK, false, Clock::now()};
                 // the engine decodes all batch rows (stale rows included), the node uses the first n
                 // (CudaCaller.cpp:269-270, BasecallerNode.cpp:185-189)
-                if (task->var) {
-                    int rc = run_sync(*task);
-                    if (rc != MIBC_OK) rc = run_sync(*task);     // retry once (:698-704)
-                    finish(f, rc);
-                } else {
+                {
+                    // fixed and variable-chunk batches share the two slots (CudaModelRunner.cpp:21-49 runs both on the
+                    // same stream pipeline): the chunk table of a variable batch travels in the slot's own pinned buffer
                     f.slot = slot_busy[0] ? 1 : 0;
                     const BatchDims &bd = m_dims.at(task->dims);
                     {
                         std::lock_guard<std::mutex> elk(m_engine_mutex);
-                        f.rc = mibc_call_async(m_engine, f.slot, task->in, task->ss, bd.N, bd.T_in, &m_opts, task->out);
+                        f.rc = task->var ? mibc_call_var_async(m_engine, f.slot, task->in, nullptr, bd.N, bd.T_in, task->var->data(),
+                                                               int(task->var->size()), &m_opts, task->out)
+                                         : mibc_call_async(m_engine, f.slot, task->in, task->ss, bd.N, bd.T_in, &m_opts, task->out);
                     }
                     slot_busy[f.slot] = true;
                     inflight.push_back(std::move(f));
                 }
                 lk.lock();
             }
-            if (inflight.empty()) continue;   // (a synchronous task just ran) back to the top: release the device, sleep
+            if (inflight.empty()) continue;
         }
         // 2. oldest batch.  While the second slot is free and could be filled, poll (a task arriving meanwhile gets its
         //    copy started at once); otherwise block on the batch's completion event.
@@ -483,12 +482,11 @@ void HipCaller::gpu_thread_fn() {
             bool could_take = false;
             if (slot_free) {
                 std::unique_lock<std::mutex> lk(dq.mut);
-                auto takeable = [&] { return front_is_mine() && dq.q.front()->var == nullptr; };
-                could_take = dq.cv.wait_for(lk, std::chrono::microseconds(200), takeable);
-                if (!could_take && !(front_is_mine() && dq.q.front()->var)) continue;   // keep polling
+                could_take = dq.cv.wait_for(lk, std::chrono::microseconds(200), front_is_mine);
+                if (!could_take) continue;   // keep polling
             }
             if (could_take) continue;
-            // both slots busy, or the next task must wait for the drain anyway: sleep on the event
+            // both slots busy: sleep on the event
             std::lock_guard<std::mutex> elk(m_engine_mutex);
             f.rc = mibc_call_wait(m_engine, f.slot);
             f.waited = true;
@@ -621,7 +619,7 @@ static std::atomic<int> g_runner_id{0};
 
 HipModelRunner::HipModelRunner(std::shared_ptr<HipCaller> caller, size_t batch_dims_idx)
         : m_caller(std::move(caller)), m_dims(batch_dims_idx), m_id(g_runner_id++) {
-    const size_t N = batch_size();
+    const size_t N = rows();
     m_in = static_cast<uint16_t *>(mibc_host_alloc(N * chunk_size() * 2));
     m_out = static_cast<int8_t *>(mibc_host_alloc(3 * N * size_t(m_caller->output_steps(m_dims))));
     m_ss = static_cast<float *>(mibc_host_alloc(N * 2 * sizeof(float)));
@@ -631,7 +629,6 @@ HipModelRunner::HipModelRunner(std::shared_ptr<HipCaller> caller, size_t batch_d
         m_ss[2 * i + 1] = 1.0f;
     }
     std::memset(m_in, 0, N * chunk_size() * 2);
-    m_var_fill.assign(N, 0);
 }
 
 HipModelRunner::~HipModelRunner() {
@@ -640,54 +637,75 @@ HipModelRunner::~HipModelRunner() {
     mibc_host_free(m_ss);
 }
 
-bool HipModelRunner::place_variable_chunk(std::vector<int> &fill, int &cur_row, size_t n, size_t chunk_size, size_t gap,
-                                          int &row, int &start) {
-    const int nrows = int(fill.size());
-    row = -1;
-    for (int r = std::max(0, cur_row - 7); r <= cur_row && r < nrows; ++r)
-        if (size_t(fill[size_t(r)]) + n <= chunk_size) {
-            row = r;
-            break;
-        }
-    if (row < 0 && cur_row + 1 < nrows) row = ++cur_row;
-    if (row < 0) return false;
-    start = fill[size_t(row)];
-    fill[size_t(row)] = int(size_t(start) + n + gap);
+void HipModelRunner::RowPacker::reset(size_t rows, size_t chunk_size, size_t gap) {
+    m_rows = rows;
+    m_cs = chunk_size;
+    m_gap = gap;
+    m_used = 0;
+    m_leaf0 = 1;
+    while (m_leaf0 < rows) m_leaf0 <<= 1;
+    m_fill.assign(rows, 0);
+    m_free.assign(2 * m_leaf0, -1);
+    for (size_t r = 0; r < rows; ++r) m_free[m_leaf0 + r] = int(chunk_size);
+    for (size_t i = m_leaf0 - 1; i >= 1; --i) m_free[i] = std::max(m_free[2 * i], m_free[2 * i + 1]);
+}
+
+bool HipModelRunner::RowPacker::place(size_t n, int &row, int &start) {
+    if (m_rows == 0 || m_free[1] < int(n)) return false;
+    size_t i = 1;
+    while (i < m_leaf0) i = (m_free[2 * i] >= int(n)) ? 2 * i : 2 * i + 1;   // leftmost row with room: first fit
+    const size_t r = i - m_leaf0;
+    if (m_fill[r] == 0) ++m_used;
+    start = m_fill[r];
+    row = int(r);
+    m_fill[r] = int(size_t(start) + n + m_gap);                  // the next chunk of this row starts behind the gap
+    m_free[i] = std::max(0, int(m_cs) - m_fill[r]);
+    for (i >>= 1; i >= 1; i >>= 1) m_free[i] = std::max(m_free[2 * i], m_free[2 * i + 1]);
     return true;
+}
+
+size_t HipModelRunner::batch_size() const {
+    const size_t N = rows();
+    if (!variable_chunk_sizes()) return N;
+    size_t b = size_t(double(N) * double(m_caller->variable_batch_fill()));
+    b = b >= 32 ? b / 32 * 32 : std::max<size_t>(1, b);         // BasecallerNode fills whole 32-row spans (:304, 421-426)
+    return std::min(b, N);
 }
 
 void HipModelRunner::accept_chunk(int idx, const uint16_t *f16, size_t n) {
     if (m_mode == 2) throw std::runtime_error("accept_chunk: this batch already holds raw int16 chunks");
     if (variable_chunk_sizes()) {
-        // pack behind the chunks already accepted (CudaModelRunner.cpp:21-32): next-fit over the last few open rows,
-        // 2 output steps between the chunks of a row
+        // CudaModelRunner::accept_chunk concatenates the chunks into one flat span (CudaModelRunner.cpp:21-32); here they
+        // are packed into the batch ROWS, first-fit, 2 output steps between the chunks of a row (the engine's rows are
+        // independent sequences: a chunk cannot continue on the next row)
         const size_t cs = chunk_size(), stride = size_t(m_caller->model_stride()), gap = 2 * stride;
         if (n == 0 || n > cs || n % stride != 0)
             throw std::runtime_error("accept_chunk: a variable chunk must be a stride multiple of at most chunk_size samples");
         m_mode = 1;
+        if (m_var_table.empty() && m_var_overflow.empty()) m_packer.reset(rows(), cs, gap);
         if (m_var_overflow.empty()) {
             int row = -1, start = 0;
-            if (place_variable_chunk(m_var_fill, m_var_row, n, cs, gap, row, start)) {
+            if (m_packer.place(n, row, start)) {
                 std::memcpy(m_in + size_t(row) * cs + size_t(start), f16, n * 2);
                 m_var_table.push_back({row, start, int(n)});
                 return;
             }
         }
-        // the rows are full although the node's aggregate budget (len / stride + 2 steps per chunk) was not: a chunk
-        // cannot straddle two rows here.  Kept aside and called in a second engine batch by call_chunks; to keep the
-        // result order trivial everything accepted from now on follows it.
+        // no row has room although the node's budget (batch_size() rows' worth of len / stride + 2 steps) was not used up:
+        // a chunk cannot straddle two rows here.  Kept aside and called in a second engine batch by call_chunks (counted:
+        // var_overflow_batches); to keep the result order trivial everything accepted from now on follows it.
         m_var_overflow.push_back({0, 0, int(n)});
         m_var_overflow_data.emplace_back(f16, f16 + n);
         return;
     }
-    if (idx < 0 || idx >= int(batch_size()) || n != chunk_size())
+    if (idx < 0 || idx >= int(rows()) || n != chunk_size())
         throw std::runtime_error("accept_chunk: bad index or chunk length");
     m_mode = 1;
     std::memcpy(m_in + size_t(idx) * n, f16, n * 2);
 }
 
 void HipModelRunner::accept_chunk_i16(int idx, const int16_t *raw, size_t n, float shift, float scale) {
-    if (idx < 0 || idx >= int(batch_size()) || n != chunk_size())
+    if (idx < 0 || idx >= int(rows()) || n != chunk_size())
         throw std::runtime_error("accept_chunk_i16: bad index or chunk length");
     if (m_mode == 1) throw std::runtime_error("accept_chunk_i16: this batch already holds scaled f16 chunks");
     m_mode = 2;
@@ -704,17 +722,15 @@ std::vector<DecodedChunk> HipModelRunner::call_chunks(int num_chunks) {
         if (size_t(num_chunks) != m_var_table.size() + m_var_overflow.size())
             throw std::runtime_error("call_chunks: num_chunks differs from the number of accepted chunks");
         std::vector<DecodedChunk> res;
-        auto reset = [&] {
-            m_var_table.clear();
-            std::fill(m_var_fill.begin(), m_var_fill.end(), 0);
-            m_var_row = 0;
-        };
         while (true) {
             auto part = m_caller->call_chunks_var(m_dims, m_in, m_out, m_var_table);
             for (auto &d : part) res.push_back(std::move(d));
-            reset();
+            ++m_var_batches;
+            m_var_rows_used += int64_t(m_packer.rows_used());
+            m_var_table.clear();
             if (m_var_overflow.empty()) break;
-            // second engine batch for what did not fit (rare: see accept_chunk)
+            // second engine batch for what did not fit (see accept_chunk and batch_size())
+            ++m_var_overflow_batches;
             std::vector<std::vector<uint16_t>> data;
             data.swap(m_var_overflow_data);
             m_var_overflow.clear();
@@ -740,6 +756,11 @@ std::string HipModelRunner::get_name() const {  // unique per instance (CudaMode
 NamedStats HipModelRunner::sample_stats() const {
     NamedStats s = m_caller->sample_stats();
     s["runner_batches_called"] = double(m_batches.load());
+    if (variable_chunk_sizes()) {
+        s["var_engine_batches"] = double(m_var_batches.load());
+        s["var_overflow_batches"] = double(m_var_overflow_batches.load());
+        s["var_rows_used"] = double(m_var_rows_used.load());
+    }
     return s;
 }
 
@@ -1026,7 +1047,7 @@ std::vector<CalledRead> SimplexBasecaller::basecall_variable(const std::vector<s
     auto worker = [&](ModelRunnerBase *base, std::atomic<bool> &failed) {
         auto *runner = dynamic_cast<HipModelRunner *>(base);
         if (!runner) throw std::runtime_error("variable chunk sizes need a HipModelRunner");
-        const size_t batch = runner->batch_size();
+        const size_t batch = runner->rows();   // this path packs the rows itself: all of them are its budget
         while (!failed.load()) {
             // fill the rows first-fit in queue order (one lock per batch)
             std::vector<Work> mine;
@@ -1416,13 +1437,14 @@ int mibch_basecall_reads(const mibc_model_desc *desc, const float *const *weight
 // test hook (CPU, no device): place `n` chunk lengths (samples) with HipModelRunner's packer into `rows` batch rows of
 // `chunk_size` samples, `gap` samples between the chunks of a row; out_row / out_start per chunk (-1 = did not fit).
 int mibch_debug_pack_rows(const int *lens, int n, int rows, int chunk_size, int gap, int *out_row, int *out_start) {
-    std::vector<int> fill(size_t(rows), 0);
-    int cur = 0, placed = 0;
+    HipModelRunner::RowPacker pk;
+    pk.reset(size_t(rows), size_t(chunk_size), size_t(gap));
+    int placed = 0;
     bool overflow = false;
     for (int i = 0; i < n; ++i) {
         int row = -1, start = 0;
         // as in accept_chunk: once one chunk has overflowed, everything behind it follows it (result order)
-        if (!overflow && HipModelRunner::place_variable_chunk(fill, cur, size_t(lens[i]), size_t(chunk_size), size_t(gap), row, start)) {
+        if (!overflow && pk.place(size_t(lens[i]), row, start)) {
             out_row[i] = row;
             out_start[i] = start;
             ++placed;

@@ -142,6 +142,11 @@ struct CallerParams {
     bool run_batchsize_benchmarks = false; // true: the reference's timing sweep; false: the engine's known knee
     bool emit_batchsize_benchmarks = false;// print the sweep's (batch, ms per chunk) table to stderr
     bool variable_chunk_sizes = false;     // runners pack several chunks per batch row (CudaModelRunner.cpp:21-49)
+    // variable chunk sizes: fraction of the batch rows' samples a runner offers BasecallerNode as its batch budget.  The
+    // node packs a 1-D span (a chunk may straddle rows), this engine packs rows: with first-fit packing 0.85 still fits on
+    // read sets whose chunks are mostly 0.5-1.0 of chunk_size (simulated); what does not fit costs a second
+    // engine call (counted in sample_stats: var_overflow_batches).
+    float variable_batch_fill = 0.8f;
 };
 
 struct BatchDims {  // CudaCaller::BatchDims (basecall/include/basecall/CudaCaller.h): batch, samples, output steps
@@ -183,6 +188,7 @@ public:
     int output_steps(size_t dims = 0) const { return m_dims.at(dims).T_out; }
     int device() const { return m_device; }
     bool variable_chunk_sizes() const { return m_params.variable_chunk_sizes; }
+    float variable_batch_fill() const { return m_params.variable_batch_fill; }
     std::pair<int, int> batch_timeouts_ms() const { return {300000, 30000}; }  // CudaCaller.cpp:126-132
     NamedStats sample_stats() const;
     std::string get_name() const { return "HipCaller_hip:" + std::to_string(m_device); }
@@ -247,7 +253,10 @@ public:
     bool variable_chunk_sizes() const override { return m_caller->variable_chunk_sizes(); }
     const mibc_model_desc &config() const override { return m_caller->config(); }
     size_t chunk_size() const override { return size_t(m_caller->chunk_size(m_dims)); }
-    size_t batch_size() const override { return size_t(m_caller->batch_size(m_dims)); }
+    // Fixed chunks: the rows of the engine batch.  Variable chunk sizes: the budget BasecallerNode may fill
+    // (batch_size() * (chunk_size / stride + 2) steps, BasecallerNode.cpp:303) = rows() * CallerParams::variable_batch_fill
+    // rounded down to the node's 32-row spans, so that the chunks it hands over fit the rows without a second engine call.
+    size_t batch_size() const override;
     std::pair<int, int> batch_timeouts_ms() const override { return m_caller->batch_timeouts_ms(); }
     void terminate() override { m_caller->terminate(); }
     void restart() override { m_caller->restart(); }
@@ -266,17 +275,29 @@ private:
     std::atomic<int64_t> m_batches{0};
     // variable-chunk packing state of the batch being filled
   public:
-    // Row placement of one variable-length chunk (pure; tests/test_host_cpu.py drives it through mibch_debug_pack_rows):
-    // next-fit over the current row and the seven before it, else the next empty row; fill[] = samples used per row incl.
-    // the `gap` behind its last chunk.  Returns false when no row can take n samples (the caller's overflow path).
-    static bool place_variable_chunk(std::vector<int> &fill, int &cur_row, size_t n, size_t chunk_size, size_t gap, int &row,
-                                     int &start);
+    // Row placement of variable-length chunks: FIRST-FIT over all rows of the batch (a max-free-space tree makes it
+    // O(log rows) per chunk).  A chunk cannot straddle two rows here (rows are independent sequences of the time-major
+    // LSTM kernels), whereas BasecallerNode budgets the batch as 32-row spans of steps (BasecallerNode.cpp:303-305,
+    // 421-426), so what the node calls a full batch only fits when the rows pack well: see batch_size().
+    class RowPacker {
+    public:
+        void reset(size_t rows, size_t chunk_size, size_t gap);
+        // places n samples; false when no row has room (the caller's overflow path).  start = first sample in the row.
+        bool place(size_t n, int &row, int &start);
+        size_t rows_used() const { return m_used; }
+
+    private:
+        std::vector<int> m_free;   // tree of max free samples (a row's free space counts the gap it must leave in front)
+        std::vector<int> m_fill;   // samples used per row incl. its chunks' trailing gaps
+        size_t m_rows = 0, m_leaf0 = 1, m_cs = 0, m_gap = 0, m_used = 0;
+    };
+    size_t rows() const { return size_t(m_caller->batch_size(m_dims)); }   // batch rows of the engine call
 
   private:
     std::vector<mibc_var_chunk> m_var_table, m_var_overflow;
     std::vector<std::vector<uint16_t>> m_var_overflow_data;
-    std::vector<int> m_var_fill;   // samples used per row (incl. the gap behind the last chunk)
-    int m_var_row = 0;
+    RowPacker m_packer;
+    std::atomic<int64_t> m_var_batches{0}, m_var_overflow_batches{0}, m_var_rows_used{0};
 };
 
 // Samples per output step: product of the conv strides, divided by the upsample factor of the transformer models

@@ -197,6 +197,12 @@ MIBC_API int mibc_call_device_var(mibc_engine *e, const void *in_dev, const floa
                          int8_t *out_dev);
 MIBC_API int mibc_call_var(mibc_engine *e, const void *in_host, const float *shift_scale_host, int N, int T_in,
                   const mibc_var_chunk *chunks_host, int n_chunks, const mibc_decode_opts *opts, int8_t *out_host);
+/* Two-phase form of mibc_call_var on the slots of mibc_call_async (same rules: pinned in_host / out_host, one submission
+ * per slot until mibc_call_wait; fixed and variable batches may be mixed across the two slots).  The reference runs its
+ * variable-chunk batches on the same stream pipeline as the fixed ones (basecall/CudaModelRunner.cpp:21-49,
+ * CudaCaller.cpp:645-719).  chunks_host is consumed before the call returns. */
+MIBC_API int mibc_call_var_async(mibc_engine *e, int slot, const void *in_host, const float *shift_scale_host, int N, int T_in,
+                        const mibc_var_chunk *chunks_host, int n_chunks, const mibc_decode_opts *opts, int8_t *out_host);
 
 /* ---- POD5 signal decode ----
  * The reference obtains a read's int16 samples from pod5_get_read_complete_signal

@@ -337,8 +337,12 @@ def test_variable_chunk_row_packer_properties():
             for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
                 assert b0 - a1 >= gap                                      # >= 2 output steps between chunks of a row
             assert all(a1 <= cs and a0 % stride == 0 for a0, a1 in spans)
-        # next-fit with look-back: a chunk never lands more than 7 rows behind the newest row in use at its time
-        newest = np.maximum.accumulate(out_row[:first_bad]) if first_bad else np.zeros(0)
-        assert ((newest - out_row[:first_bad]) <= 7).all()
-        if first_bad < n:                                                  # it really did not fit anywhere allowed
-            assert newest[-1] == rows - 1
+        # first fit over ALL rows: when chunk i was placed, no row in front of its own had room for it
+        fill = np.zeros(rows, np.int64)
+        for i in range(first_bad):
+            for r in range(int(out_row[i])):
+                assert fill[r] + lens[i] > cs
+            assert out_start[i] == fill[out_row[i]]
+            fill[out_row[i]] = out_start[i] + lens[i] + gap
+        if first_bad < n:                                                  # it really did not fit anywhere
+            assert (fill + lens[first_bad] > cs).all()
