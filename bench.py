@@ -453,6 +453,30 @@ def main():
                 line["through_host_multi_chunk_reads"] = th5
             except Exception as ex:
                 line["through_host"] = {"error": repr(ex)}
+            if cfg.tx is None:
+                # variable chunk sizes through the host layer (mibc_call_var_async, two variable batches in
+                # flight): a read set with a realistic length spread (log-normal, median 6 k samples, + a tail of short
+                # reads — tools/variable_chunks_bench.py), against the SAME reads through the fixed-chunk path
+                try:
+                    from dorado_amd import hostapi
+                    rng = np.random.default_rng(0)
+                    nrd = 9 * n
+                    lens = np.concatenate([np.exp(rng.normal(np.log(6000), 0.9, 2 * nrd // 3)),
+                                           rng.uniform(300, 3000, nrd - 2 * nrd // 3)])
+                    lens = np.clip(lens, 200, 60000).astype(np.int64)
+                    rng.shuffle(lens)
+                    sigs = synth.make_signal(64, int(lens.max()), seed=79)
+                    nwarm = nrd // 4
+                    tv = hostapi.bench_through_host_variable(cfg, ws, sigs, lens, nwarm, device=args.host_device or f"hip:{local_rank}",
+                                                             num_runners=2, batch_size=n)
+                    tv["useful_fill"] = tv["samples_per_s"] / tv["samples_incl_padding_per_s"]
+                    tv["what"] = (f"{len(lens) - nwarm} reads, lengths log-normal(median 6000, sigma 0.9) + uniform 300..3000, "
+                                  f"{float(lens[nwarm:].mean()):.0f} samples on average, cut by generate_variable_chunks, first-fit "
+                                  f"row packing, mibc_call_var_async with two batches in flight; samples_per_s = read samples "
+                                  f"(useful), samples_incl_padding_per_s = batch rows x chunk size")
+                    line["through_host_variable"] = tv
+                except Exception as ex:
+                    line["through_host_variable"] = {"error": repr(ex)}
     # the two sup configurations of BASELINE.json: full objects at N = 1, whole-job weak-scaling rates at N > 1
     if args.also_sup and args.model == "hac":
         extra = {}

@@ -362,6 +362,49 @@ class Engine:
                 L.mibc_host_free(p)
         return res
 
+    def call_two_slots_mixed(self, batches):
+        """batches: list of (x_rows [N, T_in] f16, chunks) with chunks = None (fixed batch: mibc_call_async) or
+        [(row, sample_start, n_samples)] (variable batch: mibc_call_var_async), alternating over the two slots, two in
+        flight.  Returns per batch the raw output planes int8 [3][N][T]."""
+        L = lib()
+        L.mibc_call_var_async.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                          C.POINTER(DecodeOptsC), C.c_void_p]
+        xs = [np.ascontiguousarray(b[0], np.float16) for b in batches]
+        n, t_in = xs[0].shape
+        t = self.output_steps(t_in)
+        self.reserve(n, t_in)
+        pin_in = [L.mibc_host_alloc(n * t_in * 2) for _ in range(2)]
+        pin_out = [L.mibc_host_alloc(3 * n * t) for _ in range(2)]
+        res = [None] * len(xs)
+        try:
+            def submit(i):
+                s = i & 1
+                C.memmove(pin_in[s], xs[i].ctypes.data, xs[i].nbytes)
+                ch = batches[i][1]
+                if ch is None:
+                    self._check(L.mibc_call_async(self._h, s, pin_in[s], None, n, t_in, C.byref(self.opts), pin_out[s]),
+                                "mibc_call_async")
+                else:
+                    arr = self._var_chunks(ch)      # consumed before the call returns
+                    self._check(L.mibc_call_var_async(self._h, s, pin_in[s], None, n, t_in, arr, len(ch), C.byref(self.opts),
+                                                      pin_out[s]), "mibc_call_var_async")
+
+            def collect(i):
+                s = i & 1
+                self._check(L.mibc_call_wait(self._h, s), "mibc_call_wait")
+                res[i] = np.frombuffer((C.c_int8 * (3 * n * t)).from_address(pin_out[s]), np.int8).reshape(3, n, t).copy()
+
+            for i in range(len(xs)):
+                if i >= 2:
+                    collect(i - 2)
+                submit(i)
+            for i in range(max(0, len(xs) - 2), len(xs)):
+                collect(i)
+        finally:
+            for p in pin_in + pin_out:
+                L.mibc_host_free(p)
+        return res
+
     # -- f1: ScalerNode on the device (raw int16 in)
     def call_i16(self, x_i16: np.ndarray, shift_scale: np.ndarray):
         """Host batch of RAW int16 chunks + one (shift, scale) per chunk -> decoded chunks

@@ -1049,36 +1049,31 @@ std::vector<CalledRead> SimplexBasecaller::basecall_variable(const std::vector<s
         if (!runner) throw std::runtime_error("variable chunk sizes need a HipModelRunner");
         const size_t batch = runner->rows();   // this path packs the rows itself: all of them are its budget
         while (!failed.load()) {
-            // fill the rows first-fit in queue order (one lock per batch)
+            // fill the rows first-fit (RowPacker) in queue order until a chunk finds no row (one lock per batch)
             std::vector<Work> mine;
             std::vector<mibc_var_chunk> table;
             {
                 std::lock_guard<std::mutex> lk(qmut);
-                size_t row = 0, fill = 0;
+                HipModelRunner::RowPacker pk;
+                pk.reset(batch, chunk_size, gap);
                 while (!queue.empty()) {
                     const Work w = queue.front();
                     const size_t padded = (w.len + stride - 1) / stride * stride;   // BasecallerNode.cpp:408-416
-                    size_t start = fill ? fill + gap : 0;
-                    if (start + padded > chunk_size) {
-                        ++row;
-                        fill = 0;
-                        start = 0;
-                    }
-                    if (row >= batch) break;
+                    int row = -1, start = 0;
+                    if (!pk.place(padded, row, start)) break;
                     queue.pop_front();
                     mine.push_back(w);
-                    table.push_back({int(row), int(start), int(padded)});
-                    fill = start + padded;
+                    table.push_back({row, start, int(padded)});
                 }
             }
             if (mine.empty()) return;
-            for (size_t r = 0; r < batch; ++r) std::memset(runner->batch_row(int(r)), 0, chunk_size * 2);
+            // (no clearing of the pinned rows: samples outside every chunk are ignored by the engine's sample bitmap)
             for (size_t k = 0; k < mine.size(); ++k) {
                 const uint16_t *src = reads[mine[k].read].data() + mine[k].offset;
                 uint16_t *dst = runner->batch_row(table[k].row) + table[k].sample_start;
                 for (size_t p = 0; p < size_t(table[k].n_samples); ++p) dst[p] = src[p % mine[k].len];
             }
-            // rows must be presented in (row, start) order: they are, by construction
+            // the chunks of a row appear in the table in ascending start order (first fit appends to a row)
             auto decoded = runner->call_chunks_var(table);
             ++m_batches;
             m_samples_incl_padding += int64_t(batch * chunk_size);
@@ -1207,6 +1202,53 @@ int mibch_basecall_reads_variable(const mibc_model_desc *desc, const float *cons
         auto called = node->basecall_variable(reads);
         write_outputs(called, *node, {seq_out, qstr_out, seq_len_out, moves_out, moves_len_out, offsets_out,
                                       n_offsets_out, stats4});
+        return 0;
+    } catch (const std::exception &e) {
+        g_herr = e.what();
+        return -1;
+    }
+}
+
+// Throughput of the variable-chunk host path (bench.py through_host_variable): reads of the given lengths (cycled over
+// n_distinct signals) through SimplexBasecaller::basecall_variable — generate_variable_chunks, first-fit row packing,
+// mibc_call_var_async with two batches in flight per device, slicing, stitching.  n_warm reads first (untimed).
+// out8 = {read samples/s, seconds, engine batches, bases, batch rows x chunk size per second, devices, 0, 0}.
+int mibch_bench_through_host_variable(const mibc_model_desc *desc, const float *const *weights, int n_weights,
+                                      const char *device_string, int num_runners, int chunk_size, int overlap, int batch_size,
+                                      const mibc_decode_opts *opts, const uint16_t *signals, int n_distinct, int64_t sig_len,
+                                      const int64_t *read_len, int64_t n_warm, int64_t n_reads, double *out8) {
+    try {
+        auto node = make_node(desc, weights, n_weights, device_string, num_runners, chunk_size, overlap, batch_size, opts);
+        auto make_reads = [&](int64_t first, int64_t count) {
+            std::vector<std::vector<uint16_t>> reads(static_cast<size_t>(count));
+            for (int64_t r = 0; r < count; ++r) {
+                const int64_t L = std::min<int64_t>(read_len[first + r], sig_len);
+                const uint16_t *src = signals + size_t((first + r) % n_distinct) * size_t(sig_len);
+                reads[size_t(r)].assign(src, src + L);
+            }
+            return reads;
+        };
+        if (n_warm > 0) (void)node->basecall_variable(make_reads(0, n_warm));
+        auto reads = make_reads(n_warm, n_reads);
+        double total = 0;
+        for (auto &r : reads) total += double(r.size());
+        auto st0 = node->sample_stats();
+        const auto t0 = std::chrono::steady_clock::now();
+        auto called = node->basecall_variable(reads);
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        auto st1 = node->sample_stats();
+        size_t bases = 0;
+        for (auto &c : called) bases += c.seq.size();
+        std::vector<int> ids;
+        std::string err;
+        (void)try_parse_device_ids(device_string, size_t(mibc_device_count()), ids, err);
+        out8[0] = total / sec;
+        out8[1] = sec;
+        out8[2] = st1["batches_called"] - st0["batches_called"];
+        out8[3] = double(bases);
+        out8[4] = (st1["samples_incl_padding"] - st0["samples_incl_padding"]) / sec;
+        out8[5] = double(ids.size());
+        out8[6] = out8[7] = 0.0;
         return 0;
     } catch (const std::exception &e) {
         g_herr = e.what();

@@ -228,3 +228,40 @@ def test_host_layer_variable_chunks_vs_reference_order_of_operations():
         assert got[r][0] == want[0] and got[r][1] == want[1] and (got[r][2] == want[2]).all()
     eng.close()
     assert sum(len(g[0]) for g in got) > 1000
+
+
+@pytest.mark.gpu
+def test_variable_batches_on_the_two_slot_path_equal_synchronous_calls():
+    """mibc_call_var_async: variable-chunk batches (different chunk tables) and fixed batches alternate over the two async
+    slots with two in flight — every batch's output planes must equal the synchronous mibc_call_var / mibc_call of the
+    same batch, byte for byte (the chunk table travels in the slot's own pinned buffer, nothing engine-wide)."""
+    cfg = config.tiny(128, 4)
+    cfg.lstm_layers = 3
+    ws = synth.make_weights(cfg, seed=77)
+    stride, t_in, N = cfg.stride, 1206, 64
+    rng = np.random.default_rng(11)
+    batches = []
+    for b in range(6):
+        X = synth.make_signal(N, t_in, seed=700 + b)
+        if b % 3 == 2:
+            batches.append((X, None))                      # a fixed batch between the variable ones
+            continue
+        lengths = [int(v) * stride for v in rng.integers(4, t_in // stride, 60 + 7 * b)]
+        chunks, _ = _pack(lengths, t_in, stride, N) if sum(lengths) < N * t_in // 2 else _pack(lengths[:40], t_in, stride, N)
+        batches.append((X, chunks))
+    eng = capi.Engine(cfg, ws)
+    got = eng.call_two_slots_mixed(batches)
+    L = capi.lib()
+    T = eng.output_steps(t_in)
+    for (X, chunks), g in zip(batches, got):
+        want = np.zeros((3, N, T), np.int8)
+        x = np.ascontiguousarray(X, np.float16)
+        if chunks is None:
+            rc = L.mibc_call(eng._h, x.ctypes.data, N, t_in, capi.C.byref(eng.opts), want.ctypes.data)
+        else:
+            arr = eng._var_chunks(chunks)
+            rc = L.mibc_call_var(eng._h, x.ctypes.data, None, N, t_in, arr, len(chunks), capi.C.byref(eng.opts), want.ctypes.data)
+        assert rc == 0
+        assert (g == want).all()
+        assert g[0].sum() > 0
+    eng.close()
