@@ -105,6 +105,10 @@ class ModelConfig:
     name: str = "synthetic"
     tx: Optional[TxParams] = None
     lstm_quant: bool = False   # opt-in: the reference's int8 LSTM path (nn/LSTMStack.cpp:127-211), csrc/lstm_q8.hip
+    # synthetic weights only (dorado_amd/synth.py; no effect on a loaded model): gain on the transformer's CRF projection.
+    # With gain 1 the random-init sup@v5 model calls NO base with q >= 10 (nothing discriminating to compare identities
+    # on); gain 3 gives decision margins: 48 % of the reference's bases at q >= 10, 18 % at q >= 20 (scores +-27).
+    synth_crf_gain: float = 1.0
 
     @property
     def is_tx(self) -> bool:
@@ -265,7 +269,7 @@ def sup_v50() -> ModelConfig:
             ConvParams(128, 512, 5, 2, ACT_SWISH),
         ],
         lstm_size=0, lstm_layers=0, state_len=5, clamp=False, tx=TxParams(),
-        chunk_size=12288, overlap=600, name="dna_r10.4.1_e8.2_400bps_sup@v5.0.0",
+        chunk_size=12288, overlap=600, name="dna_r10.4.1_e8.2_400bps_sup@v5.0.0", synth_crf_gain=3.0,
     )
     cfg.normalise_basecaller_params()
     return cfg

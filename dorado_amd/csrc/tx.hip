@@ -14,8 +14,13 @@
 //   residual_rmsnorm_kernel  x <- RMSNorm(in + alpha * x) * w  (nn/TxModules.cpp:881, nn/RMSNorm.cpp:14-18;
 //                          replaces host_fused_residual_rmsnorm_f16, :875)
 #include "common.h"
+#include <type_traits>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
 
 typedef float float4a __attribute__((ext_vector_type(4)));
+typedef float float2a __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------
 template <int C1>
@@ -483,86 +488,123 @@ __global__ __launch_bounds__(512) void window_attention_v3_kernel(
             qn[1] = qf[1];
         }
 
-        // ---- this tile (v2's arithmetic; staged tile w + i lives in ring slots ((k0 + (w + i) * 16) & 511) ..) ----
+        // ---- this tile; staged key tile w + i lives in ring slots ((k0 + (w + i) * 16) & 511) .. ----
+        // Round 4: the softmax was 15 VALU instructions per score (5.2 k of the 8.1 k cycles of a wave tile, 4.7x its 72
+        // MFMAs).  Now: (a) with the standard window (127 | 128, back 128) key tiles 1 .. 15 are visible to all 16 queries
+        // of the wave, tile 17 to none: masks are evaluated on tiles 0 and 16 only, tile 17 is skipped (QK^T, exp and its
+        // half of the last PV step) — except in waves that touch a chunk end, which mask every tile; (b) a mask is one
+        // unsigned compare ((c - lo) <= span, c a compile-time constant per element); (c) scale, log2(e) and the row
+        // maximum go into ONE packed fma per two scores and the exponential is the bare v_exp_f32 (2^x); (d) maxima by
+        // v_max3, sums by packed adds, f16 conversion by pairs; (e) the 1 / sum normalisation moves from the 72
+        // probabilities to the 16 outputs of a lane (probabilities enter the PV product unnormalised, in (0, 1]).
         const int qi = q0 + wave * 16 + l15;
-        float4a sc[KW];
-#pragma unroll
-        for (int i = 0; i < KW; ++i) {
-            float4a acc = (float4a)(0.0f);
-            const int slot = (k0 + (wave + i) * 16) & (RING - 1);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const half8_t kf = *(const half8_t *)(Ks + (slot + l15) * KLD + kb * 32 + 8 * lq);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kb], acc, 0, 0, 0);
-            }
-            sc[i] = acc;
-        }
+        const int qbase = q0 + wave * 16;
+        constexpr bool STD = (KW == 18);   // launcher: KW = 18 only for win_upper 127, win_lower 128, back 128 (see below)
+        const bool stdwin = STD && win_upper == 127 && win_lower == 128 && back == 128;
+        const bool edge = !stdwin || (qbase - back < 0) || (qbase + 15 + win_lower > T - 1);
         const int qe = min(T, (qi / split + 1) * split);
         const int jmax = min(min(qi + win_lower, T - 1), qe + win_upper - 1);
         const int jmin = max(qi - win_upper, 0);
         const int jbase = k0 + wave * 16 + 4 * lq;
-        float m = -3.0e38f;
+        const int lo = jmin - jbase;
+        const unsigned span = (unsigned)(jmax - jmin);
+        auto tile_body = [&](auto allmask_c) __attribute__((always_inline)) {
+            constexpr bool ALLMASK = decltype(allmask_c)::value;
+            constexpr int NT = ALLMASK ? KW : 17;          // key tiles that can hold a visible key
+            float4a sc[KW];
 #pragma unroll
-        for (int i = 0; i < KW; ++i)
+            for (int i = 0; i < NT; ++i) {
+                float4a acc = (float4a)(0.0f);
+                const int slot = (k0 + (wave + i) * 16) & (RING - 1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = jbase + i * 16 + r;
-                const bool vis = (j >= jmin) && (j <= jmax);
-                const float v = vis ? sc[i][r] * 0.125f : -3.0e38f;
-                sc[i][r] = v;
-                m = fmaxf(m, v);
-            }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float sum = 0.0f;
-#pragma unroll
-        for (int i = 0; i < KW; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = (sc[i][r] > -1.0e38f) ? __expf(sc[i][r] - m) : 0.0f;
-                sc[i][r] = e;
-                sum += e;
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-        float4a oacc[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) oacc[dt] = (float4a)(0.0f);
-#pragma unroll
-        for (int blk = 0; blk < KW / 2; ++blk) {
-            half8_t pf;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                pf[i] = (half_t)(sc[2 * blk][i] * inv);
-                pf[4 + i] = (half_t)(sc[2 * blk + 1][i] * inv);
-            }
-            const int s0 = (k0 + (wave + 2 * blk) * 16) & (RING - 1);
-            const int s1 = (k0 + (wave + 2 * blk + 1) * 16) & (RING - 1);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const half_t *vp = Vt + (dt * 16 + l15) * VLD + 4 * lq;
-                const half4_t v0 = *(const half4_t *)(vp + s0);
-                const half4_t v1 = *(const half4_t *)(vp + s1);
-                half8_t vf;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    vf[i] = v0[i];
-                    vf[4 + i] = v1[i];
+                for (int kb = 0; kb < 2; ++kb) {
+                    const half8_t kf = *(const half8_t *)(Ks + (slot + l15) * KLD + kb * 32 + 8 * lq);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kb], acc, 0, 0, 0);
                 }
-                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
+                sc[i] = acc;
             }
-        }
-        {
+            const float NEG = -__builtin_inff();
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                if (!ALLMASK && i != 0 && i != 16) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool vis = (unsigned)(i * 16 + r - lo) <= span;
+                    sc[i][r] = vis ? sc[i][r] : NEG;
+                }
+            }
+            float m = NEG;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                m = fmaxf(fmaxf(sc[i][0], sc[i][1]), m);
+                m = fmaxf(fmaxf(sc[i][2], sc[i][3]), m);
+            }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            // p = 2^(s * c - m * c), c = log2(e) / sqrt(64)
+            const float cs = 0.125f * 1.44269504088896340736f;
+            const float2a c2 = {cs, cs};
+            const float nm = -m * cs;
+            const float2a nm2 = {nm, nm};
+            float2a sum2 = {0.0f, 0.0f};
+            half2_t ph[KW][2];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int hp = 0; hp < 2; ++hp) {
+                    const float2a s2 = {sc[i][2 * hp], sc[i][2 * hp + 1]};
+                    const float2a t2 = __builtin_elementwise_fma(s2, c2, nm2);
+                    float2a e2;
+                    e2[0] = __builtin_amdgcn_exp2f(t2[0]);
+                    e2[1] = __builtin_amdgcn_exp2f(t2[1]);
+                    sum2 += e2;
+                    ph[i][hp] = __builtin_convertvector(e2, half2_t);
+                }
+            float sum = sum2[0] + sum2[1];
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = __builtin_amdgcn_rcpf(sum);
+            float4a oacc[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt] = (float4a)(0.0f);
+#pragma unroll
+            for (int blk = 0; blk < (NT + 1) / 2; ++blk) {
+                const bool second = (2 * blk + 1 < NT);     // the standard window ends on a single tile (16)
+                half8_t pf;
+                pf[0] = ph[2 * blk][0][0]; pf[1] = ph[2 * blk][0][1]; pf[2] = ph[2 * blk][1][0]; pf[3] = ph[2 * blk][1][1];
+                if (second) {
+                    pf[4] = ph[2 * blk + 1][0][0]; pf[5] = ph[2 * blk + 1][0][1]; pf[6] = ph[2 * blk + 1][1][0]; pf[7] = ph[2 * blk + 1][1][1];
+                } else {
+                    pf[4] = pf[5] = pf[6] = pf[7] = (half_t)0.0f;
+                }
+                const int s0 = (k0 + (wave + 2 * blk) * 16) & (RING - 1);
+                const int s1 = (k0 + (wave + 2 * blk + 1) * 16) & (RING - 1);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const half_t *vp = Vt + (dt * 16 + l15) * VLD + 4 * lq;
+                    const half4_t v0 = *(const half4_t *)(vp + s0);
+                    half4_t v1 = {(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+                    if (second) v1 = *(const half4_t *)(vp + s1);
+                    half8_t vf;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        vf[i] = v0[i];
+                        vf[4 + i] = v1[i];
+                    }
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
+                }
+            }
             half_t *orow = out + (row0 + qi) * C + h * 64;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 half4_t o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (half_t)oacc[dt][r];
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)(oacc[dt][r] * inv);
                 *(half4_t *)(orow + dt * 16 + 4 * lq) = o;
             }
-        }
+        };
+        if (edge) tile_body(std::true_type{});
+        else tile_body(std::false_type{});
         // ---- the new keys overwrite slots of keys < k0 + 128 + ... that this tile still read: barrier on both sides ----
         __syncthreads();
         if (more) {
@@ -672,7 +714,8 @@ extern "C" int mibc_launch_residual_rmsnorm(hipStream_t s, const half_t *in, hal
 // Returns 0 and the number of differing output halfs, the two timings (ms per launch).
 #include <vector>
 MIBC_HOOK int mibc_debug_attention_compare(int N, int T, int H, int win_upper, int win_lower, int iters,
-                                            long long *ndiff, float *ms_ring, float *ms_restage) {
+                                            long long *ndiff, float *ms_ring, float *ms_restage, float *err_ring,
+                                            float *err_restage) {
     const int C = H * 64, ld = 2 * C;
     uint32_t seed = 777u + (uint32_t)(N + 3 * T + 7 * H);
     auto lcg = [&]() {
@@ -716,6 +759,39 @@ MIBC_HOOK int mibc_debug_attention_compare(int N, int T, int H, int win_upper, i
         (void)hipMemcpy(a.data(), o1, ob, hipMemcpyDeviceToHost);
         (void)hipMemcpy(b.data(), o2, ob, hipMemcpyDeviceToHost);
         for (size_t i = 0; i < a.size(); ++i) nd += (a[i] != b[i]);
+        // both kernels against a host f64 restatement of nn/TxModules.cpp:398-418 (scaled dot product over the band
+        // -win_upper .. +win_lower, incl. the CPU path's 12-split slice: the last query row of a split loses key i + win_lower)
+        const int split = (((T + 11) / 12) + 3) / 4 * 4;
+        double e1m = 0.0, e2m = 0.0;
+        std::vector<double> p((size_t)win_upper + win_lower + 1), o(64);
+        auto hf = [](uint16_t bits) { half_t h; memcpy(&h, &bits, 2); return (double)(float)h; };
+        for (int n = 0; n < N; ++n)
+            for (int h = 0; h < H; ++h)
+                for (int i = 0; i < T; ++i) {
+                    const int qe = std::min(T, (i / split + 1) * split);
+                    const int jmin = std::max(i - win_upper, 0), jmax = std::min(std::min(i + win_lower, T - 1), qe + win_upper - 1);
+                    const half_t *q = hqk.data() + ((size_t)n * T + i) * ld + h * 64;
+                    double mx = -1e300;
+                    for (int j = jmin; j <= jmax; ++j) {
+                        const half_t *k = hqk.data() + ((size_t)n * T + j) * ld + C + h * 64;
+                        double d = 0;
+                        for (int c = 0; c < 64; ++c) d += (double)(float)q[c] * (double)(float)k[c];
+                        p[j - jmin] = d * 0.125;
+                        mx = std::max(mx, p[j - jmin]);
+                    }
+                    double sum = 0;
+                    for (int j = jmin; j <= jmax; ++j) { p[j - jmin] = exp(p[j - jmin] - mx); sum += p[j - jmin]; }
+                    for (int c = 0; c < 64; ++c) o[c] = 0;
+                    for (int j = jmin; j <= jmax; ++j)
+                        for (int c = 0; c < 64; ++c) o[c] += p[j - jmin] * (double)(float)hv[(((size_t)n * H + h) * 64 + c) * T + j];
+                    for (int c = 0; c < 64; ++c) {
+                        const size_t oi = ((size_t)n * T + i) * C + h * 64 + c;
+                        e1m = std::max(e1m, fabs(hf(a[oi]) - o[c] / sum));
+                        e2m = std::max(e2m, fabs(hf(b[oi]) - o[c] / sum));
+                    }
+                }
+        if (err_ring) *err_ring = (float)e1m;
+        if (err_restage) *err_restage = (float)e2m;
     }
     (void)hipFree(qk); (void)hipFree(vT); (void)hipFree(o1); (void)hipFree(o2);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

@@ -88,5 +88,5 @@ def _make_tx_weights(cfg: ModelConfig, rng):
         ws.append((1.0 + 0.1 * rng.standard_normal(C)).astype(np.float32))
     ws.append(rng.uniform(-k, k, size=(t.up_scale_factor * C, C)).astype(np.float32))
     ws.append(rng.uniform(-k, k, size=(t.up_scale_factor * C,)).astype(np.float32))
-    ws.append(rng.uniform(-k, k, size=(cfg.outsize, C)).astype(np.float32))
+    ws.append(rng.uniform(-k, k, size=(cfg.outsize, C)).astype(np.float32) * np.float32(getattr(cfg, "synth_crf_gain", 1.0)))
     return [np.ascontiguousarray(w, np.float32) for w in ws]

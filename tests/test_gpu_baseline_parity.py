@@ -25,10 +25,11 @@ Stated contract, each asserted below (measured on MI355X in brac
      network that agree to 0.0013 rms (device vs emulation) are as far apart in identity as either is from f32.
      Identity therefore cannot separate kernel error from precision noise here; A-C do, and D guards against
      gross decode drift only.  (No trained weights exist offline)
-  E. (round 3) identity restricted to the bases the REFERENCE calls confidently (q >= 20 in the fixture's ref_qstr;
-     q >= 10 for the transformer, whose random-weight model has no q >= 20 base at all): matched / confident
-     >= 0.999 — where the model does have a decision margin, an f16 path must not move the call.  The f16 emulation
-     itself scores 0.9995 | 1.0 | 1.0 against the reference on this metric (4.9 % | 2.9 % | 0.2 % of the bases qualify).
+  E. (round 3) identity restricted to the bases the REFERENCE calls confidently (q >= 20 in the fixture's ref_qstr):
+     matched / confident >= 0.999 over >= 500 such bases (asserted) — where the model does have a decision margin, an f16
+     path must not move the call.  Round 4: the transformer's synthetic CRF projection carries gain 3
+     (config.synth_crf_gain) so that the reference calls a sizeable share of its bases at q >= 20 (round 3: 23 bases at
+     q >= 10 out of 11 475 — nothing to discriminate on).
   F. (round 3) DENSE scores: every output step of the first 4 chunks, 256 of the K columns per step (rotating, so all
      columns are visited), against tests/golden/base_*_dense.npz, same tolerances as A / B.
 """
@@ -53,7 +54,10 @@ CASES = {
     # name: (config factory, rms/max vs reference, rms/max vs f16 emulation)
     "hac": (config.hac_v43, (0.012, 0.15), (0.003, 0.03)),
     "sup43": (config.sup_v43, (0.012, 0.15), (0.003, 0.03)),
-    "sup5": (config.sup_v50, (0.006, 0.06), (0.004, 0.04)),
+    # sup@v5: the synthetic CRF projection carries gain 3 (config.synth_crf_gain, round 4: decision margins), so scores span
+    # +-27 instead of +-9 and every absolute tolerance of the transformer scales by 3: 0.018 / 0.18 is the same 0.07 % /
+    # 0.7 % of the score range as round 3's 0.006 / 0.06
+    "sup5": (config.sup_v50, (0.018, 0.18), (0.012, 0.12)),
 }
 
 
@@ -122,7 +126,7 @@ def test_baseline_size_vs_reference(name):
     ed_f16 = _err(dsub, gd["f16_q"].astype(np.float32) / float(gd["scale"]))
 
     ref_calls, f16_calls = _calls(g, "ref"), _calls(g, "f16")
-    qmin = 10 if cfg.is_tx else 20
+    qmin = 20
     cg, ct, ca = confident_identity(got, ref_calls, qmin)
     id_f16 = np.array([identity(a[0], b[0]) for a, b in zip(got, f16_calls)])
     id_ref = np.array([identity(a[0], b[0]) for a, b in zip(got, ref_calls)])
@@ -164,7 +168,9 @@ def test_baseline_size_vs_reference(name):
     # quantisation of the dense fixture (int16 fixed point) adds <= 1.6e-4
     assert ed_ref[1] <= tol_ref[0] and ed_ref[0] <= tol_ref[1] + 2e-4, f"dense scores vs reference: {ed_ref}"
     assert ed_f16[1] <= tol_f16[0] and ed_f16[0] <= tol_f16[1] + 2e-4, f"dense scores vs f16 emulation: {ed_f16}"
-    assert ct == 0 or cg / ct >= 0.999, f"identity on the reference's confident bases (q >= {qmin}): {cg} / {ct}"
+    # the metric must be discriminating: enough confidently called reference bases to count on
+    assert ct >= 500, f"only {ct} reference bases at q >= {qmin}: the synthetic model has no decision margins"
+    assert cg / ct >= 0.999, f"identity on the reference's confident bases (q >= {qmin}): {cg} / {ct}"
     floor = float(np.median(id_floor))
     assert np.median(id_f16) >= floor - 0.02, \
         f"identity vs f16 emulation {rep['identity_vs_f16_emulation']} below the precision floor {floor:.4f}"
@@ -176,8 +182,8 @@ def test_quantised_lstm_vs_reference():
     """The opt-in int8 LSTM path (csrc/lstm_q8.hip; the reference's KOI_I8 path, nn/LSTMStack.cpp:127-211) on the hac
     configuration at BASELINE size against the compiled f32 reference.  An 8-bit path has its OWN stated tolerance — it is
     reported beside the f16 path, which stays the parity headline:
-        scores vs reference (dense, 4 chunks x all steps): rms <= 0.25, and the decoder stays bit-exact on the device's own
-        scores; identity on the reference's confident bases (q >= 20) >= 0.97; measured values are written to
+        scores vs reference (dense, 4 chunks x all steps): rms <= 0.10 [0.075], and the decoder stays bit-exact on the device's
+        own scores; identity on the reference's confident bases (q >= 20) >= 0.999 [3787 / 3789]; measured values are written to
         gpurun_out/parity_base_hac_q8.json (DESIGN.md quotes them)."""
     g = np.load(os.path.join(GOLDEN, "base_hac.npz"))
     gd = np.load(os.path.join(GOLDEN, "base_hac_dense.npz"))
@@ -214,5 +220,6 @@ def test_quantised_lstm_vs_reference():
     except OSError:
         pass
     assert dec_bad == 0
-    assert ed_ref[1] <= 0.25 and e_ref[1] <= 0.25, (e_ref, ed_ref)
-    assert ct == 0 or cg / ct >= 0.97, (cg, ct)
+    # round 4: tolerances at 1.3x the measured values (rms 0.075, confident identity 3787 / 3789), not 3x
+    assert ed_ref[1] <= 0.10 and e_ref[1] <= 0.10, (e_ref, ed_ref)
+    assert ct >= 500 and cg / ct >= 0.999, (cg, ct)

@@ -14,7 +14,7 @@ from dorado_amd import capi, config, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("C,state_len", [(128, 4), (384, 4)])
+@pytest.mark.parametrize("C,state_len", [(128, 4), (256, 4), (384, 4)])
 def test_quantised_path_runs_and_tracks_f16_path(C, state_len):
     cfg = config.tiny(C, state_len)
     cfg.lstm_layers = 5
@@ -39,6 +39,15 @@ def test_quantised_path_runs_and_tracks_f16_path(C, state_len):
     assert np.isfinite(s8).all()
     assert rms <= 0.15, rms
     assert np.median(ids) >= 0.85
+    # ... and against the f32 ORACLE (oracle.c restatement of the reference's CPU path; no oracle restates Koi's int8
+    # activation arithmetic — closed source — so the 8-bit path is held to the f32 network with its own tolerance)
+    from oracle import oracle_py as O
+    s_o = O.lstm_crf_forward(cfg, ws, x[:8].astype(np.float32)[:, None, :])
+    do = np.clip(s8[:8], -5, 5) - s_o
+    rms_o = float(np.sqrt((do ** 2).mean()))
+    d16 = np.clip(s16[:8], -5, 5) - s_o
+    print(f"C={C}: int8 path vs f32 oracle: scores rms {rms_o:.4f} (f16 path: {float(np.sqrt((d16 ** 2).mean())):.4f})")
+    assert rms_o <= 0.15, rms_o
 
 
 def test_quant_rejects_unsupported_shapes():
