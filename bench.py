@@ -229,6 +229,8 @@ def dominant_kernel(cfg, n):
         return "transformer encoder stack (per layer: qkv gemm256 + window_attention_v3 + fused out-proj/MLP kernels)", None
     if cfg.lstm_size <= 384 and getattr(cfg, "lstm_quant", False):
         return "lstm_layer_q8_kernel<%d>" % cfg.lstm_size, "lstm_layer_q8"
+    if getattr(cfg, "lstm_quant", False):
+        return "lstm_layer_cl_kernel<%d, int8>" % cfg.lstm_size, "lstm_layer_cl"
     if cfg.lstm_size <= 384:
         return "lstm_layer_x8_kernel<%d>" % cfg.lstm_size, "lstm_layer_x8"
     if n % 256 == 0 and cfg.lstm_size in (512, 768, 1024):
@@ -513,6 +515,13 @@ def main():
                 extra["hac_int8_lstm"] = r3
             except Exception as ex:
                 extra["hac_int8_lstm"] = {"error": repr(ex)}
+            try:   # the same for the sup@v4.3 shape: the int8 instance of the cluster LSTM kernel (round 4)
+                qcfg = config.sup_v43()
+                qcfg.lstm_quant = True
+                r4, _, _, _, _, _ = run_config(capi, synth, qcfg, "sup", local_rank, 3, 1, 0, seed=7, with_cpu=False)
+                extra["sup_v43_int8_lstm"] = r4
+            except Exception as ex:
+                extra["sup_v43_int8_lstm"] = {"error": repr(ex)}
         if rank == 0:
             line["extra"] = extra
     # north_star's multi-GPU shape is ONE process driving every device (one HipCaller per device fed from shared chunk

@@ -73,7 +73,8 @@ extern "C" int mibc_launch_q8_convert(hipStream_t s, const half_t *in, int8_t *o
 extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin, half_t *Xout, const half_t *Wt,
                                          const float *biascl, const half_t *zeros, float *cbuf, unsigned *flags,
                                          unsigned *err, int T, int N, int reverse,
-                                         const unsigned long long *tmask);
+                                         const unsigned long long *tmask, int q8 = 0, const float *deqcl = nullptr,
+                                         signed char *hx = nullptr);
 extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int N, int T, int S, int W,
                                       float beam_cut, float stay, float clampv, float q_shift, float q_scale,
                                       float *bwd, uint32_t *trace, uint16_t *path_state, int8_t *out3,
@@ -117,6 +118,10 @@ struct mibc_engine {
     // cluster kernel (lstm_cluster.hip), C = 512 / 768 / 1024 only
     std::vector<half_t *> lstm_wcl;  // [C/128 members][2 passes][2C/32 slabs][256 gate rows][32] swizzled LDS images
     std::vector<float *> lstm_bcl;   // [C/128][2][2][4][32]
+    // quantised cluster layers (lstm_quant, layers >= 1): int8 slab images [C/128][2][2C/64][256][64], int32 round(bias / deq)
+    // and the dequantisation factors, both in lstm_bcl order
+    std::vector<int8_t *> lstm_wclq;
+    std::vector<float *> lstm_bclq, lstm_dqcl;
     half_t *lstm_zero = nullptr;     // [256][C] zeros (h_{-1})
     unsigned *cl_flags = nullptr;    // [N_res/256][C/128][16] completed-step counters (zeroed per launch)
     float *cl_cstate = nullptr;      // [N_res][C] f32 cell state of the layer in flight (workspace)

@@ -188,8 +188,8 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
                                                    std::to_string(n_weights) + ", expected " +
                                                    std::to_string(expect));
     }
-    if (d.lstm_quant && ((C != 128 && C != 256 && C != 384) || d.lstm_layers < 2))
-        return fail(nullptr, MIBC_NOT_SUPPORTED, "lstm_quant: lstm_size 128 / 256 / 384 and at least two layers");
+    if (d.lstm_quant && ((C != 128 && C != 256 && C != 384 && C != 512 && C != 768 && C != 1024) || d.lstm_layers < 2))
+        return fail(nullptr, MIBC_NOT_SUPPORTED, "lstm_quant: lstm_size 128 / 256 / 384 / 512 / 768 / 1024 and at least two layers");
     if (two_stage && (d.out_features % 128 != 0)) {
         return fail(nullptr, MIBC_NOT_SUPPORTED, "out_features must be a multiple of 128");
     }
@@ -291,7 +291,7 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
         e->lstm_bn.push_back(dbn);
         int8_t *dwq = nullptr;
         float *ddeq = nullptr;
-        if (d.lstm_quant && l >= 1) {
+        if (d.lstm_quant && l >= 1 && C <= 384) {
             // utils::quantize_tensor(cat(W_ih, W_hh, 1), 1) (torch_utils/tensor_utils.cpp:293-300, LSTMStack.cpp:165-172):
             // per output row scale = 128 / max|row|, round to nearest even, clip +-127
             const int KS64 = 2 * C / 64;
@@ -346,6 +346,41 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
             if (upload(e, &dwcl, wcl) || upload(e, &dbcl, bcl)) return MIBC_ERR_HIP;
             e->lstm_wcl.push_back(dwcl);
             e->lstm_bcl.push_back(dbcl);
+            int8_t *dwclq = nullptr;
+            float *dbclq = nullptr, *ddqcl = nullptr;
+            if (d.lstm_quant && l >= 1) {
+                // the quantised instance of the cluster kernel: the same per-row quantisation (utils::quantize_tensor,
+                // LSTMStack.cpp:165-172), slab images of 256 gate rows x 64 k (64-byte rows, same XOR swizzle of the 16-byte
+                // column); accumulators start from round(bias / deq[row]) (an int32: the rounding is < deq / 2 ~ 1e-5 of
+                // a pre-activation), deq[row] = 1 / (127 * row scale)
+                const int KSQ = 2 * C / 64;
+                std::vector<float> scale((size_t)4 * C);
+                std::vector<int8_t> qrow((size_t)4 * C * 2 * C);      // [4C][2C], k < C: W_ih, else W_hh
+                mibc_quantize_lstm_weights(Wih, Whh, C, qrow.data(), scale.data());
+                std::vector<int8_t> wclq((size_t)4 * C * 2 * C);
+                std::vector<float> bclq((size_t)4 * C), dqcl((size_t)4 * C);
+                for (int jm = 0; jm < KCL; ++jm)
+                    for (int p = 0; p < 2; ++p)
+                        for (int row = 0; row < 256; ++row) {
+                            const int hgi = row >> 7, g = (row >> 5) & 3, hl = row & 31;
+                            const int hidden = jm * 128 + p * 64 + hgi * 32 + hl;
+                            const size_t G = (size_t)g * C + hidden;
+                            const float deq = 1.0f / (127.0f * scale[G]);
+                            const size_t bi = (((size_t)(jm * 2 + p) * 2 + hgi) * 4 + g) * 32 + hl;
+                            dqcl[bi] = deq;
+                            const int bq = (int)lrintf(fminf(fmaxf((bih[G] + bhh[G]) / deq, -2.0e9f), 2.0e9f));
+                            memcpy(&bclq[bi], &bq, 4);
+                            for (int ks = 0; ks < KSQ; ++ks) {
+                                int8_t *dst = wclq.data() + ((((size_t)(jm * 2 + p)) * KSQ + ks) * 256 + row) * 64;
+                                for (int kk = 0; kk < 64; ++kk)
+                                    dst[(((kk >> 4) ^ ((row >> 2) & 3)) << 4) + (kk & 15)] = qrow[G * 2 * C + (size_t)ks * 64 + kk];
+                            }
+                        }
+                if (upload(e, &dwclq, wclq) || upload(e, &dbclq, bclq) || upload(e, &ddqcl, dqcl)) return MIBC_ERR_HIP;
+            }
+            e->lstm_wclq.push_back(dwclq);
+            e->lstm_bclq.push_back(dbclq);
+            e->lstm_dqcl.push_back(ddqcl);
         }
     }
     if (!e->lstm_wcl.empty()) {
@@ -454,6 +489,12 @@ extern "C" void mibc_destroy(mibc_engine *e) {
     if (e->s_out) (void)hipStreamDestroy(e->s_out);
     for (auto p : e->lstm_wcl) (void)hipFree(p);
     for (auto p : e->lstm_bcl) (void)hipFree(p);
+    for (auto p : e->lstm_wclq)
+        if (p) (void)hipFree(p);
+    for (auto p : e->lstm_bclq)
+        if (p) (void)hipFree(p);
+    for (auto p : e->lstm_dqcl)
+        if (p) (void)hipFree(p);
     if (e->lstm_zero) (void)hipFree(e->lstm_zero);
     if (e->cl_err) (void)hipFree(e->cl_err);
     if (e->cl_err_host) (void)hipHostFree(e->cl_err_host);
@@ -696,11 +737,36 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
         MibcRange r_layer(e, "lstm_layer");   // the reference's range name (nn/LSTMStack.cpp:100,148)
         // wide layers: the hidden-split cluster kernel whenever the batch is a whole number of 256-row clusters
         // (same arithmetic, element for element, as the per-workgroup kernel it replaces)
-        const bool cl_ok = e->use_cluster && !e->lstm_wcl.empty() && e->cl_flags != nullptr && N % 256 == 0 &&
+        const bool wide_q = d.lstm_quant && e->C >= 512;
+        const bool cl_ok = !(wide_q && l >= 1) && (!d.lstm_quant || wide_q) &&
+                           e->use_cluster && !e->lstm_wcl.empty() && e->cl_flags != nullptr && N % 256 == 0 &&
                            mibc_launch_lstm_layer_cl(e->stream, e->C, cur, nxt, e->lstm_wcl[l], e->lstm_bcl[l],
                                                      e->lstm_zero, e->cl_cstate, e->cl_flags, e->cl_err, T, N, reverse,
                                                      e->in_tmask) == 0;
-        if (d.lstm_quant) {
+        if (wide_q) {
+            // quantised path of the wide (cluster) layers: layer 0 in f16 (cluster kernel) + conversion of its output to int8
+            // (nn/LSTMStack.cpp:199-207), layers 1 .. L-1 on the int8 instance of the cluster kernel; the last one writes f16
+            // for the head and exchanges an int8 copy of h kept behind its int8 input (the input occupies only the first
+            // T N C bytes of its f16-sized buffer)
+            if (e->in_tmask != nullptr) return fail(e, MIBC_NOT_SUPPORTED, "lstm_quant: variable chunks are not supported");
+            if (N % 256 != 0 || e->cl_flags == nullptr)
+                return fail(e, MIBC_NOT_SUPPORTED, "lstm_quant with lstm_size >= 512 needs batches that are multiples of 256");
+            if (l == 0) {
+                if (!cl_ok) return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
+                e->cl_used = true;
+                if (mibc_launch_q8_convert(e->stream, nxt, (int8_t *)cur, (size_t)T * N * e->C) != 0)
+                    return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
+                if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_LSTM0 + l], e->stream));
+                continue;      // layer 1 reads `cur` (int8): the ping-pong is not swapped after layer 0
+            }
+            const bool last = (l + 1 == d.lstm_layers);
+            signed char *hx = last ? (signed char *)cur + (size_t)T * N * e->C : nullptr;
+            if (mibc_launch_lstm_layer_cl(e->stream, e->C, cur, nxt, (const half_t *)e->lstm_wclq[l], e->lstm_bclq[l], e->lstm_zero,
+                                          e->cl_cstate, e->cl_flags, e->cl_err, T, N, reverse, nullptr, last ? 2 : 1,
+                                          e->lstm_dqcl[l], hx) != 0)
+                return fail(e, MIBC_NOT_SUPPORTED, "lstm_quant: cluster launch");
+            e->cl_used = true;
+        } else if (d.lstm_quant) {
             // the reference's quantised path: first layer f16 + conversion of its output (LSTMStack.cpp:199-207), then int8
             if (e->in_tmask != nullptr) return fail(e, MIBC_NOT_SUPPORTED, "lstm_quant: variable chunks are not supported");
             int qrc;
@@ -1444,8 +1510,22 @@ MIBC_HOOK int mibc_debug_gemm(int M, int N, int K, int dbg, int iters, float *ms
     if (hipMalloc((void **)&A, (size_t)M * K * 2) != hipSuccess) return -1;
     if (hipMalloc((void **)&B, (size_t)N * K * 2) != hipSuccess) return -1;
     if (hipMalloc((void **)&C, (size_t)M * N * 2) != hipSuccess) return -1;
-    (void)hipMemset(A, 0x3c, (size_t)M * K * 2);
-    (void)hipMemset(B, 0x2c, (size_t)N * K * 2);
+    // RANDOM operands (cdna_hip_programming.md 5.4 rule 25: constant fills run at a 15-20 % higher clock): a 32 MB block of
+    // uniform [-1, 1) halfs (B scaled by 1/16) replicated over the operands
+    {
+        const size_t blk = 16u << 20;
+        std::vector<half_t> h(blk);
+        uint32_t sd = 4242u;
+        for (auto &v : h) {
+            sd = sd * 1664525u + 1013904223u;
+            v = (half_t)((float)((sd >> 9) & 0x7fff) / 16384.0f - 1.0f);
+        }
+        for (size_t o = 0; o < (size_t)M * K; o += blk)
+            (void)hipMemcpy(A + o, h.data(), std::min(blk, (size_t)M * K - o) * 2, o == 0 ? hipMemcpyHostToDevice : hipMemcpyHostToDevice);
+        for (auto &v : h) v = (half_t)((float)v * 0.0625f);
+        for (size_t o = 0; o < (size_t)N * K; o += blk)
+            (void)hipMemcpy(B + o, h.data(), std::min(blk, (size_t)N * K - o) * 2, hipMemcpyHostToDevice);
+    }
     GemmArgs g{};
     g.A = A; g.B = B; g.out = C; g.M = M; g.Ncols = N; g.K = K;
     g.a_div = 1 << 30; g.a_inner = K; g.o_div = 1 << 30; g.o_inner = N; g.act = -1; g.dbg = dbg;
@@ -1468,8 +1548,12 @@ MIBC_HOOK int mibc_debug_gemm(int M, int N, int K, int dbg, int iters, float *ms
 // Test entry (not part of the public ABI): runs one GEMM shape through gemm256_kernel and through gemm_dma_kernel on
 // the same pseudo-random operands and reports how many output halfs differ (contract: none — same arithmetic) and
 // both run times.  epi: 0 plain (act, optional bias), 1 rotary + transposed V (N = 3 * d_model, T = rope_T), 2 SwiGLU.
-MIBC_HOOK int mibc_debug_gemm_compare(int M, int N, int K, int epi, int act, int use_bias, int rope_T, int iters,
-                                       long long *ndiff, float *maxdiff, float *ms_256, float *ms_128) {
+// dbg0: which kernel runs as the first of the two: 0 = the production choice (gemm256x_kernel for the plain / rotary
+// epilogues with K <= 1024, else gemm256_kernel), 0x1000 = gemm256_kernel (32 x 32 x 16: bit-identical to gemm_dma_kernel).
+// err_f64 (plain epilogue only, else -1): largest deviation of the first kernel from an f64 host product on 4096 sampled
+// outputs.
+MIBC_HOOK int mibc_debug_gemm_compare(int M, int N, int K, int epi, int act, int use_bias, int rope_T, int iters, int dbg0,
+                                       long long *ndiff, float *maxdiff, float *ms_256, float *ms_128, float *err_f64) {
     auto lcg = [](uint32_t &s) {
         s = s * 1664525u + 1013904223u;
         return (float)((s >> 9) & 0x7fff) / 16384.0f - 1.0f;   // [-1, 1)
@@ -1512,7 +1596,7 @@ MIBC_HOOK int mibc_debug_gemm_compare(int M, int N, int K, int epi, int act, int
     for (int which = 0; which < 2; ++which) {
         g.out = which ? C2 : C1;
         g.vT = (epi == 1) ? (which ? V2 : V1) : nullptr;
-        g.dbg = which ? 0x100 : 0;
+        g.dbg = which ? 0x100 : dbg0;
         if (mibc_launch_gemm_tn(nullptr, &g) != 0) return -2;
         (void)hipEventRecord(e0, nullptr);
         for (int i = 0; i < iters; ++i) mibc_launch_gemm_tn(nullptr, &g);
@@ -1545,6 +1629,23 @@ MIBC_HOOK int mibc_debug_gemm_compare(int M, int N, int K, int epi, int act, int
     cmp(o1, o2);
     if (epi == 1) cmp(v1, v2);
     if (amax == 0.0f) nd = -1;   // nothing was written: the comparison is void
+    double ef = -1.0;
+    if (epi == 0 && (act == -1 || act == 3)) {
+        ef = 0.0;
+        uint32_t sd = 99u;
+        for (int it = 0; it < 4096; ++it) {
+            sd = sd * 1664525u + 1013904223u;
+            const size_t m = (size_t)(sd >> 8) % (size_t)M;
+            sd = sd * 1664525u + 1013904223u;
+            const size_t n = (size_t)(sd >> 8) % (size_t)N;
+            double acc = 0.0;
+            for (int k = 0; k < K; ++k) acc += (double)(float)hA[m * K + k] * (double)(float)hB[n * K + k];
+            if (use_bias) acc += (double)hbias[n];
+            if (act == 3) acc = 5.0 * tanh(acc);
+            ef = std::max(ef, fabs(acc - (double)(float)o1[m * ocols + n]));
+        }
+    }
+    if (err_f64) *err_f64 = (float)ef;
     *ndiff = nd;
     *maxdiff = md;
     *ms_256 = ms[0];

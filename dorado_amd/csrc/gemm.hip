@@ -429,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmArgs p) {
 }
 
 extern "C" int mibc_launch_gemm256(hipStream_t s, const GemmArgs *a);
+extern "C" int mibc_launch_gemm256x(hipStream_t s, const GemmArgs *a);
 
 extern "C" int mibc_launch_gemm_tn(hipStream_t s, const GemmArgs *a) {
     if (a->K % G_BK != 0 || a->Ncols % G_BN != 0 || a->M <= 0) {
@@ -436,7 +437,10 @@ extern "C" int mibc_launch_gemm_tn(hipStream_t s, const GemmArgs *a) {
     }
     // large row counts with K = 512 / 1024 / 2048: the persistent 256 x 256 tile kernel (gemm256.hip; same
     // arithmetic, bit-identical results).  dbg bit 8 (microbenchmark) keeps the 128 x 128 kernel.
-    if ((a->dbg == 0 || a->dbg >= 0x1000) && mibc_launch_gemm256(s, a) == 0) return 0;
+    // (round 4) gemm256x.hip first: the same tile on 16 x 16 x 32 MFMAs (higher sustained clock), plain / RoPE epilogues.
+    // dbg (debug build, microbenchmarks): 0x1000 | bits = gemm256_kernel, 0x2000 | bits = gemm256x_kernel, 0x100 = 128 x 128.
+    if ((a->dbg == 0 || (a->dbg & 0xf000) == 0x2000) && mibc_launch_gemm256x(s, a) == 0) return 0;
+    if ((a->dbg == 0 || (a->dbg & 0xf000) == 0x1000) && mibc_launch_gemm256(s, a) == 0) return 0;
     const int ncol = a->Ncols / G_BN;
     const int nrow = (a->M + G_BM - 1) / G_BM;
     dim3 grid(((nrow + 7) / 8) * 8 * ncol);

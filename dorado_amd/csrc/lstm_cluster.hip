@@ -27,8 +27,21 @@
 //             hides behind ~13 us of MFMA work; a bounded blocking poll is the slow path.
 // Every spin is bounded: on a time-out the workgroup records an error word, stops waiting for the
 // rest of the launch (results are garbage, the kernel still terminates) and the host reports it.
+//
+// Round 4 — Q8: the reference's quantised path (nn/LSTMStack.cpp:127-211, KOI_I8; per-row weight scales
+// utils::quantize_tensor :165-172) on the same machine mapping.  int8 activations (round(127 h), rows of C BYTES) and
+// int8 weights keep the 64-byte slab rows, so every LDS image, DMA piece and fragment read is byte-identical to the f16
+// kernel's; a slab now covers K = 64 (v_mfma_i32_32x32x32_i8: the lane's 16-byte fragment is 16 k-values), i.e. HALF the
+// slabs per time step at the same MFMA count per slab.  Accumulators are int32 (exact), initialised with
+// round(bias / deq[row]); gate pre-activation = float(acc) * deq[row], deq = 1 / (127 * row scale); gates, cell state and
+// the h quantisation are fp32 as in the f16 kernel.  Layers 1 .. L-2 write int8 h (which is also the exchange); the last
+// layer writes f16 for the CRF head AND an int8 copy of h (Hx) that its members exchange.  Opt-in
+// (mibc_model_desc::lstm_quant), own tolerance (tests/test_gpu_baseline_parity.py).
 #include "common.h"
 #include "cluster_util.h"
+
+typedef int int4q_t __attribute__((ext_vector_type(4)));
+typedef int int16q_t __attribute__((ext_vector_type(16)));
 
 #define CL_ROWS 256
 #define CL_BK 32
@@ -42,30 +55,40 @@
 
 #define CL_OFF_PATCH (CL_NST * CL_STAGE * 2)                 // bytes
 #define CL_OFF_BIAS (CL_OFF_PATCH + 8 * CL_PATCH * 2)
-#define CL_OFF_FLAGZ (CL_OFF_BIAS + 2 * 2 * 4 * 32 * 4)
+#define CL_OFF_DEQ (CL_OFF_BIAS + 2 * 2 * 4 * 32 * 4)        // Q8: dequantisation factors, bias order
+#define CL_QPATCH_LD 48                                     // Q8: int8 h rows of a wave (32 batch rows x 32 hidden bytes) reuse its f16 patch
+#define CL_OFF_FLAGZ (CL_OFF_DEQ + 2 * 2 * 4 * 32 * 4)
 #define CL_OFF_SYNC (CL_OFF_FLAGZ + 256)
 #define CL_LDS_BYTES (CL_OFF_SYNC + 64)
+
+__device__ __forceinline__ int16q_t cl_mfma_i8(half8_t a, half8_t b, int16q_t c) {
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(int4q_t, a), __builtin_bit_cast(int4q_t, b), c, 0, 0, 0);
+}
 
 // One launch = one layer.  grid = KCL * (clusters resident at once); a workgroup loops over the row
 // groups (clusters of 256 rows) rg = first, first + stride, ... so that N may exceed one residency.
 // DBG (debug build only; results are wrong when non-zero): timing ablations — 1 no gate math, 2 no DMA after the
 // first step, 4 no MFMA, 8 no hand-off wait / publish, 16 no fragment reads, 32 / 64 weight / activation slabs
 // always fetched from the same (cache-resident) address.
-template <int C, bool MASKED, int DBG = 0>
+// Q8: 0 = f16; 1 = int8 in, int8 out; 2 = int8 in, f16 out + int8 exchange copy in Hx (last layer).
+template <int C, bool MASKED, int DBG = 0, int Q8 = 0>
 __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
-        const half_t *__restrict__ Xin,     // [T][N][C]
-        half_t *__restrict__ Xout,          // [T][N][C]
-        const half_t *__restrict__ Wt,      // [KCL][2][KS][256][32]: swizzled LDS images of the weight slabs
-        const float *__restrict__ biascl,   // [KCL][2][2][4][32]  (b_ih + b_hh)
+        const half_t *__restrict__ Xin,     // [T][N][C]  (Q8: int8 rows of C bytes)
+        half_t *__restrict__ Xout,          // [T][N][C]  (Q8 == 1: int8)
+        const half_t *__restrict__ Wt,      // [KCL][2][KS][256][32]: swizzled LDS images of the weight slabs (Q8: [256][64] int8)
+        const float *__restrict__ biascl,   // [KCL][2][2][4][32]  (b_ih + b_hh); Q8: int32 round(bias / deq)
         const half_t *__restrict__ zeros,   // [256][C] zeros (h_{-1})
         float *__restrict__ cbuf,           // [N][C] f32 cell state, private layout (see seg_gates); no init needed
         unsigned *__restrict__ flags,       // [nclusters][KCL][16]: completed steps of member j (zeroed per launch)
         unsigned *__restrict__ err,         // [4]: sticky error word, first failing (cluster, step)
         int T, int N, int reverse, int cpx /* clusters per XCD slot group, 0 = linear map */,
         int resident_clusters,
-        const unsigned long long *__restrict__ tmask /* MASKED: [T][N/64] */) {
+        const unsigned long long *__restrict__ tmask /* MASKED: [T][N/64] */,
+        const float *__restrict__ deqcl /* Q8: [KCL][2][2][4][32] */, signed char *__restrict__ Hx /* Q8 == 2: [T][N][C] int8 h */) {
+    static_assert(!(Q8 && MASKED), "the quantised path has no variable-chunk instance");
     constexpr int KCL = C / 128;
-    constexpr int KSX = C / CL_BK;         // x-part slabs per pass
+    constexpr int EB = Q8 ? 1 : 2;         // bytes per activation / weight element
+    constexpr int KSX = C * EB / 64;       // x-part slabs per pass (a slab row is 64 bytes: 32 halfs or 64 int8)
     constexpr int KS = 2 * KSX;            // slabs per pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // every LDS access goes through explicit LDS-address-space pointers (no generic pointers, no aperture tests)
@@ -73,6 +96,7 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
     LDSP(half_t) stage = (LDSP(half_t))smem3;
     LDSP(half_t) patch_all = (LDSP(half_t))(smem3 + CL_OFF_PATCH);
     LDSP(float) bias_s = (LDSP(float))(smem3 + CL_OFF_BIAS);
+    LDSP(float) deq_s = (LDSP(float))(smem3 + CL_OFF_DEQ);
     LDSP(unsigned) flagz = (LDSP(unsigned))(smem3 + CL_OFF_FLAGZ);
     LDSP(volatile unsigned) syncw = (LDSP(volatile unsigned))(smem3 + CL_OFF_SYNC);
     const unsigned lds0 = (unsigned)(size_t)smem3;   // byte address of the allocation (DMA destinations)
@@ -106,12 +130,15 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
     for (int q = 0; q < 2; ++q) {
         const int row = (wave * 2 + q) * 16 + (lane >> 2);
         const int col = (lane & 3) ^ ((row >> 2) & 3);
-        aoff[q] = (unsigned)(row * C + col * 8);
+        aoff[q] = (unsigned)(row * C * EB + col * 16);       // bytes
     }
-    const half_t *wsrc = Wt + (size_t)j * 2 * KS * CL_WTILE + (size_t)(wave * 2) * 512 + lane * 8;
 
-    for (int i = tid; i < 2 * 2 * 4 * 32; i += 512) bias_s[i] = biascl[(size_t)j * 2 * 2 * 4 * 32 + i];
+    for (int i = tid; i < 2 * 2 * 4 * 32; i += 512) {
+        bias_s[i] = biascl[(size_t)j * 2 * 2 * 4 * 32 + i];
+        if (Q8) deq_s[i] = deqcl[(size_t)j * 2 * 2 * 4 * 32 + i];
+    }
     LDSP(half_t) patch = patch_all + wave * CL_PATCH;
+    LDSP(unsigned char) qpatch = (LDSP(unsigned char))patch;   // same memory: the f16 rows (if any) have left before the int8 rows are written
     bool dead = false;
 
     const bool grpB = wave >= 4;
@@ -121,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
     const int woff = (hg * 128 + l31) * CL_BK, xoff = CL_WTILE + (rgw * 64 + l31) * CL_BK;
     const unsigned long long wslice = (unsigned long long)(Wt + (size_t)j * 2 * KS * CL_WTILE);   // uniform
     const unsigned wlane = (unsigned)(((wave * 2) * 512 + lane * 8) * 2);                              // bytes
-    const unsigned aoffb[2] = {aoff[0] * 2u, aoff[1] * 2u};                                             // bytes
+    const unsigned aoffb[2] = {aoff[0], aoff[1]};                                                       // bytes
     const unsigned dma_lds = lds0 + (unsigned)(wave * 2) * 1024u;   // + slot * 64 KiB/2 ... + tile + q * 1 KiB
 
     for (int cl = cl0; cl < nclusters; cl += resident_clusters) {
@@ -135,11 +162,13 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
         // scalar instructions alone took as long as the slab's MFMAs).
         // (Addresses are integers: selects between pointers into different allocations trip an address-space
         // inference bug of this hipcc: "Illegal instruction ... V_CMP_NE_U32 0, $src_shared_base".)
-        const long long dstep = (reverse ? -1LL : 1LL) * (long long)N * C * 2;           // bytes per time step
+        const long long dstep = (reverse ? -1LL : 1LL) * (long long)N * C * EB;          // bytes per time step
         const int t_first = reverse ? (T - 1) : 0;
-        unsigned long long x_cur = (unsigned long long)Xin + 2ull * (((size_t)t_first * N + n0) * C);
+        unsigned long long x_cur = (unsigned long long)Xin + (unsigned long long)EB * (((size_t)t_first * N + n0) * C);
         unsigned long long h_cur = (unsigned long long)zeros;                              // h_{-1} = 0
-        const unsigned long long o_first = (unsigned long long)Xout + 2ull * (((size_t)t_first * N + n0) * C);
+        // the rows the members exchange: the layer output itself, or (Q8 == 2: f16 output) its int8 copy
+        const unsigned long long o_first = (Q8 == 2 ? (unsigned long long)Hx : (unsigned long long)Xout) +
+                                           (unsigned long long)EB * (((size_t)t_first * N + n0) * C);
 
         // DMA of one slab into ring slot `slot`: weights from byte offset w_off of this member's slice,
         // activations from a_base (row 0 of the cluster, first column of the slab).  Both activation halves
@@ -180,6 +209,7 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
         // flag fetch) only make a wait stricter.  The DMAs of slab g + 2 reuse the ring slot of slab g - 2, last
         // read in M(g-2), which both groups have finished before the instance A.B1(g).
         float16_t acc[4][2];
+        int16q_t acq[4][2];        // Q8 accumulators (the unused set is dead code)
         half8_t wf[4], xa[2];
         float4_t cpre[2][4];
         // ---- gates of one pass (gp, time index gt): D row = hidden (r&3) + 8 (r>>2) + 4 lhi, D col = batch row l31.
@@ -208,13 +238,23 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
             const int hcol = j * 128 + gp * 64 + hg * 32;
             const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
                     (void *)(Xout + ((size_t)gt * N + n0 + rgw * 64) * C + hcol), 0, 64 * C * 2, 0x00020000);
+            // Q8: the int8 rows (the layer output when Q8 == 1, the exchange copy Hx when Q8 == 2)
+            const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)((Q8 == 2 ? Hx : (signed char *)Xout) + ((size_t)gt * N + n0 + rgw * 64) * C + hcol), 0, 64 * C, 0x00020000);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
+                int pkq[4] = {0, 0, 0, 0};
                 const bool rowon = !MASKED || ((gvm >> (rt * 32 + l31)) & 1ull);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     half4_t hv;
                     float4_t cn;
+                    float4_t dq[4];      // Q8: dequantisation factors of this lane's 4 hidden units, per gate
+                    int pk = 0;          // Q8: round(127 h) of the 4 units, one byte each (kept in pkq[q] for the int8 round)
+                    if (Q8) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) dq[g] = *(LDSP(const float4_t))(deq_s + ((gp * 2 + hg) * 4 + g) * 32 + 4 * lhi + 8 * q);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = q * 4 + e;
@@ -223,10 +263,14 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
                             c = cpre[rt][q][e];
                             hval = 1e-3f * (acc[0][rt][r] + acc[1][rt][r] + acc[2][rt][r] + acc[3][rt][r]);
                         } else {
-                            const float ig = fast_sigmoid(acc[0][rt][r]);
-                            const float fg = fast_sigmoid(acc[1][rt][r]);
-                            const float gg = fast_tanh(acc[2][rt][r]);
-                            const float og = fast_sigmoid(acc[3][rt][r]);
+                            const float p0 = Q8 ? (float)acq[0][rt][r] * dq[0][e] : acc[0][rt][r];
+                            const float p1 = Q8 ? (float)acq[1][rt][r] * dq[1][e] : acc[1][rt][r];
+                            const float p2 = Q8 ? (float)acq[2][rt][r] * dq[2][e] : acc[2][rt][r];
+                            const float p3 = Q8 ? (float)acq[3][rt][r] * dq[3][e] : acc[3][rt][r];
+                            const float ig = fast_sigmoid(p0);
+                            const float fg = fast_sigmoid(p1);
+                            const float gg = fast_tanh(p2);
+                            const float og = fast_sigmoid(p3);
                             c = fmaf(fg, cpre[rt][q][e], ig * gg);
                             hval = og * fast_tanh(c);
                         }
@@ -236,18 +280,33 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
                         }
                         cn[e] = c;
                         hv[e] = (half_t)hval;
+                        if (Q8) pk |= ((int)__builtin_rintf(hval * 127.0f) & 0xff) << (8 * e);
                     }
                     *((float4_t *)(cbuf + ((((((size_t)cl * KCL + j) * 2 + gp) * 8 + wave) * 2 + rt) * 4 + q) * 256) + lane) = cn;
-                    *(LDSP(half4_t))(patch + l31 * CL_PATCH_LD + 8 * q + 4 * lhi) = hv;
+                    if (Q8 != 1) *(LDSP(half4_t))(patch + l31 * CL_PATCH_LD + 8 * q + 4 * lhi) = hv;
+                    if (Q8) pkq[q] = pk;
                 }
                 __builtin_amdgcn_wave_barrier();   // same wave: LDS operations execute in order
+                if (Q8 != 1) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int prow = (lane >> 2) + 16 * i, seg = lane & 3;
-                    const half8_t v = *(LDSP(const half8_t))(patch + prow * CL_PATCH_LD + seg * 8);
+                    for (int i = 0; i < 2; ++i) {
+                        const int prow = (lane >> 2) + 16 * i, seg = lane & 3;
+                        const half8_t v = *(LDSP(const half8_t))(patch + prow * CL_PATCH_LD + seg * 8);
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                                __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v), ors,
+                                ((rt * 32 + prow) * C + seg * 8) * 2, 0, Q8 ? 0 : 16 /* f16 exchange: sc1 write-through */);
+                    }
+                }
+                if (Q8) {   // int8 rows of 32 bytes: one 16-byte piece per lane (the exchange: write-through)
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *(LDSP(int))(qpatch + l31 * CL_QPATCH_LD + 8 * q + 4 * lhi) = pkq[q];
+                    __builtin_amdgcn_wave_barrier();
+                    const int prow = lane >> 1, seg = lane & 1;
+                    const int4q_t v = *(LDSP(const int4q_t))(qpatch + prow * CL_QPATCH_LD + seg * 16);
                     __builtin_amdgcn_raw_buffer_store_b128(
-                            __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v), ors,
-                            ((rt * 32 + prow) * C + seg * 8) * 2, 0, 16 /* sc1: write-through */);
+                            __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v), qrs,
+                            (rt * 32 + prow) * C + seg * 16, 0, 16 /* sc1 */);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -378,10 +437,18 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
                                     const float4_t v = *(LDSP(const float4_t))(bp + 8 * q);
+                                    // (Q8: read the int32 words AS ints — hipcc folded bit_cast<int>(v[e]) of the float vector to
+                                    // element 0 for all four e: every hidden unit of a lane started from its first unit's bias)
+                                    const int4q_t vi = *(LDSP(const int4q_t))((LDSP(const int))bp + 8 * q);
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
-                                        acc[g][0][q * 4 + e] = v[e];
-                                        acc[g][1][q * 4 + e] = v[e];
+                                        if (Q8) {
+                                            acq[g][0][q * 4 + e] = vi[e];
+                                            acq[g][1][q * 4 + e] = vi[e];
+                                        } else {
+                                            acc[g][0][q * 4 + e] = v[e];
+                                            acc[g][1][q * 4 + e] = v[e];
+                                        }
                                     }
                                 }
                             }
@@ -396,7 +463,10 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            if (!(DBG & 4)) {
+                            if (Q8) {
+                                acq[g][0] = cl_mfma_i8(wf[g], xa[0], acq[g][0]);
+                                acq[g][1] = cl_mfma_i8(wf[g], xa[1], acq[g][1]);
+                            } else if (!(DBG & 4)) {
                                 acc[g][0] = mfma32x32x16(wf[g], xa[0], acc[g][0]);
                                 acc[g][1] = mfma32x32x16(wf[g], xa[1], acc[g][1]);
                             } else {
@@ -414,7 +484,10 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
                         }
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            if (!(DBG & 4)) {
+                            if (Q8) {
+                                acq[g][0] = cl_mfma_i8(wf[g], xb[0], acq[g][0]);
+                                acq[g][1] = cl_mfma_i8(wf[g], xb[1], acq[g][1]);
+                            } else if (!(DBG & 4)) {
                                 acc[g][0] = mfma32x32x16(wf[g], xb[0], acc[g][0]);
                                 acc[g][1] = mfma32x32x16(wf[g], xb[1], acc[g][1]);
                             } else {
@@ -453,12 +526,15 @@ MibcClusterGate &mibc_cluster_gate() {
     return g;
 }
 
+// q8: 0 = f16 layer; 1 = int8 in / int8 out; 2 = int8 in / f16 out + int8 exchange copy hx (last layer).  For q8 != 0 Xin / Wt
+// point at int8 data, biascl holds int32 round(bias / deq), deqcl the dequantisation factors.
 extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin, half_t *Xout, const half_t *Wt,
                                          const float *biascl, const half_t *zeros, float *cbuf, unsigned *flags,
                                          unsigned *err, int T, int N, int reverse,
-                                         const unsigned long long *tmask) {
+                                         const unsigned long long *tmask, int q8, const float *deqcl, signed char *hx) {
     if (Wt == nullptr || biascl == nullptr || zeros == nullptr || cbuf == nullptr || flags == nullptr || err == nullptr)
         return 1;
+    if (q8 != 0 && (tmask != nullptr || deqcl == nullptr || (q8 == 2 && hx == nullptr) || q8 < 0 || q8 > 2)) return 1;
     if ((C != 512 && C != 768 && C != 1024) || N < CL_ROWS || N % CL_ROWS != 0) return 1;
     const int KCL = C / 128;
     const int nclusters = N / CL_ROWS;
@@ -477,8 +553,28 @@ extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin
     do {                                                                                                    \
         MIBC_LDS_ATTR_ONCE((lstm_layer_cl_kernel<CC, M_>), CL_LDS_BYTES);                                   \
         hipLaunchKernelGGL((lstm_layer_cl_kernel<CC, M_>), grid, dim3(512), CL_LDS_BYTES, s, Xin, Xout, Wt, \
-                           biascl, zeros, cbuf, flags, err, T, N, reverse, cpx, resident, tmask);           \
+                           biascl, zeros, cbuf, flags, err, T, N, reverse, cpx, resident, tmask, nullptr, nullptr); \
     } while (0)
+#define CL_LAUNCH_Q8(CC, Q_)                                                                                \
+    do {                                                                                                    \
+        MIBC_LDS_ATTR_ONCE((lstm_layer_cl_kernel<CC, false, 0, Q_>), CL_LDS_BYTES);                         \
+        hipLaunchKernelGGL((lstm_layer_cl_kernel<CC, false, 0, Q_>), grid, dim3(512), CL_LDS_BYTES, s, Xin, Xout, Wt, \
+                           biascl, zeros, cbuf, flags, err, T, N, reverse, cpx, resident, nullptr, deqcl, hx); \
+    } while (0)
+    if (q8 == 1) {
+        switch (C) {
+            case 512: CL_LAUNCH_Q8(512, 1); return 0;
+            case 768: CL_LAUNCH_Q8(768, 1); return 0;
+            default: CL_LAUNCH_Q8(1024, 1); return 0;
+        }
+    }
+    if (q8 == 2) {
+        switch (C) {
+            case 512: CL_LAUNCH_Q8(512, 2); return 0;
+            case 768: CL_LAUNCH_Q8(768, 2); return 0;
+            default: CL_LAUNCH_Q8(1024, 2); return 0;
+        }
+    }
 #ifdef MIBC_DEBUG_KERNELS
     static const int dbg = MIBC_ENV_INT("MIBC_CL_DBG", 0);
     if (dbg && C == 1024 && tmask == nullptr) {
@@ -487,7 +583,7 @@ extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin
         (void)hipFuncSetAttribute((const void *)lstm_layer_cl_kernel<1024, false, D_>,                      \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, CL_LDS_BYTES);                \
         hipLaunchKernelGGL((lstm_layer_cl_kernel<1024, false, D_>), grid, dim3(512), CL_LDS_BYTES, s, Xin,  \
-                           Xout, Wt, biascl, zeros, cbuf, flags, err, T, N, reverse, cpx, resident, tmask); \
+                           Xout, Wt, biascl, zeros, cbuf, flags, err, T, N, reverse, cpx, resident, tmask, nullptr, nullptr); \
         return 0;                                                                                           \
     }
         switch (dbg) { CL_DBG(1) CL_DBG(2) CL_DBG(4) CL_DBG(8) CL_DBG(16) CL_DBG(18) CL_DBG(22) CL_DBG(27) CL_DBG(32) CL_DBG(64) CL_DBG(96) CL_DBG(128) default: break; }
@@ -507,4 +603,5 @@ extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin
         default: CL_LAUNCH(1024, false); return 0;
     }
 #undef CL_LAUNCH
+#undef CL_LAUNCH_Q8
 }

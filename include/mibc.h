@@ -62,8 +62,8 @@ typedef struct mibc_model_desc {
     int crf_expand_blanks;
     /* 1: the reference's quantised LSTM path (nn/LSTMStack.cpp:127-211, KOI_I8): layers 2..L run on int8 weights
      * (per-row scales, utils::quantize_tensor) and int8 activations, the first layer in f16 (:199-207).  LSTM models with
-     * lstm_size 128 / 256 / 384 and >= 2 layers; not combinable with variable chunks.  0 (default): f16 throughout —
-     * the path the parity contract is stated for. */
+     * lstm_size 128 / 256 / 384 (any batch) or 512 / 768 / 1024 (batches that are multiples of 256) and >= 2 layers; not
+     * combinable with variable chunks.  0 (default): f16 throughout — the path the parity contract is stated for. */
     int lstm_quant;
 } mibc_model_desc;
 

@@ -178,6 +178,53 @@ def test_baseline_size_vs_reference(name):
         f"identity vs reference {rep['identity_vs_reference']} below the precision floor {floor:.4f}"
 
 
+def test_quantised_cluster_lstm_vs_reference():
+    """Round 4: the int8 instance of the cluster LSTM kernel (lstm_size 1024: the sup@v4.3 shape, where the reference's GPU
+    path is int8 too, nn/LSTMStack.cpp:127-211) at BASELINE size against the compiled f32 reference.  The fixture's 32 chunks
+    are tiled to 256 rows (the cluster kernel works on whole 256-row clusters).  Own tolerance: dense scores rms <= 0.10,
+    decoder bit-exact on the device's own scores, identity on the reference's confident bases (q >= 20) >= 0.999."""
+    g = np.load(os.path.join(GOLDEN, "base_sup43.npz"))
+    gd = np.load(os.path.join(GOLDEN, "base_sup43_dense.npz"))
+    cfg = config.sup_v43()
+    cfg.lstm_quant = True
+    N, t_in = int(g["N"]), int(g["T_in"])
+    ws = synth.make_weights(cfg, seed=int(g["weight_seed"]))
+    x16 = synth.make_signal(N, t_in, seed=int(g["signal_seed"]))
+    xb = np.tile(x16, (256 // N, 1))
+    eng = capi.Engine(cfg, ws)
+    T = eng.output_steps(t_in)
+    scf = np.clip(eng.forward(xb).astype(np.float32), -5.0, 5.0)
+    got = eng.call(xb)
+    eng.close()
+    assert (scf[:N] == scf[N:2 * N]).all()                 # a row's result does not depend on where it sits in the batch
+    scf, got = scf[:N], got[:N]
+    rows = np.arange(N)[:, None]
+    e_ref = _err(scf[rows, g["steps"]], g["ref_scores"])
+    grp = scf.shape[2] // int(gd["ncols"])
+    dcols = np.arange(int(gd["ncols"]))[None, :] * grp + (np.arange(T) % grp)[:, None]
+    ed_ref = _err(scf[gd["chunks"]][:, np.arange(T)[:, None], dcols], gd["ref_q"].astype(np.float32) / float(gd["scale"]))
+    want_own = O.decode(scf, q_shift=cfg.qbias, q_scale=cfg.qscale, det=1)
+    dec_bad = sum(1 for a, b in zip(got, want_own) if a[0] != b[0] or not (a[2] == b[2]).all())
+    ref_calls = _calls(g, "ref")
+    cg, ct, ca = confident_identity(got, ref_calls, 20)
+    id_ref = np.array([identity(a[0], b[0]) for a, b in zip(got, ref_calls)])
+    rep = {"case": "sup43 int8 cluster LSTM (lstm_quant)", "N": N, "scores_vs_reference_sampled": {"max_abs": e_ref[0], "rms": e_ref[1]},
+           "scores_vs_reference_dense": {"max_abs": ed_ref[0], "rms": ed_ref[1]},
+           "decoder_chunks_not_bit_exact": dec_bad,
+           "confident_identity": {"qmin": 20, "matched": cg, "confident_ref_bases": ct, "identity": cg / max(ct, 1)},
+           "identity_vs_reference": {"median": float(np.median(id_ref)), "mean": float(id_ref.mean())}}
+    print(json.dumps(rep))
+    try:
+        os.makedirs(DUMP, exist_ok=True)
+        with open(os.path.join(DUMP, "parity_base_sup43_q8.json"), "w") as f:
+            json.dump(rep, f, indent=1)
+    except OSError:
+        pass
+    assert dec_bad == 0
+    assert ed_ref[1] <= 0.10 and e_ref[1] <= 0.10, (e_ref, ed_ref)
+    assert ct >= 500 and cg / ct >= 0.999, (cg, ct)
+
+
 def test_quantised_lstm_vs_reference():
     """The opt-in int8 LSTM path (csrc/lstm_q8.hip; the reference's KOI_I8 path, nn/LSTMStack.cpp:127-211) on the hac
     configuration at BASELINE size against the compiled f32 reference.  An 8-bit path has its OWN stated tolerance — it is

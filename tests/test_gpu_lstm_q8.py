@@ -51,7 +51,47 @@ def test_quantised_path_runs_and_tracks_f16_path(C, state_len):
 
 
 def test_quant_rejects_unsupported_shapes():
-    cfg = config.tiny(512, 5)
+    cfg = config.tiny(96, 3)
     cfg.lstm_quant = True
     with pytest.raises(capi.MibcNotSupported):
         capi.Engine(cfg, synth.make_weights(cfg, seed=1))
+    # the wide (cluster) instance needs whole 256-row clusters
+    cfg = config.tiny(512, 5)
+    cfg.lstm_quant = True
+    eng = capi.Engine(cfg, synth.make_weights(cfg, seed=1))
+    with pytest.raises(capi.MibcNotSupported):
+        eng.forward(synth.make_signal(64, 306, seed=2))
+    eng.close()
+
+
+@pytest.mark.parametrize("C,state_len,layers", [(512, 5, 3), (1024, 5, 5)])
+def test_quantised_cluster_path_tracks_f16_path_and_oracle(C, state_len, layers):
+    """Round 4: the int8 instance of the CU-cluster kernel (csrc/lstm_cluster.hip, Q8; lstm_size 512 / 768 / 1024): layer 0 in
+    f16 + conversion, the middle layers int8 -> int8, the last layer int8 -> f16 with an int8 exchange copy.  Same stated
+    tolerance as the narrow int8 kernel: scores rms <= 0.15 against the f16 path and against the f32 oracle; deterministic."""
+    cfg = config.tiny(C, state_len)
+    cfg.lstm_layers = layers
+    ws = synth.make_weights(cfg, seed=21)
+    x = synth.make_signal(512, 606, seed=22)       # two clusters of 256 rows
+    e16 = capi.Engine(cfg, ws)
+    s16 = e16.forward(x).astype(np.float32)
+    c16 = e16.call(x)
+    e16.close()
+    cfg.lstm_quant = True
+    e8 = capi.Engine(cfg, ws)
+    s8 = e8.forward(x).astype(np.float32)
+    c8 = e8.call(x)
+    assert (e8.forward(x).astype(np.float32) == s8).all()
+    e8.close()
+    d = np.clip(s8, -5, 5) - np.clip(s16, -5, 5)
+    rms = float(np.sqrt((d ** 2).mean()))
+    from parity_utils import identity
+    from oracle import oracle_py as O
+    ids = [identity(a[0], b[0]) for a, b in zip(c8, c16)]
+    s_o = O.lstm_crf_forward(cfg, ws, x[:4].astype(np.float32)[:, None, :])
+    rms_o = float(np.sqrt(((np.clip(s8[:4], -5, 5) - s_o) ** 2).mean()))
+    print(f"C={C}: int8 cluster path vs f16 path: scores rms {rms:.4f} max {np.abs(d).max():.3f}; identity median "
+          f"{np.median(ids):.3f}; vs f32 oracle rms {rms_o:.4f}")
+    assert np.isfinite(s8).all()
+    assert rms <= 0.15 and rms_o <= 0.15, (rms, rms_o)
+    assert np.median(ids) >= 0.85

@@ -1,4 +1,5 @@
-mkdir -p gpurun_out/r4c
-{ timeout 900 python -m pytest tests/test_gpu_attention.py tests/test_gpu_lstm_q8.py "tests/test_gpu_baseline_parity.py" tests/test_gpu_parity.py -q -m gpu -s 2>&1 | grep -E "passed|failed|Error|error|N=|C=|assert|case" | cut -c1-600; } > gpurun_out/r4c/tests.log 2>&1
-timeout 300 python tools/stage_times.py --model sup5 --batch 1024 --steps 2 > gpurun_out/r4c/stage_sup5.json 2>&1
-cat gpurun_out/r4c/tests.log; tail -n1 gpurun_out/r4c/stage_sup5.json
+mkdir -p gpurun_out/r4p
+timeout 600 python tools/q8_cluster_debug.py 512 3 none 2>&1 | grep -E "^C=" > gpurun_out/r4p/tests.log
+timeout 900 python -m pytest tests/test_gpu_lstm_q8.py "tests/test_gpu_baseline_parity.py::test_quantised_cluster_lstm_vs_reference" -q -m gpu -s 2>&1 | grep -E "passed|failed|rror|C=|assert|case|spin|time" | cut -c1-900 >> gpurun_out/r4p/tests.log
+timeout 300 python tools/stage_times.py --model sup --batch 8192 --steps 2 --quant 1 > gpurun_out/r4p/stage_sup_q8.json 2>&1
+cat gpurun_out/r4p/tests.log; tail -n1 gpurun_out/r4p/stage_sup_q8.json

@@ -18,11 +18,14 @@ ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--model", default="hac")
 ap.add_argument("--tin", type=int, default=0)
 ap.add_argument("--profile-level", type=int, default=1, help="2 = also roctx ranges around the stages (rocprofv3 --marker-trace)")
+ap.add_argument("--quant", type=int, default=0, help="1 = lstm_quant (the int8 LSTM path)")
 ap.add_argument("--lib", default="", help="'dbg' = dorado_amd/libmibc_dbg.so (make -C dorado_amd/csrc debug): MIBC_* switches")
 a = ap.parse_args()
 if a.lib == "dbg":
     capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), "libmibc_dbg.so")
 cfg = {"hac": config.hac_v43, "sup": config.sup_v43, "sup5": config.sup_v50, "fast": config.fast_v43}.get(a.model, lambda: config.tiny(128, 4))()
+if a.quant:
+    cfg.lstm_quant = True
 t_in = a.tin or cfg.chunk_size
 eng = capi.Engine(cfg, synth.make_weights(cfg, seed=42))
 T = eng.output_steps(t_in)
