@@ -8,6 +8,9 @@
 #include "engine.h"
 
 static int check_cluster_error(mibc_engine *e, int slot = 2);
+#ifndef MIBC_CL_WROW
+#define MIBC_CL_WROW 0     // layout of the cluster LSTM's weight slices: must equal lstm_cluster.hip's
+#endif
 static int set_geometry(mibc_engine *e, int T_in);
 
 #include <dlfcn.h>
@@ -332,11 +335,15 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
                         const size_t G = (size_t)g * C + hidden;
                         bcl[(((size_t)(jm * 2 + p) * 2 + hgi) * 4 + g) * 32 + hl] = bih[G] + bhh[G];
                         for (int ks = 0; ks < KSL; ++ks) {
-                            half_t *dst = wcl.data() + ((((size_t)(jm * 2 + p)) * KSL + ks) * 256 + row) * 32;
                             for (int kk = 0; kk < 32; ++kk) {
                                 const int k = ks * 32 + kk;
                                 const float v = (k < C) ? Wih[G * C + k] : Whh[G * C + (k - C)];
+#if MIBC_CL_WROW   // row-major [pass][256 rows][2C]: the kernel's DMA pieces apply the swizzle (lstm_cluster.hip)
+                                wcl[((size_t)(jm * 2 + p) * 256 + row) * 2 * C + k] = (half_t)v;
+#else
+                                half_t *dst = wcl.data() + ((((size_t)(jm * 2 + p)) * KSL + ks) * 256 + row) * 32;
                                 dst[(((kk >> 3) ^ ((row >> 2) & 3)) << 3) + (kk & 7)] = (half_t)v;
+#endif
                             }
                         }
                     }
@@ -371,9 +378,14 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
                             const int bq = (int)lrintf(fminf(fmaxf((bih[G] + bhh[G]) / deq, -2.0e9f), 2.0e9f));
                             memcpy(&bclq[bi], &bq, 4);
                             for (int ks = 0; ks < KSQ; ++ks) {
+#if MIBC_CL_WROW
+                                for (int kk = 0; kk < 64; ++kk)
+                                    wclq[((size_t)(jm * 2 + p) * 256 + row) * 2 * C + (size_t)ks * 64 + kk] = qrow[G * 2 * C + (size_t)ks * 64 + kk];
+#else
                                 int8_t *dst = wclq.data() + ((((size_t)(jm * 2 + p)) * KSQ + ks) * 256 + row) * 64;
                                 for (int kk = 0; kk < 64; ++kk)
                                     dst[(((kk >> 4) ^ ((row >> 2) & 3)) << 4) + (kk & 15)] = qrow[G * 2 * C + (size_t)ks * 64 + kk];
+#endif
                             }
                         }
                 if (upload(e, &dwclq, wclq) || upload(e, &dbclq, bclq) || upload(e, &ddqcl, dqcl)) return MIBC_ERR_HIP;

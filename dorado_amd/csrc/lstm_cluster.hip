@@ -60,6 +60,11 @@ typedef int int16q_t __attribute__((ext_vector_type(16)));
 #define CL_OFF_FLAGZ (CL_OFF_DEQ + 2 * 2 * 4 * 32 * 4)
 #define CL_OFF_SYNC (CL_OFF_FLAGZ + 256)
 #define CL_LDS_BYTES (CL_OFF_SYNC + 64)
+#ifndef MIBC_CL_WROW
+#define MIBC_CL_WROW 0
+#endif
+// byte distance between consecutive K slabs of a weight slice: 64 B along a row (row-major image) or one 16 KiB slab image
+#define CL_WSLAB (MIBC_CL_WROW ? 64u : (unsigned)(CL_WTILE * 2))
 
 __device__ __forceinline__ int16q_t cl_mfma_i8(half8_t a, half8_t b, int16q_t c) {
     return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(int4q_t, a), __builtin_bit_cast(int4q_t, b), c, 0, 0, 0);
@@ -148,6 +153,10 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
     const int woff = (hg * 128 + l31) * CL_BK, xoff = CL_WTILE + (rgw * 64 + l31) * CL_BK;
     const unsigned long long wslice = (unsigned long long)(Wt + (size_t)j * 2 * KS * CL_WTILE);   // uniform
     const unsigned wlane = (unsigned)(((wave * 2) * 512 + lane * 8) * 2);                              // bytes
+    // MIBC_CL_WROW = 1 (experiment, round 4; measured and NOT adopted: 207 vs 200 ms per f16 layer, 114 vs 112 int8): the
+    // member's weights stored ROW-major ([pass][256 gate rows][2C], 64-byte slab segments 2C * EB bytes apart), a DMA piece
+    // gathering 16 rows x 64 B exactly like an activation piece instead of reading 1 KiB of a pre-swizzled slab image
+    const unsigned woffb[2] = {aoff[0] * 2u - (aoff[0] & 63u), aoff[1] * 2u - (aoff[1] & 63u)};     // row pitch 2C * EB, same 16-byte column
     const unsigned aoffb[2] = {aoff[0], aoff[1]};                                                       // bytes
     const unsigned dma_lds = lds0 + (unsigned)(wave * 2) * 1024u;   // + slot * 64 KiB/2 ... + tile + q * 1 KiB
 
@@ -184,16 +193,21 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
             unsigned long long wb = wslice + w_off;
             asm volatile("" : "+s"(wb));
             asm volatile("" : "+s"(a_base));
-            ghalf_p wp = (ghalf_p)(wb + wlane);
-            cl_dma16(wp, l);
-            cl_dma16(wp + 512, l + 1024);
+            if (MIBC_CL_WROW) {
+                cl_dma16((ghalf_p)(wb + woffb[0]), l);
+                cl_dma16((ghalf_p)(wb + woffb[1]), l + 1024);
+            } else {
+                ghalf_p wp = (ghalf_p)(wb + wlane);
+                cl_dma16(wp, l);
+                cl_dma16(wp + 512, l + 1024);
+            }
             cl_dma16_sc1((ghalf_p)(a_base + aoffb[0]), l + CL_WTILE * 2);
             cl_dma16_sc1((ghalf_p)(a_base + aoffb[1]), l + CL_WTILE * 2 + 1024);
         };
 
         __syncthreads();   // bias_s visible; previous row group's LDS reads are done
         issue(0, 0u, x_cur, true);                       // slabs 0 and 1 of (step 0, pass 0): 2 slabs ahead
-        issue(1, 2u * CL_WTILE, x_cur + 2ull * CL_BK, true);
+        issue(1, CL_WSLAB, x_cur + 2ull * CL_BK, true);
 
         // ---- two wave groups in anti-phase ----
         // Waves w and w + 4 share a SIMD.  Group A = waves 0-3, group B = waves 4-7; per slab every wave runs a LOAD
@@ -408,11 +422,11 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
                         constexpr int LA = 2;
                         const int kt = ks + LA;
                         if (kt < KSX) {
-                            issue(kt & 3, w_pass + (unsigned)kt * (CL_WTILE * 2), x_cur + (unsigned)kt * (CL_BK * 2), dma_on);
+                            issue(kt & 3, w_pass + (unsigned)kt * CL_WSLAB, x_cur + (unsigned)kt * (CL_BK * 2), dma_on);
                         } else if (kt < KS) {
-                            issue(kt & 3, w_pass + (unsigned)kt * (CL_WTILE * 2), h_cur + (unsigned)(kt - KSX) * (CL_BK * 2), dma_on);
+                            issue(kt & 3, w_pass + (unsigned)kt * CL_WSLAB, h_cur + (unsigned)(kt - KSX) * (CL_BK * 2), dma_on);
                         } else {
-                            issue(kt & 3, w_n + (unsigned)(kt - KS) * (CL_WTILE * 2), x_n + (unsigned)(kt - KS) * (CL_BK * 2),
+                            issue(kt & 3, w_n + (unsigned)(kt - KS) * CL_WSLAB, x_n + (unsigned)(kt - KS) * (CL_BK * 2),
                                   dma_on && p == 0);
                         }
                         if (ks == 0 && !grpB && g_pending) gates(g_p, g_t, g_first, g_vm);

@@ -23,6 +23,8 @@ ap.add_argument("--lib", default="", help="'dbg' = dorado_amd/libmibc_dbg.so (ma
 a = ap.parse_args()
 if a.lib == "dbg":
     capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), "libmibc_dbg.so")
+elif a.lib:
+    capi.LIB_PATH = os.path.abspath(a.lib)        # an A/B build of the library (tool switch, not a product one)
 cfg = {"hac": config.hac_v43, "sup": config.sup_v43, "sup5": config.sup_v50, "fast": config.fast_v43}.get(a.model, lambda: config.tiny(128, 4))()
 if a.quant:
     cfg.lstm_quant = True
