@@ -228,7 +228,10 @@ __global__ __launch_bounds__(NW * 64, 2) void wsgemm_kernel(WsArgs p) {
                             } else {
                                 orow = p.out + ((size_t)(out_base + row) * p.N + grp) * p.cols;
                             }
-                            *(half8_t *)(orow + col0 + seg * 8) = v;
+                            // head: streamed (nt) stores — the 56 GB of scores are not read back by this kernel (25.1 -> 24.2 ms on
+                            // the hac batch, same box); conv3 keeps the default policy (nt measured 16.4 -> 17.5 ms)
+                            if (MODE == 0) __builtin_nontemporal_store(v, (half8_t *)(orow + col0 + seg * 8));
+                            else *(half8_t *)(orow + col0 + seg * 8) = v;
                         }
                     }
                 }
