@@ -345,6 +345,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="chunks per GPU per step (0 = auto)")
     ap.add_argument("--model", default="hac")
+    ap.add_argument("--quant", type=int, default=0,
+                    help="1 = run --model with the opt-in int8 LSTM path (lstm_quant); for rocprofv3 / PMC passes of the int8 kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-run", action="store_true",
                     help="for rocprofv3 --stats: no small-batch parity call, so per-kernel averages are full-batch launches")
@@ -380,6 +382,8 @@ def main():
     if args.model not in factories:
         raise SystemExit(f"unknown model {args.model}")
     cfg = factories[args.model]()
+    if args.quant:
+        cfg.lstm_quant = True
 
     def barrier():
         torch.cuda.synchronize()

@@ -1044,6 +1044,18 @@ std::vector<CalledRead> SimplexBasecaller::basecall_variable(const std::vector<s
         }
     }
     std::mutex qmut;
+    std::vector<std::atomic<int>> remaining(reads.size());
+    for (size_t r = 0; r < reads.size(); ++r) remaining[r].store(int(chunks[r].size()));
+    auto stitch_read = [&](size_t r) {
+        std::vector<const Chunk *> cc;
+        for (auto &c : chunks[r]) cc.push_back(&c);
+        StitchedRead st = stitch_chunks(cc, reads[r].size(), m_stride);
+        out[r].seq = std::move(st.seq);
+        out[r].qstring = std::move(st.qstring);
+        out[r].moves = std::move(st.moves);
+        std::vector<Chunk>().swap(chunks[r]);
+        m_samples_processed += int64_t(reads[r].size());
+    };
     auto worker = [&](ModelRunnerBase *base, std::atomic<bool> &failed) {
         auto *runner = dynamic_cast<HipModelRunner *>(base);
         if (!runner) throw std::runtime_error("variable chunk sizes need a HipModelRunner");
@@ -1082,19 +1094,12 @@ std::vector<CalledRead> SimplexBasecaller::basecall_variable(const std::vector<s
                 c.seq = std::move(decoded[k].sequence);
                 c.qstring = std::move(decoded[k].qstring);
                 c.moves = std::move(decoded[k].moves);
+                // the worker that delivers a read's last chunk stitches it (as basecall() does): no serial pass at the end
+                if (remaining[mine[k].read].fetch_sub(1) == 1) stitch_read(mine[k].read);
             }
         }
     };
     run_workers(m_runners, worker);
-    for (size_t r = 0; r < reads.size(); ++r) {
-        std::vector<const Chunk *> cc;
-        for (auto &c : chunks[r]) cc.push_back(&c);
-        StitchedRead st = stitch_chunks(cc, reads[r].size(), m_stride);
-        out[r].seq = std::move(st.seq);
-        out[r].qstring = std::move(st.qstring);
-        out[r].moves = std::move(st.moves);
-        m_samples_processed += int64_t(reads[r].size());
-    }
     return out;
 }
 
