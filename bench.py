@@ -230,7 +230,8 @@ def dominant_kernel(cfg, n):
     if cfg.lstm_size <= 384 and getattr(cfg, "lstm_quant", False):
         return "lstm_layer_q8_kernel<%d>" % cfg.lstm_size, "lstm_layer_q8"
     if getattr(cfg, "lstm_quant", False):
-        return "lstm_layer_cl_kernel<%d, int8>" % cfg.lstm_size, "lstm_layer_cl"
+        # (the mangled name of the int8 -> int8 instance: template arguments <C, MASKED = false, DBG = 0, Q8 = 1>)
+        return "lstm_layer_cl_kernel<%d, int8>" % cfg.lstm_size, "lstm_layer_cl_kernelILi%dELb0ELi0ELi1E" % cfg.lstm_size
     if cfg.lstm_size <= 384:
         return "lstm_layer_x8_kernel<%d>" % cfg.lstm_size, "lstm_layer_x8"
     if n % 256 == 0 and cfg.lstm_size in (512, 768, 1024):

@@ -198,7 +198,10 @@ __device__ __forceinline__ int lanes_below(unsigned long long m, int lane) {
 #define BS_CAND (5 * BS_MAXW)
 
 template <int S>
-__global__ __launch_bounds__(64) void beam_search_kernel(
+// amdgpu_waves_per_eu(8): the kernel is latency-bound (one wave per chunk, a serial chain per step), so resident waves are its
+// throughput; left alone hipcc takes 86 VGPRs for S = 256 (5 waves per SIMD = 20 chunks per CU); asked for 8 it needs 63 without
+// scratch, and the 5.5 KB LDS arena then sets the limit (29 chunks per CU).  (S = 1024 keeps its 138 registers: LDS-bound at 10.)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void beam_search_kernel(
         const half_t *__restrict__ scores,   // [N][T][4S]
         const float *__restrict__ bwd,       // [N][T+1][S]
         uint32_t *__restrict__ trace,        // [N][T+1][W]  state | prev<<16 | stay<<24

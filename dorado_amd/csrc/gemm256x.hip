@@ -400,6 +400,11 @@ extern "C" int mibc_launch_gemm256x(hipStream_t s, const GemmArgs *a) {
     int stagger = 0;
 #ifdef MIBC_DEBUG_KERNELS
     stagger = MIBC_ENV_INT("MIBC_GX_STAGGER", 0);
+    if (MIBC_ENV_INT("MIBC_GX_OFF", 0)) return 1;          // A/B inside the engine: fall back to gemm256_kernel
+    {
+        const int c = MIBC_ENV_INT("MIBC_GX_CG", 0), ncol = a->Ncols / 256;
+        if (c > 0 && ncol % c == 0 && (ncol / c == 1 || ncol / c == 2 || ncol / c == 4 || ncol / c == 8)) cg = c;
+    }
 #endif
 #ifdef MIBC_DEBUG_KERNELS
     // microbenchmark switches (tools/gemm_bench.py): dbg = 0x2000 | (col group << 4) | ablation bits (1, 2, 8)

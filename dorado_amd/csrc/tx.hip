@@ -546,37 +546,38 @@ __global__ __launch_bounds__(512) void window_attention_v3_kernel(
             const float2a c2 = {cs, cs};
             const float nm = -m * cs;
             const float2a nm2 = {nm, nm};
+            // exponentials and the PV product, two key tiles at a time: the four MFMAs of a block run in the matrix pipe while
+            // the VALU works on the next block's exponentials (the sum is only needed for the final normalisation)
             float2a sum2 = {0.0f, 0.0f};
-            half2_t ph[KW][2];
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                for (int hp = 0; hp < 2; ++hp) {
-                    const float2a s2 = {sc[i][2 * hp], sc[i][2 * hp + 1]};
-                    const float2a t2 = __builtin_elementwise_fma(s2, c2, nm2);
-                    float2a e2;
-                    e2[0] = __builtin_amdgcn_exp2f(t2[0]);
-                    e2[1] = __builtin_amdgcn_exp2f(t2[1]);
-                    sum2 += e2;
-                    ph[i][hp] = __builtin_convertvector(e2, half2_t);
-                }
-            float sum = sum2[0] + sum2[1];
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            const float inv = __builtin_amdgcn_rcpf(sum);
             float4a oacc[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) oacc[dt] = (float4a)(0.0f);
 #pragma unroll
             for (int blk = 0; blk < (NT + 1) / 2; ++blk) {
                 const bool second = (2 * blk + 1 < NT);     // the standard window ends on a single tile (16)
-                half8_t pf;
-                pf[0] = ph[2 * blk][0][0]; pf[1] = ph[2 * blk][0][1]; pf[2] = ph[2 * blk][1][0]; pf[3] = ph[2 * blk][1][1];
-                if (second) {
-                    pf[4] = ph[2 * blk + 1][0][0]; pf[5] = ph[2 * blk + 1][0][1]; pf[6] = ph[2 * blk + 1][1][0]; pf[7] = ph[2 * blk + 1][1][1];
-                } else {
-                    pf[4] = pf[5] = pf[6] = pf[7] = (half_t)0.0f;
+                half2_t ph[2][2];
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = 2 * blk + ii;
+                    if (ii == 1 && !second) {
+                        ph[1][0] = half2_t{(half_t)0.0f, (half_t)0.0f};
+                        ph[1][1] = ph[1][0];
+                        continue;
+                    }
+#pragma unroll
+                    for (int hp = 0; hp < 2; ++hp) {
+                        const float2a s2 = {sc[i][2 * hp], sc[i][2 * hp + 1]};
+                        const float2a t2 = __builtin_elementwise_fma(s2, c2, nm2);
+                        float2a e2;
+                        e2[0] = __builtin_amdgcn_exp2f(t2[0]);
+                        e2[1] = __builtin_amdgcn_exp2f(t2[1]);
+                        sum2 += e2;
+                        ph[ii][hp] = __builtin_convertvector(e2, half2_t);
+                    }
                 }
+                half8_t pf;
+                pf[0] = ph[0][0][0]; pf[1] = ph[0][0][1]; pf[2] = ph[0][1][0]; pf[3] = ph[0][1][1];
+                pf[4] = ph[1][0][0]; pf[5] = ph[1][0][1]; pf[6] = ph[1][1][0]; pf[7] = ph[1][1][1];
                 const int s0 = (k0 + (wave + 2 * blk) * 16) & (RING - 1);
                 const int s1 = (k0 + (wave + 2 * blk + 1) * 16) & (RING - 1);
 #pragma unroll
@@ -594,6 +595,10 @@ __global__ __launch_bounds__(512) void window_attention_v3_kernel(
                     oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
                 }
             }
+            float sum = sum2[0] + sum2[1];
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = __builtin_amdgcn_rcpf(sum);
             half_t *orow = out + (row0 + qi) * C + h * 64;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {

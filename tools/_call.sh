@@ -1,16 +1,7 @@
-mkdir -p gpurun_out/r4t && cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-( time timeout 1500 python $R/bench.py ) > $R/gpurun_out/r4t/bench.json 2> $R/gpurun_out/r4t/bench.err
-tail -5 $R/gpurun_out/r4t/bench.err; python - <<'PY'
-import json,os
-l=[x for x in open(os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/r4t/bench.json') if x.startswith('{')]
-d=json.loads(l[-1])
-print("value %.4g ms/step %.1f"%(d['value'], d['ms_per_step']), d['stage_ms_last_step'])
-print("roofline", {k:d['roofline'][k] for k in ('kernel','frac','launch_ms','traffic')})
-print("cpu", d.get('cpu_baseline'))
-for k in ('through_host','through_host_multi_chunk_reads','through_host_variable'):
-    v=d.get(k,{}); print(k, {a:v[a] for a in v if a!='what'})
-for k,v in d.get('extra',{}).items():
-    if 'error' in v: print(k, v); continue
-    print(k, "%.4g"%v['samples_per_s'], "ms %.1f"%v['ms_per_step'], v['stage_ms_last_step'], v['roofline']['frac'], v['parity'].get('ok'), (v.get('cpu_baseline') or {}).get('value'))
-PY
+mkdir -p gpurun_out/r4w
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_parity.py -q -m gpu -k "decod or baseline or beam or exact" 2>&1 | tail -2 > gpurun_out/r4w/t.log
+for i in 1 2; do timeout 300 python tools/stage_times.py --model hac --batch 16384 --steps 3 2>&1 | tail -1 | cut -c1-100 >> gpurun_out/r4w/t.log; done
+cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r4w/st -o s -- python $R/tools/stage_times.py --model hac --batch 16384 --steps 3 > /dev/null 2>&1
+f=$(find $R/gpurun_out/r4w/st -name '*kernel_stats.csv' | head -1); grep -E "beam|bwd_scan|posts" $f | cut -c1-120 >> $R/gpurun_out/r4w/t.log; rm -rf $R/gpurun_out/r4w/st
+cat $R/gpurun_out/r4w/t.log
