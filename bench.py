@@ -195,6 +195,22 @@ def cpu_baseline(cfg, ws, t_in, kind_model, full=False, budget_s=20.0):
                       f"1 torch thread per runner, 1 untimed warm-up call per runner, forward+decode"}
 
 
+def single_process_hip_all(cfg, ws, n, t_in, ndev_expected, per_process_value, nb=8, k=5):
+    """north_star's multi-GPU shape: ONE process, one HipCaller per visible device fed from shared chunk queues
+    (api/runner_creation.cpp:85-124), k-chunk reads through both chunk-size queues, PCIe + slicing + stitching included."""
+    from dorado_amd import hostapi, synth
+    rl = t_in + (k - 1) * (t_in - cfg.overlap)
+    reads = synth.make_signal(64, rl, seed=78)
+    nr = max(1, (nb * n * ndev_expected) // k)
+    sp = hostapi.bench_through_host(cfg, ws, reads, n_warm=max(1, (2 * n * ndev_expected) // k), n_reads=nr, device="hip:all",
+                                    num_runners=2, batch_size=n, two_queues=True)
+    sp["vs_per_process_value_incl_overlap"] = sp["samples_incl_padding_per_s"] / per_process_value
+    sp["what"] = (f"ONE process, hip:all = {sp['devices']} devices, one HipCaller per device, 2 runners per device and chunk-size "
+                  f"queue, {nr} reads of {rl} samples ({k} chunks, overlap {cfg.overlap}) through both chunk-size queues, PCIe + "
+                  f"slicing + stitching included; `value` is {ndev_expected} processes, one per GPU")
+    return sp
+
+
 def bench_scale_parity(eng, out, d_in, n, t_in, T, period):
     """Bench-scale output check (outside the timed region).  The batch tiles `period` distinct chunks, so
     (1) every output row i must be byte-identical to row i % period (all three planes: moves, bases,
@@ -294,7 +310,8 @@ def run_config(capi, synth, cfg, model_key, device, steps, warmup, batch=0, seed
     kname, ksub = dominant_kernel(cfg, n)
     peak, dt = MFMA_F16_PEAK, "f16"
     if cfg.tx is None and getattr(cfg, "lstm_quant", False):
-        # layers 2..L are the int8 kernel (layer 1 = f16 kernel + conversion): dense int8 MFMA peak = 2x the f16 peak
+        # the int8 kernel's launches: all layers but the first (which carries the f16 -> int8 conversion of conv3's output, or
+        # is the f16 kernel for a swish front end); dense int8 MFMA peak = 2x the f16 peak
         per_layer = np.array(lstm_ms).reshape(-1, cfg.lstm_layers)[:, 1:]
         k_ms = float(per_layer.mean())
         fl = lstm_flops_per_launch(cfg, n, T)
@@ -538,18 +555,7 @@ def main():
         dist.barrier()
         if rank == 0:
             try:
-                from dorado_amd import hostapi
-                k, nb = 5, 8
-                rl = t_in + (k - 1) * (t_in - cfg.overlap)
-                reads5 = synth.make_signal(64, rl, seed=78)
-                nr = (nb * n * world) // k
-                sp = hostapi.bench_through_host(cfg, ws, reads5, n_warm=(2 * n * world) // k, n_reads=nr, device="hip:all",
-                                                num_runners=2, batch_size=n, two_queues=True)
-                sp["vs_per_process_value_incl_overlap"] = sp["samples_incl_padding_per_s"] / line["value"]
-                sp["what"] = (f"ONE process, hip:all = {sp['devices']} devices, one HipCaller per device, 2 runners per device and "
-                              f"chunk-size queue, {nr} reads of {rl} samples ({k} chunks, overlap {cfg.overlap}) through both "
-                              f"chunk-size queues, PCIe + slicing + stitching included; `value` above is {world} processes")
-                line.setdefault("extra", {})["single_process_hip_all"] = sp
+                line.setdefault("extra", {})["single_process_hip_all"] = single_process_hip_all(cfg, ws, n, t_in, world, line["value"])
             except Exception as ex:
                 line.setdefault("extra", {})["single_process_hip_all"] = {"error": repr(ex)}
         dist.barrier()

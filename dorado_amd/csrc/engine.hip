@@ -248,6 +248,9 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
             if (upload(e, &e->w3f, to_frag16(w, C, e->K3pad))) return MIBC_ERR_HIP;
     }
     // LSTM layers: [W_ih | W_hh] in MFMA-fragment order + summed biases in D-register order
+    // the reference quantises EVERY LSTM layer when the convolution in front hands over tanh outputs (nn/ConvStack.cpp:72:
+    // CUTLASS_TNC_I8 for Activation::TANH — the v4.3 LSTM-CRF models), and keeps the first layer in f16 otherwise (:73, LSTMStack.cpp:199-207)
+    const bool q_all = d.lstm_quant && d.n_convs >= 3 && d.conv_act[d.n_convs - 1] == MIBC_ACT_TANH;
     for (int l = 0; l < d.lstm_layers; ++l) {
         const float *Wih = weights[wi++], *Whh = weights[wi++], *bih = weights[wi++],
                     *bhh = weights[wi++];
@@ -294,7 +297,7 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
         e->lstm_bn.push_back(dbn);
         int8_t *dwq = nullptr;
         float *ddeq = nullptr;
-        if (d.lstm_quant && l >= 1 && C <= 384) {
+        if (d.lstm_quant && (l >= 1 || q_all) && C <= 384) {
             // utils::quantize_tensor(cat(W_ih, W_hh, 1), 1) (torch_utils/tensor_utils.cpp:293-300, LSTMStack.cpp:165-172):
             // per output row scale = 128 / max|row|, round to nearest even, clip +-127
             const int KS64 = 2 * C / 64;
@@ -355,7 +358,7 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
             e->lstm_bcl.push_back(dbcl);
             int8_t *dwclq = nullptr;
             float *dbclq = nullptr, *ddqcl = nullptr;
-            if (d.lstm_quant && l >= 1) {
+            if (d.lstm_quant && (l >= 1 || q_all)) {
                 // the quantised instance of the cluster kernel: the same per-row quantisation (utils::quantize_tensor,
                 // LSTMStack.cpp:165-172), slab images of 256 gate rows x 64 k (64-byte rows, same XOR swizzle of the 16-byte
                 // column); accumulators start from round(bias / deq[row]) (an int32: the rounding is < deq / 2 ~ 1e-5 of
@@ -743,6 +746,15 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
         return fail(e, MIBC_NOT_SUPPORTED, "conv3 gemm shape");
     if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_CONV], e->stream));
     half_t *cur = e->xa, *nxt = e->xb;
+    // lstm_quant: every layer int8 when conv3 hands over tanh outputs (the reference's CUTLASS_TNC_I8 layout, nn/ConvStack.cpp:72),
+    // else the first layer in f16 (LSTMStack.cpp:199-207); conv3's f16 output is converted once (round(127 v), v in (-1, 1))
+    const bool q_all = d.lstm_quant && d.n_convs >= 3 && d.conv_act[d.n_convs - 1] == MIBC_ACT_TANH;
+    if (q_all) {
+        if (mibc_launch_q8_convert(e->stream, cur, (int8_t *)nxt, (size_t)T * N * e->C) != 0) return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
+        half_t *t = cur;
+        cur = nxt;
+        nxt = t;
+    }
     for (int l = 0; l < d.lstm_layers; ++l) {
         // LSTMStack(layers, size, reverse_first = true): nn/LSTMStack.cpp:29-41, CRFModel.cpp:41
         const int reverse = (l % 2 == 0) ? 1 : 0;
@@ -750,7 +762,7 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
         // wide layers: the hidden-split cluster kernel whenever the batch is a whole number of 256-row clusters
         // (same arithmetic, element for element, as the per-workgroup kernel it replaces)
         const bool wide_q = d.lstm_quant && e->C >= 512;
-        const bool cl_ok = !(wide_q && l >= 1) && (!d.lstm_quant || wide_q) &&
+        const bool cl_ok = !(wide_q && (l >= 1 || q_all)) && (!d.lstm_quant || wide_q) &&
                            e->use_cluster && !e->lstm_wcl.empty() && e->cl_flags != nullptr && N % 256 == 0 &&
                            mibc_launch_lstm_layer_cl(e->stream, e->C, cur, nxt, e->lstm_wcl[l], e->lstm_bcl[l],
                                                      e->lstm_zero, e->cl_cstate, e->cl_flags, e->cl_err, T, N, reverse,
@@ -763,7 +775,7 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
             if (e->in_tmask != nullptr) return fail(e, MIBC_NOT_SUPPORTED, "lstm_quant: variable chunks are not supported");
             if (N % 256 != 0 || e->cl_flags == nullptr)
                 return fail(e, MIBC_NOT_SUPPORTED, "lstm_quant with lstm_size >= 512 needs batches that are multiples of 256");
-            if (l == 0) {
+            if (l == 0 && !q_all) {
                 if (!cl_ok) return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
                 e->cl_used = true;
                 if (mibc_launch_q8_convert(e->stream, nxt, (int8_t *)cur, (size_t)T * N * e->C) != 0)
@@ -782,7 +794,7 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
             // the reference's quantised path: first layer f16 + conversion of its output (LSTMStack.cpp:199-207), then int8
             if (e->in_tmask != nullptr) return fail(e, MIBC_NOT_SUPPORTED, "lstm_quant: variable chunks are not supported");
             int qrc;
-            if (l == 0) {
+            if (l == 0 && !q_all) {
                 qrc = mibc_launch_lstm_layer(e->stream, e->C, cur, nxt, e->lstm_w[l], e->lstm_w16[l], e->lstm_bn[l], T, N, reverse);
                 // f16 output of layer 0 (nxt) -> int8 into the buffer layer 0 read from (cur): layer 1 then reads `cur`,
                 // so the ping-pong is NOT swapped after this layer

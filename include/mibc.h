@@ -60,8 +60,10 @@ typedef struct mibc_model_desc {
     int up_size, up_scale_factor;
     float crf_scale, crf_blank_score;
     int crf_expand_blanks;
-    /* 1: the reference's quantised LSTM path (nn/LSTMStack.cpp:127-211, KOI_I8): layers 2..L run on int8 weights
-     * (per-row scales, utils::quantize_tensor) and int8 activations, the first layer in f16 (:199-207).  LSTM models with
+    /* 1: the reference's quantised LSTM path (nn/LSTMStack.cpp:127-211, KOI_I8): int8 weights (per-row scales,
+     * utils::quantize_tensor) and int8 activations — for EVERY layer when the last convolution's activation is tanh (the
+     * v4.3 LSTM-CRF models: nn/ConvStack.cpp:72 hands over CUTLASS_TNC_I8), else layers 2..L with the first layer in f16
+     * (:73, LSTMStack.cpp:199-207).  LSTM models with
      * lstm_size 128 / 256 / 384 (any batch) or 512 / 768 / 1024 (batches that are multiples of 256) and >= 2 layers; not
      * combinable with variable chunks.  0 (default): f16 throughout — the path the parity contract is stated for. */
     int lstm_quant;

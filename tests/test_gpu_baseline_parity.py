@@ -181,7 +181,7 @@ def test_baseline_size_vs_reference(name):
 def test_quantised_cluster_lstm_vs_reference():
     """Round 4: the int8 instance of the cluster LSTM kernel (lstm_size 1024: the sup@v4.3 shape, where the reference's GPU
     path is int8 too, nn/LSTMStack.cpp:127-211) at BASELINE size against the compiled f32 reference.  The fixture's 32 chunks
-    are tiled to 256 rows (the cluster kernel works on whole 256-row clusters).  Own tolerance: dense scores rms <= 0.10,
+    are tiled to 256 rows (the cluster kernel works on whole 256-row clusters).  Own tolerance: dense scores rms <= 0.13 [0.101],
     decoder bit-exact on the device's own scores, identity on the reference's confident bases (q >= 20) >= 0.999."""
     g = np.load(os.path.join(GOLDEN, "base_sup43.npz"))
     gd = np.load(os.path.join(GOLDEN, "base_sup43_dense.npz"))
@@ -221,7 +221,8 @@ def test_quantised_cluster_lstm_vs_reference():
     except OSError:
         pass
     assert dec_bad == 0
-    assert ed_ref[1] <= 0.10 and e_ref[1] <= 0.10, (e_ref, ed_ref)
+    # all five layers int8 (the reference's scheme for tanh-conv models): measured rms 0.101; tolerance 1.3x that
+    assert ed_ref[1] <= 0.13 and e_ref[1] <= 0.13, (e_ref, ed_ref)
     assert ct >= 500 and cg / ct >= 0.999, (cg, ct)
 
 
@@ -229,7 +230,7 @@ def test_quantised_lstm_vs_reference():
     """The opt-in int8 LSTM path (csrc/lstm_q8.hip; the reference's KOI_I8 path, nn/LSTMStack.cpp:127-211) on the hac
     configuration at BASELINE size against the compiled f32 reference.  An 8-bit path has its OWN stated tolerance — it is
     reported beside the f16 path, which stays the parity headline:
-        scores vs reference (dense, 4 chunks x all steps): rms <= 0.10 [0.075], and the decoder stays bit-exact on the device's
+        scores vs reference (dense, 4 chunks x all steps): rms <= 0.13 [0.102], and the decoder stays bit-exact on the device's
         own scores; identity on the reference's confident bases (q >= 20) >= 0.999 [3787 / 3789]; measured values are written to
         gpurun_out/parity_base_hac_q8.json (DESIGN.md quotes them)."""
     g = np.load(os.path.join(GOLDEN, "base_hac.npz"))
@@ -267,6 +268,8 @@ def test_quantised_lstm_vs_reference():
     except OSError:
         pass
     assert dec_bad == 0
-    # round 4: tolerances at 1.3x the measured values (rms 0.075, confident identity 3787 / 3789), not 3x
-    assert ed_ref[1] <= 0.10 and e_ref[1] <= 0.10, (e_ref, ed_ref)
+    # round 4: tolerances at 1.3x the measured values, not 3x.  With the first layer in f16 the rms was 0.075; the path now
+    # follows the reference for tanh-conv models (nn/ConvStack.cpp:72: EVERY layer int8): measured rms 0.102, confident
+    # identity 3787 / 3789
+    assert ed_ref[1] <= 0.13 and e_ref[1] <= 0.13, (e_ref, ed_ref)
     assert ct >= 500 and cg / ct >= 0.999, (cg, ct)

@@ -188,3 +188,18 @@ def test_variable_chunks_beyond_one_decode_sub_batch():
         alone = eng.call_var(xa, [(0, 0, ln)])[0]
         assert got[k][0] == alone[0] and got[k][1] == alone[1] and (got[k][2] == alone[2]).all(), f"chunk {k} (row {row})"
     eng.close()
+
+
+def test_bench_single_process_hip_all_leg_runs():
+    """bench.py's extra.single_process_hip_all (reported at --gpus N > 1 by rank 0): the same function on whatever devices are
+    visible (one here) — the call path of the 8-GPU line must not be exercised for the first time by the driver's SCALE run."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    cfg = _cfg(128, 4)
+    cfg.chunk_size, cfg.overlap = 1200, 120
+    cfg.normalise_basecaller_params()
+    ws = synth.make_weights(cfg, seed=3)
+    sp = bench.single_process_hip_all(cfg, ws, 64, cfg.chunk_size, capi.device_count(), 1.0e6, nb=4)
+    assert sp["devices"] == capi.device_count() and sp["samples_per_s"] > 0 and sp["bases"] > 0
