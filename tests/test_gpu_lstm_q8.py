@@ -64,7 +64,7 @@ def test_quant_rejects_unsupported_shapes():
     eng.close()
 
 
-@pytest.mark.parametrize("C,state_len,layers", [(512, 5, 3), (1024, 5, 5)])
+@pytest.mark.parametrize("C,state_len,layers", [(512, 5, 3), (768, 5, 2), (1024, 5, 5)])
 def test_quantised_cluster_path_tracks_f16_path_and_oracle(C, state_len, layers):
     """Round 4: the int8 instance of the CU-cluster kernel (csrc/lstm_cluster.hip, Q8; lstm_size 512 / 768 / 1024): layer 0 in
     f16 + conversion, the middle layers int8 -> int8, the last layer int8 -> f16 with an int8 exchange copy.  Same stated
@@ -95,3 +95,26 @@ def test_quantised_cluster_path_tracks_f16_path_and_oracle(C, state_len, layers)
     assert np.isfinite(s8).all()
     assert rms <= 0.15 and rms_o <= 0.15, (rms, rms_o)
     assert np.median(ids) >= 0.85
+
+
+@pytest.mark.parametrize("C,state_len,N", [(256, 4, 128), (512, 5, 256)])
+def test_quantised_path_with_swish_front_end_keeps_first_layer_f16(C, state_len, N):
+    """The reference hands int8 to the FIRST LSTM layer only when the last convolution ends in tanh (nn/ConvStack.cpp:72); with a
+    swish front end the first layer runs in f16 and its output is converted (nn/LSTMStack.cpp:199-207).  Both branches exist
+    here (engine.hip q_all); the tanh models of the other tests take the all-int8 one, this test the other."""
+    cfg = config.tiny(C, state_len)
+    cfg.lstm_layers = 3
+    cfg.convs[2].activation = config.ACT_SWISH_CLAMP
+    ws = synth.make_weights(cfg, seed=31)
+    x = synth.make_signal(N, 606, seed=32)
+    e16 = capi.Engine(cfg, ws)
+    s16 = e16.forward(x).astype(np.float32)
+    e16.close()
+    cfg.lstm_quant = True
+    e8 = capi.Engine(cfg, ws)
+    s8 = e8.forward(x).astype(np.float32)
+    e8.close()
+    d = np.clip(s8, -5, 5) - np.clip(s16, -5, 5)
+    rms = float(np.sqrt((d ** 2).mean()))
+    print(f"C={C} swish front end: int8 (layers 2..L) vs f16: scores rms {rms:.4f} max {np.abs(d).max():.3f}")
+    assert np.isfinite(s8).all() and rms <= 0.15

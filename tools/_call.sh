@@ -1,1 +1,3 @@
-SPECS="hac:1:16384:9996 sup:1:8192:9996" bash tools/refresh_profiles.sh r04_d 2>&1 | cut -c1-160 | tail -40
+mkdir -p gpurun_out/r4z
+timeout 900 python -m pytest tests/test_gpu_lstm_q8.py tests/test_gpu_multi.py -q -m gpu -s 2>&1 | grep -E "passed|failed|rror|C=|assert" | cut -c1-300 > gpurun_out/r4z/t.log
+cat gpurun_out/r4z/t.log
