@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/r4z
-timeout 900 python -m pytest tests/test_gpu_lstm_q8.py tests/test_gpu_multi.py -q -m gpu -s 2>&1 | grep -E "passed|failed|rror|C=|assert" | cut -c1-300 > gpurun_out/r4z/t.log
-cat gpurun_out/r4z/t.log
+mkdir -p gpurun_out/r4aa
+timeout 300 python tools/txlayer_time.py 1048576 2 0x102 0x202 3 2>&1 | grep -E "^mode|stamps" | cut -c1-200 > gpurun_out/r4aa/t.log
+cat gpurun_out/r4aa/t.log

@@ -8,7 +8,7 @@ from dorado_amd import capi
 import os
 if os.environ.get("MIBC_LIB"):      # A/B of an alternative build (tools/txlayer_store16_ab.sh); a tool switch, not a product one
     capi.LIB_PATH = os.path.abspath(os.environ["MIBC_LIB"])
-L = capi.lib()
+L = capi.dbg_lib() if not os.environ.get("MIBC_LIB") else capi.lib()
 L.mibc_debug_txlayer_compare.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)] + \
     [C.POINTER(C.c_float)] * 5 + [C.c_void_p, C.c_void_p]
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 1024 * 1024
