@@ -396,7 +396,10 @@ __global__ __launch_bounds__(512) void window_attention_v2_kernel(
 // memory latency per tile with a single workgroup per CU); here a tile brings in only its 128 new keys, requested
 // before the tile's matrix work and written behind it.  Same per-wave tile mapping and operation order as v2
 // (bit-identical results).  Needs back % 16 == 0 and T % 128 == 0.
-template <int KW>
+// DBG (debug library only; wrong results): 1 = no exponentials (p = raw score), 2 = no PV product, 4 = no QK^T product,
+// 8 = the ring is not refilled after the first tile (no global loads / LDS writes / ring barriers per tile), 16 = no K / V
+// fragment reads from LDS, 32 = no output stores
+template <int KW, int DBG = 0>
 __global__ __launch_bounds__(512) void window_attention_v3_kernel(
         const half_t *__restrict__ qk,   // [N*T][ld]  q | k (| unused), head h at h*64
         const half_t *__restrict__ vT,   // [N][H][64][T]
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(512) void window_attention_v3_kernel(
         const int q0 = qt * 128;
         const int k0 = q0 - back;
         // ---- request the 128 keys the NEXT tile adds: [k0 + NK, k0 + NK + 128), and its query fragments ----
-        const bool more = (qt + 1 < qtiles);
+        const bool more = (qt + 1 < qtiles) && !(DBG & 8);
         half8_t kn[2], vn[2], qn[2];
         const int knew = k0 + NK;
 #pragma unroll
@@ -518,8 +521,11 @@ __global__ __launch_bounds__(512) void window_attention_v3_kernel(
                 const int slot = (k0 + (wave + i) * 16) & (RING - 1);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
-                    const half8_t kf = *(const half8_t *)(Ks + (slot + l15) * KLD + kb * 32 + 8 * lq);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kb], acc, 0, 0, 0);
+                    half8_t kf;
+                    if (DBG & 16) kf = qf[kb ^ 1];      // ablation: no K fragment reads from LDS
+                    else kf = *(const half8_t *)(Ks + (slot + l15) * KLD + kb * 32 + 8 * lq);
+                    if (!(DBG & 4)) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kb], acc, 0, 0, 0);
+                    else acc[0] += (float)kf[0] * (float)qf[kb][0];
                 }
                 sc[i] = acc;
             }
@@ -569,8 +575,12 @@ __global__ __launch_bounds__(512) void window_attention_v3_kernel(
                         const float2a s2 = {sc[i][2 * hp], sc[i][2 * hp + 1]};
                         const float2a t2 = __builtin_elementwise_fma(s2, c2, nm2);
                         float2a e2;
-                        e2[0] = __builtin_amdgcn_exp2f(t2[0]);
-                        e2[1] = __builtin_amdgcn_exp2f(t2[1]);
+                        if (DBG & 1) {
+                            e2 = t2;
+                        } else {
+                            e2[0] = __builtin_amdgcn_exp2f(t2[0]);
+                            e2[1] = __builtin_amdgcn_exp2f(t2[1]);
+                        }
                         sum2 += e2;
                         ph[ii][hp] = __builtin_convertvector(e2, half2_t);
                     }
@@ -583,16 +593,20 @@ __global__ __launch_bounds__(512) void window_attention_v3_kernel(
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const half_t *vp = Vt + (dt * 16 + l15) * VLD + 4 * lq;
-                    const half4_t v0 = *(const half4_t *)(vp + s0);
+                    half4_t v0 = {(half_t)0.5f, (half_t)0.25f, (half_t)0.125f, (half_t)1.0f};
                     half4_t v1 = {(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
-                    if (second) v1 = *(const half4_t *)(vp + s1);
+                    if (!(DBG & 16)) {                   // (DBG 16: no V fragment reads from LDS)
+                        v0 = *(const half4_t *)(vp + s0);
+                        if (second) v1 = *(const half4_t *)(vp + s1);
+                    }
                     half8_t vf;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         vf[i] = v0[i];
                         vf[4 + i] = v1[i];
                     }
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
+                    if (!(DBG & 2)) oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
+                    else oacc[dt][0] += (float)vf[0] * (float)pf[dt];
                 }
             }
             float sum = sum2[0] + sum2[1];
@@ -605,13 +619,14 @@ __global__ __launch_bounds__(512) void window_attention_v3_kernel(
                 half4_t o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (half_t)(oacc[dt][r] * inv);
-                *(half4_t *)(orow + dt * 16 + 4 * lq) = o;
+                if (DBG & 32) asm volatile("" ::"v"(o));      // ablation: no output stores
+                else *(half4_t *)(orow + dt * 16 + 4 * lq) = o;
             }
         };
         if (edge) tile_body(std::true_type{});
         else tile_body(std::false_type{});
         // ---- the new keys overwrite slots of keys < k0 + 128 + ... that this tile still read: barrier on both sides ----
-        __syncthreads();
+        if (!(DBG & 8)) __syncthreads();
         if (more) {
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
@@ -622,11 +637,12 @@ __global__ __launch_bounds__(512) void window_attention_v3_kernel(
         }
         qf[0] = qn[0];
         qf[1] = qn[1];
-        __syncthreads();
+        if (!(DBG & 8)) __syncthreads();
     }
 }
 
 static int g_att_force_restage = 0;   // test hook (mibc_debug_attention_compare): run the re-staging v2 kernel
+static int g_att_dbg = 0;             // debug library: ablation instance of the ring kernel (timing only)
 
 extern "C" int mibc_launch_window_attention_v2(hipStream_t s, const half_t *qk, const half_t *vT, half_t *out,
                                                int N, int T, int C, int H, int ld, int win_upper,
@@ -640,6 +656,16 @@ extern "C" int mibc_launch_window_attention_v2(hipStream_t s, const half_t *qk, 
     const int split = (((T + 11) / 12) + 3) / 4 * 4;
     const int npairs = N * H;
     if (!g_att_force_restage && kw > 4 && kw <= 18 && back % 16 == 0 && T % 128 == 0 && T >= 256) {
+#ifdef MIBC_DEBUG_KERNELS
+#define ATT_DBG(D_)                                                                                                  \
+    if (g_att_dbg == D_) {                                                                                           \
+        hipLaunchKernelGGL((window_attention_v3_kernel<18, D_>), dim3(npairs), dim3(512), 0, s, qk, vT, out, T, C, H, ld, \
+                           win_upper, win_lower, split, back);                                                       \
+        return 0;                                                                                                    \
+    }
+        ATT_DBG(1) ATT_DBG(2) ATT_DBG(4) ATT_DBG(8) ATT_DBG(3) ATT_DBG(7) ATT_DBG(15) ATT_DBG(16) ATT_DBG(32) ATT_DBG(31) ATT_DBG(47) ATT_DBG(63)
+#undef ATT_DBG
+#endif
         hipLaunchKernelGGL((window_attention_v3_kernel<18>), dim3(npairs), dim3(512), 0, s, qk, vT, out, T, C, H, ld,
                            win_upper, win_lower, split, back);
         return 0;
@@ -744,6 +770,8 @@ MIBC_HOOK int mibc_debug_attention_compare(int N, int T, int H, int win_upper, i
     (void)hipEventCreate(&e1);
     float ms[2] = {0, 0};
     int rc = 0;
+    g_att_dbg = (iters >> 16) & 0xff;      // timing ablation of the ring kernel (results wrong): pass iters | (dbg << 16)
+    iters &= 0xffff;
     for (int which = 0; which < 2 && rc == 0; ++which) {
         g_att_force_restage = which;
         half_t *o = which ? o2 : o1;
@@ -757,9 +785,11 @@ MIBC_HOOK int mibc_debug_attention_compare(int N, int T, int H, int win_upper, i
         ms[which] /= (float)(iters > 0 ? iters : 1);
     }
     g_att_force_restage = 0;
+    const bool timing_only = (g_att_dbg != 0) || (err_ring == nullptr && err_restage == nullptr);
+    g_att_dbg = 0;
     if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = -3;
     long long nd = 0;
-    if (rc == 0) {
+    if (rc == 0 && !timing_only) {
         std::vector<uint16_t> a(ob / 2), b(ob / 2);
         (void)hipMemcpy(a.data(), o1, ob, hipMemcpyDeviceToHost);
         (void)hipMemcpy(b.data(), o2, ob, hipMemcpyDeviceToHost);
