@@ -2,6 +2,7 @@
 #include "mibc_host.h"
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -380,6 +381,46 @@ std::vector<std::pair<float, float>> HipCaller::scaler_stats(
     return out;
 }
 
+std::vector<std::vector<uint16_t>> HipCaller::scale_reads(const std::vector<std::pair<const int16_t *, size_t>> &reads,
+                                                          const std::vector<std::pair<float, float>> &shift_scale) {
+    if (shift_scale.size() != reads.size()) throw std::invalid_argument("scale_reads: one (shift, scale) pair per read");
+    std::vector<int64_t> off(reads.size() + 1, 0);
+    for (size_t i = 0; i < reads.size(); ++i) off[i + 1] = off[i] + int64_t(reads[i].second);
+    const size_t total = size_t(off.back());
+    std::vector<std::vector<uint16_t>> out(reads.size());
+    if (reads.empty() || total == 0) return out;
+    std::vector<float> ss(reads.size() * 2);
+    for (size_t i = 0; i < reads.size(); ++i) {
+        ss[2 * i] = shift_scale[i].first;
+        ss[2 * i + 1] = shift_scale[i].second;
+    }
+    std::lock_guard<std::mutex> lk(m_engine_mutex);
+    void *d_sig = mibc_device_alloc(m_engine, total * 2);
+    void *d_out = mibc_device_alloc(m_engine, total * 2);
+    void *d_off = mibc_device_alloc(m_engine, off.size() * 8);
+    void *d_ss = mibc_device_alloc(m_engine, ss.size() * 4);
+    int rc = (d_sig && d_out && d_off && d_ss) ? MIBC_OK : MIBC_ERR_MEM;
+    for (size_t i = 0; i < reads.size() && rc == MIBC_OK; ++i)
+        if (reads[i].second)
+            rc = mibc_memcpy_h2d(m_engine, static_cast<char *>(d_sig) + off[i] * 2, reads[i].first, reads[i].second * 2);
+    if (rc == MIBC_OK) rc = mibc_memcpy_h2d(m_engine, d_off, off.data(), off.size() * 8);
+    if (rc == MIBC_OK) rc = mibc_memcpy_h2d(m_engine, d_ss, ss.data(), ss.size() * 4);
+    if (rc == MIBC_OK)
+        rc = mibc_scale_reads(m_engine, static_cast<const int16_t *>(d_sig), static_cast<const int64_t *>(d_off),
+                              int(reads.size()), static_cast<const float *>(d_ss), static_cast<uint16_t *>(d_out));
+    for (size_t i = 0; i < reads.size() && rc == MIBC_OK; ++i) {
+        out[i].resize(reads[i].second);
+        if (reads[i].second)
+            rc = mibc_memcpy_d2h(m_engine, out[i].data(), static_cast<char *>(d_out) + off[i] * 2, reads[i].second * 2);
+    }
+    if (d_sig) mibc_device_free(m_engine, d_sig);
+    if (d_out) mibc_device_free(m_engine, d_out);
+    if (d_off) mibc_device_free(m_engine, d_off);
+    if (d_ss) mibc_device_free(m_engine, d_ss);
+    if (rc != MIBC_OK) throw std::runtime_error(std::string("mibc_scale_reads: ") + mibc_last_error(m_engine));
+    return out;
+}
+
 void HipCaller::gpu_thread_fn() {
     // Two batches in flight (the reference gets the same overlap from its runners' own streams,
     // CudaCaller.cpp:645-719): a task is submitted to the engine as soon as one of the two slots is free — its H2D
@@ -612,6 +653,105 @@ int dna_trim_start(const SignalNormalisationParams &p, const uint16_t *scaled, s
         trim_start = trim_signal(scaled, max_samples);
     }
     return size_t(trim_start) < n_samples ? trim_start : 0;
+}
+
+int rna_adapter_pos(const int16_t *signal, int signal_len) {
+    // ScalerNode.cpp:58-107.  The median of a window is at::median's: the LOWER middle element for even lengths.
+    constexpr int kWindowSize = 250, kStride = 50;
+    constexpr int kMedianDiff = 125, kMedianDiffForDiffOnlyCheck = 150, kMinMedianForRNASignal = 700;
+    std::array<int16_t, 5> medians = {0, 0, 0, 0, 0};
+    std::array<int32_t, 5> window_pos = {0, 0, 0, 0, 0};
+    int median_pos = 0;
+    const int signal_start = 1000;
+    const int signal_end = 3 * signal_len / 4;
+    std::vector<int16_t> w(kWindowSize);
+    for (int i = signal_start; i < signal_end; i += kStride) {
+        const int len = std::min(kWindowSize, signal_len - i);
+        std::copy(signal + i, signal + i + len, w.begin());
+        std::nth_element(w.begin(), w.begin() + (len - 1) / 2, w.begin() + len);
+        medians[size_t(median_pos) % medians.size()] = w[size_t(len - 1) / 2];
+        window_pos[size_t(median_pos) % window_pos.size()] = median_pos;
+        // first smallest, LAST largest (std::minmax_element's tie rule, which the reference relies on)
+        const auto mm = std::minmax_element(medians.begin(), medians.end());
+        const int min_median = *mm.first, max_median = *mm.second;
+        const auto min_at = size_t(mm.first - medians.begin()), max_at = size_t(mm.second - medians.begin());
+        if (median_pos >= int(medians.size()) && window_pos[max_at] > window_pos[min_at] &&
+            ((max_median > kMinMedianForRNASignal && max_median - min_median > kMedianDiff) ||
+             max_median - min_median > kMedianDiffForDiffOnlyCheck))
+            return i;
+        ++median_pos;
+    }
+    return 0;
+}
+
+RnaTrim rna_trim(const int16_t *raw, size_t n_samples, bool has_rna_based_adapters) {
+    // ScalerNode.cpp:157-184
+    RnaTrim r;
+    if (has_rna_based_adapters) return r;
+    const int pos = rna_adapter_pos(raw, int(n_samples));
+    if (size_t(pos) < n_samples) {
+        r.trim_start = pos;
+        r.rna_adapter_end_signal_pos = 0;
+    } else {
+        r.trim_start = 0;
+        r.rna_adapter_end_signal_pos = pos;
+    }
+    return r;
+}
+
+ScaledRead scaler_node(HipCaller &caller, const SignalNormalisationParams &p, bool is_rna_model, bool has_rna_based_adapters,
+                       const int16_t *raw, size_t n, const ReadCalibration &cal, bool want_signal) {
+    ScalerOps ops;
+    ops.stats = [&caller](const int16_t *x, size_t len, const SignalNormalisationParams &sp) {
+        return caller.scaler_stats({{x, len}}, sp)[0];
+    };
+    ops.scale = [&caller](const int16_t *x, size_t len, float shift, float scale) {
+        return std::move(caller.scale_reads({{x, len}}, {{shift, scale}})[0]);
+    };
+    return scaler_node(ops, p, is_rna_model, has_rna_based_adapters, raw, n, cal, want_signal);
+}
+
+ScaledRead scaler_node(const ScalerOps &ops, const SignalNormalisationParams &p, bool is_rna_model, bool has_rna_based_adapters,
+                       const int16_t *raw, size_t n, const ReadCalibration &cal, bool want_signal) {
+    ScaledRead r;
+    int trim_start = 0;
+    if (is_rna_model) {   // ScalerNode.cpp:157-184: trim the adapter of RNA reads first, before scaling
+        const RnaTrim t = rna_trim(raw, n, has_rna_based_adapters);
+        trim_start = t.trim_start;
+        r.rna_adapter_end_signal_pos = t.rna_adapter_end_signal_pos;
+        raw += trim_start;
+        n -= size_t(trim_start);
+    }
+    if (p.strategy == ScalingStrategy::PA) {   // :190-215
+        r.scaling = pa_read_scaling(p, cal);
+    } else {                                   // :216-224: the statistics ignore an un-cut RNA adapter
+        const size_t skip = std::min(size_t(r.rna_adapter_end_signal_pos), n);
+        const auto ss = ops.stats(raw + skip, n - skip, p);
+        r.scaling = finish_read_scaling(ss.first, ss.second, cal);
+    }
+    // :228-229 the sample map, on the device; without want_signal only the prefix the DNA trim looks at
+    const bool dna_heuristic = !is_rna_model && trim_start == 0 && !p.standardisation.standardise;
+    const size_t n_scaled = want_signal ? n : dna_heuristic ? size_t(std::min(8000, int(n / 2))) : 0;
+    std::vector<std::vector<uint16_t>> scaled(1);
+    if (n_scaled) scaled[0] = ops.scale(raw, n_scaled, r.scaling.device_shift(), r.scaling.scale);
+    if (!is_rna_model) {   // :233-254: no DNA trimming on RNA
+        if (trim_start == 0 && p.standardisation.standardise) {
+            trim_start = 10;
+        } else if (trim_start == 0) {
+            trim_start = trim_signal(scaled[0].data(), std::min(8000, int(n / 2)));
+        }
+        if (size_t(trim_start) < n) {
+            if (want_signal) scaled[0].erase(scaled[0].begin(), scaled[0].begin() + trim_start);
+            r.first_sample = size_t(trim_start);
+        } else {
+            trim_start = 0;
+        }
+    } else {
+        r.first_sample = size_t(trim_start);
+    }
+    r.num_trimmed_samples = trim_start;   // :256
+    if (want_signal) r.signal_f16 = std::move(scaled[0]);
+    return r;
 }
 
 // ------------------------------------------------------------------ HipModelRunner
@@ -1182,6 +1322,86 @@ int mibch_pa_read_scaling(int standardise, float mean, float stdev, float scalin
 }
 int mibch_trim_signal(const uint16_t *f16, int n, float threshold, int window_size, int min_elements) {
     return trim_signal(f16, n, threshold, window_size, min_elements);
+}
+int mibch_rna_adapter_pos(const int16_t *raw, int n) { return rna_adapter_pos(raw, n); }
+// out2 = {trim_start, rna_adapter_end_signal_pos}
+int mibch_rna_trim(const int16_t *raw, uint64_t n, int has_rna_based_adapters, int *out2) {
+    const RnaTrim r = rna_trim(raw, size_t(n), has_rna_based_adapters != 0);
+    out2[0] = r.trim_start;
+    out2[1] = r.rna_adapter_end_signal_pos;
+    return 0;
+}
+// One read through scaler_node (the tests' entry; builds a caller for `desc`).  strategy 0 MED_MAD, 1 QUANTILE, 2 PA
+// (config::ScalingStrategy order); params7 = {quantile_a, quantile_b, shift_multiplier, scale_multiplier, standardise, mean,
+// stdev}; cal3 = {scaling, offset, open_pore_level}.  out_f16 (capacity n, may be null) / out_n: the scaled, trimmed signal;
+// out_f5 = {shift, scale, open_pore_adjustment, scale_pa, shift_pa}; out_i3 = {num_trimmed_samples, rna_adapter_end_signal_pos,
+// first_sample}.
+static SignalNormalisationParams scaler_params(int strategy, const float *params7) {
+    SignalNormalisationParams p;
+    p.strategy = strategy == 0 ? ScalingStrategy::MED_MAD : strategy == 1 ? ScalingStrategy::QUANTILE : ScalingStrategy::PA;
+    p.quantile = {params7[0], params7[1], params7[2], params7[3]};
+    p.standardisation = {params7[4] != 0.0f, params7[5], params7[6]};
+    return p;
+}
+static void scaler_outputs(const ScaledRead &r, uint64_t n, uint16_t *out_f16, uint64_t *out_n, float *out_f5, int *out_i3) {
+    if (out_f16 && !r.signal_f16.empty()) std::memcpy(out_f16, r.signal_f16.data(), r.signal_f16.size() * 2);
+    if (out_n) *out_n = out_f16 ? r.signal_f16.size() : n - r.first_sample;
+    out_f5[0] = r.scaling.shift; out_f5[1] = r.scaling.scale; out_f5[2] = r.scaling.open_pore_adjustment;
+    out_f5[3] = r.scaling.scale_pa; out_f5[4] = r.scaling.shift_pa;
+    out_i3[0] = r.num_trimmed_samples; out_i3[1] = r.rna_adapter_end_signal_pos; out_i3[2] = int(r.first_sample);
+}
+int mibch_scaler_node(const mibc_model_desc *desc, const float *const *weights, int n_weights, const char *device_string,
+                      int strategy, const float *params7, int is_rna_model, int has_rna_based_adapters, const int16_t *raw,
+                      uint64_t n, const float *cal3, const char *flow_cell_product_code, uint16_t *out_f16, uint64_t *out_n,
+                      float *out_f5, int *out_i3) {
+    try {
+        const mibc_decode_opts opts{32, 100.0f, 2.0f, 0.0f, 1.0f};
+        std::vector<int> ids;
+        std::string err;
+        if (!try_parse_device_ids(device_string ? device_string : "hip:0", size_t(mibc_device_count()), ids, err))
+            throw std::runtime_error(err);
+        if (ids.empty()) throw std::runtime_error("mibch_scaler_node: no GPU device (the HIP engine has no CPU fallback)");
+        HipCaller caller(*desc, weights, n_weights, ids[0], 64 * model_stride(*desc), 32, opts);
+        ReadCalibration cal{cal3[0], cal3[1], cal3[2], flow_cell_product_code ? flow_cell_product_code : ""};
+        const ScaledRead r = scaler_node(caller, scaler_params(strategy, params7), is_rna_model != 0, has_rna_based_adapters != 0,
+                                         raw, size_t(n), cal, out_f16 != nullptr);
+        scaler_outputs(r, n, out_f16, out_n, out_f5, out_i3);
+        return 0;
+    } catch (const std::exception &e) {
+        g_herr = e.what();
+        return -1;
+    }
+}
+// The same orchestration with the caller's own sample passes (ScalerOps): stats_fn(x, n, strategy, params4, out shift_scale[2]),
+// scale_fn(x, n, shift, scale, out f16[n]).  No device involved.
+typedef void (*mibch_scaler_stats_fn)(const int16_t *, uint64_t, int, const float *, float *);
+typedef void (*mibch_scaler_scale_fn)(const int16_t *, uint64_t, float, float, uint16_t *);
+int mibch_scaler_node_ops(mibch_scaler_stats_fn stats_fn, mibch_scaler_scale_fn scale_fn, int strategy, const float *params7,
+                          int is_rna_model, int has_rna_based_adapters, const int16_t *raw, uint64_t n, const float *cal3,
+                          const char *flow_cell_product_code, uint16_t *out_f16, uint64_t *out_n, float *out_f5, int *out_i3) {
+    try {
+        ScalerOps ops;
+        ops.stats = [&](const int16_t *x, size_t len, const SignalNormalisationParams &sp) {
+            const float p4[4] = {sp.quantile.quantile_a, sp.quantile.quantile_b, sp.quantile.shift_multiplier,
+                                 sp.quantile.scale_multiplier};
+            float ss[2] = {0.0f, 1.0f};
+            stats_fn(x, len, sp.strategy == ScalingStrategy::MED_MAD ? 0 : 1, p4, ss);
+            return std::make_pair(ss[0], ss[1]);
+        };
+        ops.scale = [&](const int16_t *x, size_t len, float shift, float scale) {
+            std::vector<uint16_t> out(len);
+            scale_fn(x, len, shift, scale, out.data());
+            return out;
+        };
+        ReadCalibration cal{cal3[0], cal3[1], cal3[2], flow_cell_product_code ? flow_cell_product_code : ""};
+        const ScaledRead r = scaler_node(ops, scaler_params(strategy, params7), is_rna_model != 0, has_rna_based_adapters != 0,
+                                         raw, size_t(n), cal, out_f16 != nullptr);
+        scaler_outputs(r, n, out_f16, out_n, out_f5, out_i3);
+        return 0;
+    } catch (const std::exception &e) {
+        g_herr = e.what();
+        return -1;
+    }
 }
 int mibch_dna_trim_start(int standardise, const uint16_t *f16, uint64_t n) {
     SignalNormalisationParams p;

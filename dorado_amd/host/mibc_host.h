@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <deque>
 #include <map>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <optional>
@@ -133,6 +134,41 @@ int trim_signal(const uint16_t *signal_f16, int n, float threshold = 2.4f, int w
 // The DNA branch of ScalerNode.cpp:231-254: 10 for standardised models, else trim() over the first
 // min(8000, n/2) scaled samples; 0 when the trim would swallow the read.
 int dna_trim_start(const SignalNormalisationParams &p, const uint16_t *scaled_f16, size_t n_samples);
+// RNA models, in front of the scaling (ScalerNode.cpp:58-107, determine_rna_adapter_pos): where the DNA adapter of a dRNA read
+// ends, from the median of a 250-sample window sliding in steps of 50 over raw samples [1000, 3n/4) — the first window at which,
+// among the last five medians, the largest came after the smallest and exceeds it by > 150, or by > 125 with the largest > 700.
+// 0 if no such window.
+int rna_adapter_pos(const int16_t *raw, int n_samples);
+// What ScalerNode does with it (:157-184): with no RNA-based adapter info on the read, cut the signal at the position when it
+// lies inside the read (then the scaling statistics see the whole remainder), else keep the signal and let the statistics skip
+// the adapter.  has_rna_based_adapters: the read's AdapterInfo asks for RNA adapter trimming downstream -> nothing happens here.
+struct RnaTrim {
+    int trim_start = 0;                    // samples cut from the front (= num_trimmed_samples for RNA reads, :256)
+    int rna_adapter_end_signal_pos = 0;    // first sample the data-driven scaling statistics use (:218-219)
+};
+RnaTrim rna_trim(const int16_t *raw, size_t n_samples, bool has_rna_based_adapters);
+
+// ScalerNode::input_thread_fn for one read (ScalerNode.cpp:144-267), in the reference's order: RNA adapter cut (RNA models) ->
+// shift / scale (PA: closed formula; QUANTILE / MED_MAD: mibc_scaler_stats on the device over the samples behind
+// rna_adapter_end_signal_pos) -> the sample map on the device -> DNA trim on the scaled prefix (DNA models).
+struct ScaledRead {
+    ReadScaling scaling;                  // shift, scale, open-pore adjustment; read_common.scale / shift in pA
+    int num_trimmed_samples = 0;          // read_common.num_trimmed_samples
+    int rna_adapter_end_signal_pos = 0;   // read_common.rna_adapter_end_signal_pos
+    size_t first_sample = 0;              // the samples that go on = raw[first_sample, n): adapter cut + DNA trim
+    std::vector<uint16_t> signal_f16;     // want_signal: what the reference leaves in read_common.raw_data (scaled, trimmed)
+};
+// The two passes over the samples, as a seam: HipCaller supplies the device kernels (mibc_scaler_stats / mibc_scale_reads);
+// the host-logic tests supply their own (tests/test_scaler_node.py drives the orchestration on a machine without a GPU).
+struct ScalerOps {
+    std::function<std::pair<float, float>(const int16_t *, size_t, const SignalNormalisationParams &)> stats;   // QUANTILE / MED_MAD
+    std::function<std::vector<uint16_t>(const int16_t *, size_t, float shift, float scale)> scale;           // f16((x - shift) / scale)
+};
+ScaledRead scaler_node(const ScalerOps &ops, const SignalNormalisationParams &p, bool is_rna_model, bool has_rna_based_adapters,
+                       const int16_t *raw, size_t n_samples, const ReadCalibration &cal, bool want_signal);
+class HipCaller;
+ScaledRead scaler_node(HipCaller &caller, const SignalNormalisationParams &p, bool is_rna_model, bool has_rna_based_adapters,
+                       const int16_t *raw, size_t n_samples, const ReadCalibration &cal, bool want_signal);
 
 // The fields of basecall::BasecallerCreationParams that shape a caller (basecall/include/basecall/ModelRunnerBase.h:43-52;
 // model_config / device / pipeline_type arrive as constructor arguments).
@@ -178,6 +214,10 @@ public:
     // Per-read (shift, scale) of the QUANTILE / MED_MAD strategies on the device (mibc_scaler_stats).
     std::vector<std::pair<float, float>> scaler_stats(const std::vector<std::pair<const int16_t *, size_t>> &reads,
                                                       const SignalNormalisationParams &p);
+    // f16((x - shift) / scale) of whole reads on the device (mibc_scale_reads == utils::shift_scale_tensor_i16_to_f16_inplace
+    // bit for bit); shift_scale[r] = (ReadScaling::device_shift(), ReadScaling::scale).
+    std::vector<std::vector<uint16_t>> scale_reads(const std::vector<std::pair<const int16_t *, size_t>> &reads,
+                                                   const std::vector<std::pair<float, float>> &shift_scale);
     void terminate();
     void restart();
     const mibc_model_desc &config() const { return m_desc; }

@@ -241,6 +241,94 @@ def dna_trim_start(standardise, scaled_f16):
                                           C.c_uint64(s.size)))
 
 
+def rna_adapter_pos(raw_i16):
+    """ScalerNode.cpp:58-107 (determine_rna_adapter_pos) on a raw int16 read: where the DNA adapter of a dRNA read ends, 0 if
+    no median jump is found."""
+    s = np.ascontiguousarray(raw_i16, np.int16)
+    return int(lib().mibch_rna_adapter_pos(s.ctypes.data_as(C.c_void_p), C.c_int(s.size)))
+
+
+def rna_trim(raw_i16, has_rna_based_adapters=False):
+    """ScalerNode.cpp:157-184 -> dict(trim_start, rna_adapter_end_signal_pos)."""
+    s = np.ascontiguousarray(raw_i16, np.int16)
+    out = (C.c_int * 2)()
+    lib().mibch_rna_trim(s.ctypes.data_as(C.c_void_p), C.c_uint64(s.size), C.c_int(int(has_rna_based_adapters)), out)
+    return {"trim_start": int(out[0]), "rna_adapter_end_signal_pos": int(out[1])}
+
+
+SCALING_STRATEGIES = {"med_mad": 0, "quantile": 1, "pa": 2}   # config::ScalingStrategy order
+
+
+def scaler_node(cfg: ModelConfig, weights, raw_i16, strategy="quantile", quantile=(0.2, 0.9, 0.51, 0.53),
+                standardisation=(False, 0.0, 1.0), is_rna_model=False, has_rna_based_adapters=False,
+                scaling=1.0, offset=0.0, open_pore_level=float("nan"), flow_cell_product_code="", device="hip:0",
+                want_signal=True):
+    """One raw int16 read through the host mirror of ScalerNode::input_thread_fn (ScalerNode.cpp:144-267; statistics and the
+    sample map on the device) -> dict(signal (np.float16, scaled + trimmed; None without want_signal), n_out, shift, scale,
+    open_pore_adjustment, scale_pa, shift_pa, num_trimmed_samples, rna_adapter_end_signal_pos, first_sample)."""
+    L = lib()
+    d = cfg.to_desc()
+    ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+    arr = (C.POINTER(C.c_float) * len(ws))(*[w.ctypes.data_as(C.POINTER(C.c_float)) for w in ws])
+    x = np.ascontiguousarray(raw_i16, np.int16)
+    p7 = (C.c_float * 7)(*quantile, float(bool(standardisation[0])), standardisation[1], standardisation[2])
+    cal = (C.c_float * 3)(scaling, offset, open_pore_level)
+    out = np.empty(max(x.size, 1), np.uint16) if want_signal else None
+    on = C.c_uint64()
+    f5 = (C.c_float * 5)()
+    i3 = (C.c_int * 3)()
+    rc = L.mibch_scaler_node(C.byref(d), arr, len(ws), device.encode(), C.c_int(SCALING_STRATEGIES[strategy]), p7,
+                             C.c_int(int(is_rna_model)), C.c_int(int(has_rna_based_adapters)),
+                             x.ctypes.data_as(C.c_void_p), C.c_uint64(x.size), cal, flow_cell_product_code.encode(),
+                             out.ctypes.data_as(C.c_void_p) if want_signal else None, C.byref(on), f5, i3)
+    if rc != 0:
+        raise capi.MibcError(L.mibch_last_error().decode())
+    return {"signal": out[:on.value].view(np.float16).copy() if want_signal else None, "n_out": int(on.value),
+            "shift": float(f5[0]), "scale": float(f5[1]), "open_pore_adjustment": float(f5[2]),
+            "scale_pa": float(f5[3]), "shift_pa": float(f5[4]), "num_trimmed_samples": int(i3[0]),
+            "rna_adapter_end_signal_pos": int(i3[1]), "first_sample": int(i3[2])}
+
+
+_STATS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float))
+_SCALE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_void_p)
+
+
+def scaler_node_ops(stats, scale, raw_i16, strategy="quantile", quantile=(0.2, 0.9, 0.51, 0.53),
+                    standardisation=(False, 0.0, 1.0), is_rna_model=False, has_rna_based_adapters=False, scaling=1.0,
+                    offset=0.0, open_pore_level=float("nan"), flow_cell_product_code="", want_signal=True):
+    """scaler_node with the caller's own two passes over the samples (host::ScalerOps; no device): stats(x int16, strategy
+    name, params4) -> (shift, scale); scale(x int16, shift, scale) -> np.float16.  Same dict as scaler_node."""
+    L = lib()
+    x = np.ascontiguousarray(raw_i16, np.int16)
+
+    def _stats(ptr, n, strat, p4, out2):
+        v = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int16)), (int(n),)) if n else np.zeros(0, np.int16)
+        sh, sc = stats(v, "med_mad" if strat == 0 else "quantile", tuple(p4[i] for i in range(4)))
+        out2[0], out2[1] = sh, sc
+
+    def _scale(ptr, n, shift, sc, outp):
+        v = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int16)), (int(n),)) if n else np.zeros(0, np.int16)
+        y = np.ascontiguousarray(scale(v, shift, sc), np.float16)
+        C.memmove(outp, y.ctypes.data, int(n) * 2)
+
+    p7 = (C.c_float * 7)(*quantile, float(bool(standardisation[0])), standardisation[1], standardisation[2])
+    cal = (C.c_float * 3)(scaling, offset, open_pore_level)
+    out = np.empty(max(x.size, 1), np.uint16) if want_signal else None
+    on = C.c_uint64()
+    f5 = (C.c_float * 5)()
+    i3 = (C.c_int * 3)()
+    rc = L.mibch_scaler_node_ops(_STATS_FN(_stats), _SCALE_FN(_scale), C.c_int(SCALING_STRATEGIES[strategy]), p7,
+                                 C.c_int(int(is_rna_model)), C.c_int(int(has_rna_based_adapters)),
+                                 x.ctypes.data_as(C.c_void_p), C.c_uint64(x.size), cal, flow_cell_product_code.encode(),
+                                 out.ctypes.data_as(C.c_void_p) if want_signal else None, C.byref(on), f5, i3)
+    if rc != 0:
+        raise ValueError(L.mibch_last_error().decode())
+    return {"signal": out[:on.value].view(np.float16).copy() if want_signal else None, "n_out": int(on.value),
+            "shift": float(f5[0]), "scale": float(f5[1]), "open_pore_adjustment": float(f5[2]),
+            "scale_pa": float(f5[3]), "shift_pa": float(f5[4]), "num_trimmed_samples": int(i3[0]),
+            "rna_adapter_end_signal_pos": int(i3[1]), "first_sample": int(i3[2])}
+
+
 def basecall_raw_reads(cfg: ModelConfig, weights, reads_i16, shift_scale, trim_start=None, device="hip:0",
                        num_runners=2, batch_size=64, beam_width=32):
     """reads_i16: list of RAW int16 reads; shift_scale [n,2]; trim_start [n] samples cut from the front

@@ -1128,6 +1128,44 @@ ORC_API int orc_trim(const float *signal, int n, float threshold, int window_siz
     return min_trim;
 }
 
+/* read_pipeline/nodes/ScalerNode.cpp:58-107 (determine_rna_adapter_pos): end of the DNA adapter of a dRNA read on the raw
+ * int16 samples.  Window median = at::median = the LOWER middle element; ties of the five-median buffer resolve as
+ * std::minmax_element does (first smallest, last largest). */
+ORC_API int orc_rna_adapter_pos(const int16_t *signal, long signal_len) {
+    const int kWindowSize = 250, kStride = 50;
+    const int kMedianDiff = 125, kMedianDiffForDiffOnlyCheck = 150, kMinMedianForRNASignal = 700;
+    int medians[5] = {0, 0, 0, 0, 0};
+    int window_pos[5] = {0, 0, 0, 0, 0};
+    int median_pos = 0;
+    const long signal_start = 1000, signal_end = 3 * signal_len / 4;
+    for (long i = signal_start; i < signal_end; i += kStride) {
+        int16_t w[250];
+        const int len = (int)(signal_len - i < kWindowSize ? signal_len - i : kWindowSize);
+        for (int k = 0; k < len; ++k) {         /* insertion sort of the window */
+            const int16_t v = signal[i + k];
+            int j = k;
+            while (j > 0 && w[j - 1] > v) {
+                w[j] = w[j - 1];
+                --j;
+            }
+            w[j] = v;
+        }
+        medians[median_pos % 5] = w[(len - 1) / 2];
+        window_pos[median_pos % 5] = median_pos;
+        int mn = 0, mx = 0;
+        for (int k = 1; k < 5; ++k) {
+            if (medians[k] < medians[mn]) mn = k;    /* first smallest */
+            if (medians[k] >= medians[mx]) mx = k;   /* last largest */
+        }
+        const int diff = medians[mx] - medians[mn];
+        if (median_pos >= 5 && window_pos[mx] > window_pos[mn] &&
+            ((medians[mx] > kMinMedianForRNASignal && diff > kMedianDiff) || diff > kMedianDiffForDiffOnlyCheck))
+            return (int)i;
+        ++median_pos;
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * f2: POD5 signal decompression.  The reference reads signals through
  * pod5_get_read_complete_signal (data_loader/DataLoader.cpp:163-170) of the un-vendored pod5 library

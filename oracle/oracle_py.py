@@ -293,6 +293,99 @@ def trim(signal_f32, threshold=2.4, window_size=40, min_elements=3):
                               C.c_int(min_elements)))
 
 
+def rna_adapter_pos(x_i16, use_ref=False):
+    """ScalerNode.cpp:58-107 (determine_rna_adapter_pos); use_ref: the reference's own function (ref_scaler.cpp)."""
+    x = np.ascontiguousarray(x_i16, np.int16)
+    if use_ref:
+        return int(ref_scaler().ref_determine_rna_adapter_pos(x.ctypes.data_as(_i16p), C.c_long(x.size)))
+    return int(lib().orc_rna_adapter_pos(x.ctypes.data_as(_i16p), C.c_long(x.size)))
+
+
+_ref_scaler = None
+REF_SCALER_SO = os.path.join(os.path.dirname(REF_SO), "libdorado_ref_scaler.so")
+SCALING_STRATEGIES = {"med_mad": 0, "quantile": 1, "pa": 2}   # config::ScalingStrategy order
+
+
+def ref_scaler():
+    """oracle/_ref/libdorado_ref_scaler.so: the reference's ScalerNode.cpp compiled in place + MessageSink, kits, tensor_utils
+    (oracle/Makefile.ref, oracle/ref_scaler.cpp)."""
+    global _ref_scaler
+    if _ref_scaler is None:
+        import torch  # noqa: F401  (libtorch must be loaded first)
+
+        _ref_scaler = C.CDLL(REF_SCALER_SO)
+        _ref_scaler.ref_scaler_last_error.restype = C.c_char_p
+        _ref_scaler.ref_expected_open_pore_level.restype = C.c_float
+    return _ref_scaler
+
+
+def ref_scaler_node(raw_i16, strategy="quantile", quantile=(0.2, 0.9, 0.51, 0.53), standardisation=(False, 0.0, 1.0),
+                    is_rna_model=False, scaling=1.0, offset=0.0, open_pore_level=float("nan"), flow_cell_product_code=""):
+    """One read through the REFERENCE's ScalerNode (a real node with its worker thread; ref_scaler.cpp) ->
+    dict(signal np.float16, scale_pa, shift_pa, num_trimmed_samples, rna_adapter_end_signal_pos)."""
+    x = np.ascontiguousarray(raw_i16, np.int16)
+    p7 = (C.c_float * 7)(*quantile, float(bool(standardisation[0])), standardisation[1], standardisation[2])
+    cal = (C.c_float * 3)(scaling, offset, open_pore_level)
+    out = np.empty(max(x.size, 1), np.uint16)
+    on = C.c_long()
+    f2 = (C.c_float * 2)()
+    i2 = (C.c_int * 2)()
+    r = ref_scaler()
+    rc = r.ref_scaler_node(x.ctypes.data_as(_i16p), C.c_long(x.size), C.c_int(SCALING_STRATEGIES[strategy]), p7,
+                           C.c_int(int(is_rna_model)), cal, flow_cell_product_code.encode(), out.ctypes.data_as(_u16p),
+                           C.byref(on), f2, i2)
+    if rc != 0:
+        raise RuntimeError(r.ref_scaler_last_error().decode())
+    return {"signal": out[:on.value].view(np.float16).copy(), "scale_pa": float(f2[0]), "shift_pa": float(f2[1]),
+            "num_trimmed_samples": int(i2[0]), "rna_adapter_end_signal_pos": int(i2[1])}
+
+
+EXPECTED_OPEN_PORE_LEVEL = {   # ScalerNode.cpp:109-127 (flow cell product code -> pA)
+    "FLO-FLG114": 200.0, "FLO-FLG114HD": 200.0, "FLO-MIN004RA": 195.50, "FLO-PRO004RA": 194.97, "FLO-MIN114": 197.61,
+    "FLO-MIN114HD": 197.61, "FLO-PRO114": 199.21, "FLO-PRO114HD": 199.21, "FLO-PRO114M": 199.21,
+}
+
+
+def scaler_node(raw_i16, strategy="quantile", quantile=(0.2, 0.9, 0.51, 0.53), standardisation=(False, 0.0, 1.0),
+                is_rna_model=False, has_rna_based_adapters=False, scaling=1.0, offset=0.0, open_pore_level=float("nan"),
+                flow_cell_product_code=""):
+    """CPU restatement of ScalerNode::input_thread_fn for one read (ScalerNode.cpp:144-267), composed from the restated
+    pieces above; same dict as ref_scaler_node."""
+    x = np.ascontiguousarray(raw_i16, np.int16)
+    trim_start, rna_end = 0, 0
+    if is_rna_model and not has_rna_based_adapters:          # :157-184
+        pos = rna_adapter_pos(x)
+        if pos < x.size:
+            trim_start, rna_end = pos, 0
+            x = x[pos:]
+        else:
+            rna_end = pos
+    f32 = np.float32
+    adj = f32(0.0)
+    if strategy == "pa":                                     # :190-215
+        sh, sc, adj = pa_shift_scale(scaling, offset, standardisation[0], standardisation[1], standardisation[2],
+                                     open_pore_level, EXPECTED_OPEN_PORE_LEVEL.get(flow_cell_product_code, 0.0))
+    elif strategy == "quantile":                             # :216-224
+        sh, sc = quantile_shift_scale(x[rna_end:], *quantile)
+    else:
+        sh, sc = med_mad(x[rna_end:])
+    sh, sc, adj = f32(sh), f32(sc), f32(adj)
+    sig = shift_scale_i16_to_f16(x, float(sh + adj), float(sc))      # :228-229
+    scale_pa = f32(scaling) * sc                             # :226-227
+    shift_pa = f32(scaling) * (sh + f32(offset))
+    if not is_rna_model:                                     # :233-254
+        if trim_start == 0 and standardisation[0]:
+            trim_start = 10
+        elif trim_start == 0:
+            trim_start = trim(sig[:min(8000, x.size // 2)].astype(np.float32))
+        if trim_start < x.size:
+            sig = sig[trim_start:]
+        else:
+            trim_start = 0
+    return {"signal": sig, "scale_pa": float(scale_pa), "shift_pa": float(shift_pa), "num_trimmed_samples": int(trim_start),
+            "rna_adapter_end_signal_pos": int(rna_end)}
+
+
 def trimtest_signal(n=2000):
     """The input of tests/TrimTest.cpp "Test trim signal" regenerated by the compiled driver."""
     out = np.empty(n, np.float32)
