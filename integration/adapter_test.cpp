@@ -88,6 +88,16 @@ static std::vector<at::Tensor> make_weights(const float *const *weights, const i
 }
 }  // namespace
 
+// shared with basecaller_node_test.cpp
+config::BasecallModelConfig adapter_test_make_cfg(const mibc_model_desc *md, float qscale, float qbias, int chunk_size, int overlap,
+                                                  int batch_size) {
+    return make_cfg(md, qscale, qbias, chunk_size, overlap, batch_size);
+}
+std::vector<at::Tensor> adapter_test_make_weights(const float *const *weights, const int64_t *wnumel, int n_weights) {
+    return make_weights(weights, wnumel, n_weights);
+}
+void adapter_test_set_error(const std::string &e) { g_err = e; }
+
 extern "C" {
 
 const char *adapter_last_error() { return g_err.c_str(); }

@@ -171,3 +171,59 @@ def test_adapter_honours_creation_params():
     assert rc == 0 and tiny == 64
     rc, swept = auto(0.8, penalty=0.5, bench=1)      # a generous penalty accepts a smaller batch than the best one
     assert rc == 0 and 64 <= swept <= 2 * full and swept % 64 == 0
+
+
+@needs_so
+@pytest.mark.gpu
+@pytest.mark.parametrize("variable", [0, 1])
+def test_reference_basecaller_node_drives_the_engine(variable):
+    """The drop-in claim end to end: the reference's OWN BasecallerNode (read_pipeline/nodes/BasecallerNode.cpp compiled in place
+    with its MessageSink / chunk / stitch sources — integration/basecaller_node_test.cpp) chunks, batches, times out, stitches;
+    its runners are the HipModelRunnerAdapter objects create_hip_basecall_runners returns ([device][runner][chunk size], two
+    chunk-size queues for the simplex pipeline).  Reads go in through push_message, called reads come out of a sink.  Every read
+    must equal what this repo's own node (host::SimplexBasecaller, the mirror of that file) returns for it: same chunk plan,
+    same stitching, same bytes."""
+    L = _load()
+    # variable chunk sizes: the adapter applies the reference's model rule (api/runner_creation.cpp:24-44): lstm_size > 128,
+    # else the runners report fixed chunks and the node repeat-pads short reads (which the first version of this test ran into)
+    cfg = config.tiny(256, 4) if variable else config.tiny(128, 4)
+    cfg.lstm_layers = 3 if variable else 5
+    cfg.chunk_size, cfg.overlap = 1200, 120
+    cfg.qscale, cfg.qbias = 1.05, -0.3
+    cfg.normalise_basecaller_params()
+    ws = [np.ascontiguousarray(w, np.float32) for w in synth.make_weights(cfg, seed=17)]
+    lens = [300, 594, 600, 1200, 1206, 2500, 3343, 5010, 809, 4106, 7777, 12000, 312 if variable else 66]
+    reads = [synth.make_signal(1, L_, seed=300 + i)[0] for i, L_ in enumerate(lens)]
+    d = cfg.to_desc()
+    arr = (C.POINTER(C.c_float) * len(ws))(*[w.ctypes.data_as(C.POINTER(C.c_float)) for w in ws])
+    numel = (C.c_int64 * len(ws))(*[w.size for w in ws])
+    n = len(reads)
+    pitch = max(lens) // cfg.stride + 8
+    seq, qs, mv = (np.zeros((n, pitch), np.uint8) for _ in range(3))
+    sl, ml = np.zeros(n, np.int64), np.zeros(n, np.int64)
+    st = (C.c_double * 5)()
+    sig = np.ascontiguousarray(np.concatenate(reads).astype(np.float16))
+    rl = np.array(lens, np.int64)
+    rc = L.adapter_run_basecaller_node(C.byref(d), arr, numel, len(ws), b"hip:0", 2, cfg.chunk_size, cfg.overlap, 64, variable,
+                                       C.c_float(cfg.qscale), C.c_float(cfg.qbias), sig.ctypes.data_as(C.c_void_p),
+                                       rl.ctypes.data_as(C.c_void_p), n, pitch, seq.ctypes.data_as(C.c_void_p),
+                                       qs.ctypes.data_as(C.c_void_p), mv.ctypes.data_as(C.c_void_p),
+                                       sl.ctypes.data_as(C.c_void_p), ml.ctypes.data_as(C.c_void_p), st)
+    assert rc == 0, L.adapter_last_error().decode()
+    assert st[4] == variable                           # the runners really are in the mode under test
+    if variable:
+        want, _ = hostapi.basecall_reads(cfg, ws, reads, device="hip:0", num_runners=2, batch_size=64, variable_chunks=True)
+    else:
+        want, _ = hostapi.basecall_reads(cfg, ws, reads, device="hip:0", num_runners=2, batch_size=64, two_queues=True)
+    bases = 0
+    for r in range(n):
+        got_seq = seq[r, :sl[r]].tobytes().decode()
+        got_qs = qs[r, :sl[r]].tobytes().decode()
+        assert ml[r] == lens[r] // cfg.stride, (r, lens[r])
+        assert got_seq == want[r][0] and got_qs == want[r][1], (r, lens[r])
+        assert (mv[r, :ml[r]] == want[r][2]).all(), (r, lens[r])
+        assert int(mv[r, :ml[r]].sum()) == len(got_seq)
+        bases += len(got_seq)
+    assert bases > 1000
+    assert st[2] == sum(lens)                          # samples_processed as BasecallerNode counts them
+    assert st[0] + st[1] >= 1

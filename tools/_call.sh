@@ -1,3 +1,3 @@
 mkdir -p gpurun_out/r4g
-( time timeout 150 python -m pytest tests/test_scaler_node.py -x -q -m gpu ) > gpurun_out/r4g/scaler_gpu.log 2>&1
-tail -12 gpurun_out/r4g/scaler_gpu.log
+timeout 18 python -m pytest tests/test_adapter.py -x -q -m gpu -k "basecaller_node and 1" -p no:cacheprovider > gpurun_out/r4g/node_var.log 2>&1
+tail -15 gpurun_out/r4g/node_var.log
