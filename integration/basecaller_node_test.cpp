@@ -40,10 +40,11 @@ bool is_rna_model(const BasecallModelConfig &c) {
 }
 }  // namespace config
 
-class Pipeline {
+class Pipeline {   // also used by node_cpu_test.cpp
 public:
-    static void connect(MessageSink &from, MessageSink &to) { from.add_sink(to); }
+    static void connect(MessageSink &from, MessageSink &to);
 };
+void Pipeline::connect(MessageSink &from, MessageSink &to) { from.add_sink(to); }
 
 namespace {
 class CaptureSink final : public MessageSink {

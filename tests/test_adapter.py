@@ -227,3 +227,39 @@ def test_reference_basecaller_node_drives_the_engine(variable):
     assert bases > 1000
     assert st[2] == sum(lens)                          # samples_processed as BasecallerNode counts them
     assert st[0] + st[1] >= 1
+
+
+@needs_so
+def test_host_node_equals_reference_node_with_identical_runners():
+    """No GPU: the reference's OWN BasecallerNode and this repo's node (host::SimplexBasecaller) get runners that call a chunk by
+    the same pure function of its samples (integration/node_cpu_test.cpp), and the same reads — 60 random configurations (stride,
+    chunk size, overlap, one or two chunk-size queues, batch size 1 .. 40, 1 .. 3 runners per size) x up to 200 reads of 1 sample
+    to 6 chunks, plus the boundary lengths.  Chunk plan, queue choice, repeat-padding, partial batches and stitching must agree:
+    every read byte-identical, and both sides must have called the same number of chunks."""
+    L = _load()
+    rng = np.random.default_rng(7)
+    reads_total = bases_total = 0
+    for it in range(60):
+        stride = int(rng.choice([5, 6, 12, 2]))
+        cs = int(rng.integers(40, 700)) * stride
+        overlap = int(rng.integers(0, max(1, cs // stride // 3))) * stride
+        sizes = [cs]
+        if rng.integers(0, 2):
+            half = max(stride * (overlap // stride + 1), (cs // 2) // stride * stride)
+            if half < cs:
+                sizes.append(half)
+        batch, runners = int(rng.integers(1, 40)), int(rng.integers(1, 4))
+        lens = np.concatenate([rng.integers(1, 6 * cs, int(rng.integers(1, 200))), rng.integers(1, 3 * stride, 5),
+                               [cs, cs - 1, cs + 1, sizes[-1], sizes[-1] + 1, 2 * cs - overlap]]).astype(np.int64)
+        sig = rng.integers(0, 65535, int(lens.sum())).astype(np.uint16)
+        arr = (C.c_int * len(sizes))(*sizes)
+        out = (C.c_long * 6)()
+        rc = L.node_cpu_compare(sig.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), len(lens), arr, len(sizes),
+                                overlap, stride, batch, runners, 5, out)
+        cfg = (stride, sizes, overlap, batch, runners, len(lens))
+        assert rc == 0, (cfg, L.adapter_last_error().decode())
+        assert out[0] == 0, (cfg, "first differing read", out[1], int(lens[out[1]]))
+        assert out[3] == out[4] > 0, cfg                 # chunks called by the two nodes' runners
+        reads_total += len(lens)
+        bases_total += out[2]
+    assert reads_total > 4000 and bases_total > 1e6
