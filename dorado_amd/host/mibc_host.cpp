@@ -713,6 +713,7 @@ ScaledRead scaler_node(HipCaller &caller, const SignalNormalisationParams &p, bo
 
 ScaledRead scaler_node(const ScalerOps &ops, const SignalNormalisationParams &p, bool is_rna_model, bool has_rna_based_adapters,
                        const int16_t *raw, size_t n, const ReadCalibration &cal, bool want_signal) {
+    if (!raw || n == 0) throw std::invalid_argument("scaler_node: empty read");   // (the reference's at::median throws on it too)
     ScaledRead r;
     int trim_start = 0;
     if (is_rna_model) {   // ScalerNode.cpp:157-184: trim the adapter of RNA reads first, before scaling

@@ -84,6 +84,11 @@ def test_host_orchestration_vs_reference_fixture():
         assert (short["shift"], short["scale"]) == (got["shift"], got["scale"])
 
 
+def test_scaler_node_rejects_an_empty_read():
+    with pytest.raises(ValueError, match="empty read"):
+        hostapi.scaler_node_ops(_oracle_stats, O.shift_scale_i16_to_f16, np.zeros(0, np.int16))
+
+
 def test_rna_trim_decision():
     rng = np.random.default_rng(2)
     x = np.concatenate([rng.normal(480, 30, 3000), rng.normal(830, 90, 6000)]).round().astype(np.int16)
