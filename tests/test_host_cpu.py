@@ -346,3 +346,18 @@ def test_variable_chunk_row_packer_properties():
             fill[out_row[i]] = out_start[i] + lens[i] + gap
         if first_bad < n:                                                  # it really did not fit anywhere
             assert (fill + lens[first_bad] > cs).all()
+
+
+def test_host_layer_under_sanitizers():
+    """Race / memory checking of the host layer without a GPU (the reference runs TSan / ASan builds in CI):
+    tools/sanitize_host.sh builds tools/host_node_sanitize.cpp + dorado_amd/host/*.cpp with -fsanitize=thread and with
+    -fsanitize=address,undefined and runs the node over stand-in runners (8 worker threads, 9000 reads, both chunk-size queues,
+    the parallel chunking path), scaler_node from eight threads and the row packer; any report fails the script."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "sanitize_host: thread clean" in r.stdout and "sanitize_host: address clean" in r.stdout
