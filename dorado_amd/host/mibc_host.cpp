@@ -158,6 +158,19 @@ struct HipCaller::DeviceQueue {
     HipCaller *owner = nullptr;
 };
 
+// Timed wait on the steady clock — except in a ThreadSanitizer build: GCC 11's libtsan does not intercept
+// pthread_cond_clockwait (what libstdc++'s wait_for uses for the steady clock), misses the unlock inside the wait and then
+// reports every access under that mutex as a race ("double lock of a mutex"); the system-clock wait goes through the intercepted
+// pthread_cond_timedwait.  (tools/sanitize_host.sh)
+template <class Pred>
+static bool cv_wait_for(std::condition_variable &cv, std::unique_lock<std::mutex> &lk, std::chrono::microseconds d, Pred pred) {
+#if defined(__SANITIZE_THREAD__)
+    return cv.wait_until(lk, std::chrono::system_clock::now() + d, pred);
+#else
+    return cv.wait_for(lk, d, pred);
+#endif
+}
+
 static HipCaller::DeviceQueue &device_queue(int device) {
     static std::mutex m;
     static std::map<int, std::unique_ptr<HipCaller::DeviceQueue>> queues;
@@ -523,7 +536,7 @@ void HipCaller::gpu_thread_fn() {
             bool could_take = false;
             if (slot_free) {
                 std::unique_lock<std::mutex> lk(dq.mut);
-                could_take = dq.cv.wait_for(lk, std::chrono::microseconds(200), front_is_mine);
+                could_take = cv_wait_for(dq.cv, lk, std::chrono::microseconds(200), front_is_mine);
                 if (!could_take) continue;   // keep polling
             }
             if (could_take) continue;

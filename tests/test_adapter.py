@@ -263,3 +263,26 @@ def test_host_node_equals_reference_node_with_identical_runners():
         reads_total += len(lens)
         bases_total += out[2]
     assert reads_total > 4000 and bases_total > 1e6
+
+
+FAKE_SO = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libmibc_adapter_fake.so")
+
+
+@pytest.mark.skipif(not os.path.exists(FAKE_SO), reason="oracle/_ref/libmibc_adapter_fake.so not built (needs /root/reference)")
+def test_reference_node_over_the_whole_host_layer_without_a_gpu():
+    """No GPU: the reference's OWN BasecallerNode -> HipModelRunnerAdapter -> HipModelRunner -> HipCaller (GPU thread, device
+    FIFO, two asynchronous slots) -> C-ABI test double (tools/fake_mibc.cpp), 1500 reads from 6 samples to 12 chunks, fixed (two
+    chunk-size queues) and variable chunk sizes (several chunks per batch row, the node's 32-row-span budget against the
+    runner's batch_size(), overflow batches) — every read must equal what this repo's node returns over the same double.
+    Own process: the double never meets the real libmibc.so (tools/ref_node_over_fake_engine.py)."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "ref_node_over_fake_engine.py"), "1500"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    for mode, is_var in (("fixed", 0), ("variable", 1)):
+        m = res[mode]
+        assert m["differing_reads"] == 0, (mode, m)
+        assert m["runners_variable"] == is_var and m["reads"] >= 1500 and m["bases"] > 2e5, (mode, m)

@@ -350,9 +350,11 @@ def test_variable_chunk_row_packer_properties():
 
 def test_host_layer_under_sanitizers():
     """Race / memory checking of the host layer without a GPU (the reference runs TSan / ASan builds in CI):
-    tools/sanitize_host.sh builds tools/host_node_sanitize.cpp + dorado_amd/host/*.cpp with -fsanitize=thread and with
-    -fsanitize=address,undefined and runs the node over stand-in runners (8 worker threads, 9000 reads, both chunk-size queues,
-    the parallel chunking path), scaler_node from eight threads and the row packer; any report fails the script."""
+    tools/sanitize_host.sh builds dorado_amd/host/*.cpp against the C-ABI test double (tools/fake_mibc.cpp) with -fsanitize=thread
+    and with -fsanitize=address,undefined (+ leak check) and runs (a) the node over stand-in runners (8 worker threads, 9000 reads,
+    both chunk-size queues, the parallel chunking path), scaler_node from eight threads, the row packer; (b) the whole layer:
+    HipCaller's GPU thread, device FIFO and two asynchronous slots, variable / raw int16 batches, two devices, scaler_node beside
+    the node — every leg cross-checked against a direct evaluation.  Any report or failed check fails the script."""
     import shutil
     import subprocess
     if shutil.which("g++") is None:

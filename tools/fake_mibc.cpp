@@ -1,0 +1,315 @@
+// tools/fake_mibc.cpp — TEST DOUBLE of the C-ABI (include/mibc.h), CPU only.  Never linked into the product.
+// Purpose: run the WHOLE host layer (dorado_amd/host: HipCaller's GPU thread, the per-device queue, the two asynchronous slots,
+// HipModelRunner's variable-chunk packing and overflow batches, SimplexBasecaller, scaler_node) on a machine without a GPU —
+// under ThreadSanitizer / AddressSanitizer (tools/sanitize_host.sh) and under the reference's own BasecallerNode
+// (integration/, oracle/Makefile.ref: libmibc_adapter_fake.so) — by linking the host sources against this file instead of
+// libmibc.so.  It implements the 25 entry points the host layer uses with the documented semantics:
+//   * a "call" of a chunk is a pure function of the chunk's samples (receptive field of two steps either side, cut at the chunk's
+//     ends, plus the chunk length) — the same function integration/node_cpu_test.cpp uses for its stand-in runners;
+//   * output planes int8 [3][N][T] as the engine writes them (moves per step; bases and qualities packed at the chunk's start);
+//   * mibc_call_async / mibc_call_var_async run on a worker thread and READ in_host / WRITE out_host there, completion through
+//     mibc_call_poll / mibc_call_wait — so a host layer that touches a batch's buffers too early or too late is a data race the
+//     thread sanitizer sees; a slot submitted twice without a wait is an error;
+//   * variable batches check the chunk table as engine.hip's var_build does (stride aligned, inside the row, ordered, >= 2 steps
+//     apart) and leave the gaps of the output planes zero;
+//   * mibc_scaler_stats / mibc_scale_reads with the reference's arithmetic (quantile_counting index rule, lower medians, int16
+//     wrap of |x - med|, f32 subtract / divide, RNE to f16).
+#include "mibc.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <future>
+#include <mutex>
+#include <string>
+#include <vector>
+
+struct mibc_engine {
+    mibc_model_desc d;
+    int stride = 1;
+    int device = 0;
+    std::string err;
+    std::future<int> slot[2];
+    bool busy[2] = {false, false};
+    std::atomic<long> calls{0};
+};
+
+static thread_local std::string g_err;
+static std::atomic<long> g_engines{0};
+
+static int fail(mibc_engine *e, int rc, const char *msg) {
+    if (e) e->err = msg;
+    g_err = msg;
+    return rc;
+}
+
+static uint16_t f32_to_f16_bits(float f) {   // round to nearest even, overflow to inf, subnormals kept
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return uint16_t(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
+    if (x >= 0x477ff000u) return uint16_t(sign | 0x7c00u);      // rounds to >= 65520 -> inf
+    if (x < 0x33000001u) return uint16_t(sign);                 // below half of the smallest subnormal
+    int e = int(x >> 23) - 127;
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    int shift = e < -14 ? 13 + (-14 - e) : 13;
+    uint32_t half = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1), mid = 1u << (shift - 1);
+    if (rem > mid || (rem == mid && (half & 1))) ++half;
+    if (e < -14) return uint16_t(sign | half);                  // subnormal (a carry lands on the first normal correctly)
+    return uint16_t(sign | (uint32_t(e + 15) << 10) + (half - 0x400u));
+}
+
+static void fake_call(const uint16_t *x, size_t n, size_t stride, int8_t *mv, int8_t *sq, int8_t *qs) {
+    const size_t T = n / stride;
+    size_t nb = 0;
+    for (size_t t = 0; t < T; ++t) {
+        uint32_t h = 2166136261u ^ uint32_t(n);
+        const size_t a = t >= 2 ? (t - 2) * stride : 0, b = std::min(n, (t + 3) * stride);
+        for (size_t k = a; k < b; ++k) {
+            h = (h ^ (x[k] & 0xffu)) * 16777619u;
+            h = (h ^ (x[k] >> 8)) * 16777619u;
+        }
+        mv[t] = 0;
+        if ((h >> 9) % 5 < 2) {
+            mv[t] = 1;
+            sq[nb] = int8_t("ACGT"[(h >> 3) & 3]);
+            qs[nb] = int8_t('!' + (h >> 12) % 41);
+            ++nb;
+        }
+    }
+}
+
+// rows as f16 bits: either the input itself or the ScalerNode map of raw int16 rows
+static std::vector<uint16_t> rows_f16(const void *in, const float *ss, int N, int T_in) {
+    std::vector<uint16_t> x(size_t(N) * size_t(T_in));
+    if (!ss) {
+        std::memcpy(x.data(), in, x.size() * 2);
+    } else {
+        const int16_t *r = static_cast<const int16_t *>(in);
+        for (int n = 0; n < N; ++n)
+            for (int t = 0; t < T_in; ++t)
+                x[size_t(n) * T_in + t] = f32_to_f16_bits((float(r[size_t(n) * T_in + t]) - ss[2 * n]) / ss[2 * n + 1]);
+    }
+    return x;
+}
+
+static int run_fixed(mibc_engine *e, const void *in, const float *ss, int N, int T_in, int8_t *out) {
+    const int T = T_in / e->stride;
+    const auto x = rows_f16(in, ss, N, T_in);
+    std::vector<int8_t> o(size_t(3) * N * T, 0);
+    for (int n = 0; n < N; ++n)
+        fake_call(x.data() + size_t(n) * T_in, size_t(T_in), size_t(e->stride), o.data() + size_t(n) * T,
+                  o.data() + size_t(N) * T + size_t(n) * T, o.data() + size_t(2) * N * T + size_t(n) * T);
+    std::memcpy(out, o.data(), o.size());
+    ++e->calls;
+    return MIBC_OK;
+}
+
+static int check_var(mibc_engine *e, int N, int T_in, const mibc_var_chunk *ch, int n_chunks) {
+    if (!ch || n_chunks <= 0) return fail(e, MIBC_ERR_ARG, "no chunks");
+    std::vector<int> row_end(size_t(N), -2);
+    for (int c = 0; c < n_chunks; ++c) {
+        const int r = ch[c].row, s0 = ch[c].sample_start, L = ch[c].n_samples;
+        if (r < 0 || r >= N || s0 < 0 || L <= 0 || s0 % e->stride || L % e->stride || s0 + L > T_in)
+            return fail(e, MIBC_ERR_ARG, "variable chunks: chunk outside its row or not stride aligned");
+        const int t0 = s0 / e->stride, Tc = L / e->stride;
+        if (t0 < row_end[size_t(r)] + 3 && row_end[size_t(r)] >= 0)
+            return fail(e, MIBC_ERR_ARG, "variable chunks: chunks of a row must be ordered and >= 2 steps apart");
+        row_end[size_t(r)] = t0 + Tc - 1;
+    }
+    return MIBC_OK;
+}
+
+static int run_var(mibc_engine *e, const void *in, const float *ss, int N, int T_in, const std::vector<mibc_var_chunk> &ch,
+                   int8_t *out) {
+    const int T = T_in / e->stride;
+    const auto x = rows_f16(in, ss, N, T_in);
+    std::vector<int8_t> o(size_t(3) * N * T, 0);
+    for (const auto &c : ch) {
+        const size_t base = size_t(c.row) * T + size_t(c.sample_start / e->stride);
+        fake_call(x.data() + size_t(c.row) * T_in + c.sample_start, size_t(c.n_samples), size_t(e->stride), o.data() + base,
+                  o.data() + size_t(N) * T + base, o.data() + size_t(2) * N * T + base);
+    }
+    std::memcpy(out, o.data(), o.size());
+    ++e->calls;
+    return MIBC_OK;
+}
+
+static int check_call(mibc_engine *e, int N, int T_in) {
+    if (!e) return MIBC_ERR_ARG;
+    if (N <= 0 || N % mibc_batch_granularity(e) != 0) return fail(e, MIBC_ERR_ARG, "N must be a positive multiple of mibc_batch_granularity()");
+    if (T_in <= 0 || T_in % e->stride != 0) return fail(e, MIBC_ERR_ARG, "T_in must be a stride multiple");
+    return MIBC_OK;
+}
+
+extern "C" {
+
+int mibc_device_count(void) {
+    const char *s = std::getenv("FAKE_MIBC_DEVICES");
+    return s ? std::atoi(s) : 1;
+}
+int mibc_device_memory(int, size_t *free_bytes, size_t *total_bytes) {
+    *free_bytes = size_t(200) << 30;
+    *total_bytes = size_t(288) << 30;
+    return MIBC_OK;
+}
+const char *mibc_last_error(const mibc_engine *e) { return e ? e->err.c_str() : g_err.c_str(); }
+
+int mibc_create(int device_id, const mibc_model_desc *desc, const float *const *, int, mibc_engine **out) {
+    if (!desc || !out || device_id < 0 || device_id >= mibc_device_count()) return fail(nullptr, MIBC_ERR_ARG, "mibc_create: bad argument");
+    auto *e = new mibc_engine();
+    e->d = *desc;
+    e->device = device_id;
+    e->stride = 1;
+    for (int i = 0; i < desc->n_convs; ++i) e->stride *= desc->conv_stride[i];
+    if (desc->tx_d_model > 0 && desc->up_scale_factor > 1) e->stride /= desc->up_scale_factor;
+    if (e->stride < 1) e->stride = 1;
+    ++g_engines;
+    *out = e;
+    return MIBC_OK;
+}
+void mibc_destroy(mibc_engine *e) {
+    if (!e) return;
+    for (int s = 0; s < 2; ++s)
+        if (e->busy[s] && e->slot[s].valid()) e->slot[s].wait();
+    --g_engines;
+    delete e;
+}
+int mibc_query_memory(const mibc_engine *e, int T_in, size_t *bytes_per_chunk, size_t *bytes_fixed) {
+    if (!e || T_in <= 0) return MIBC_ERR_ARG;
+    if (bytes_per_chunk) *bytes_per_chunk = size_t(T_in) * 64;
+    if (bytes_fixed) *bytes_fixed = size_t(64) << 20;
+    return MIBC_OK;
+}
+int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
+    if (!e || N_max <= 0 || T_in <= 0) return MIBC_ERR_ARG;
+    if (N_max % mibc_batch_granularity(e) != 0) return fail(e, MIBC_ERR_ARG, "N_max must be a multiple of mibc_batch_granularity()");
+    return MIBC_OK;
+}
+int mibc_output_steps(const mibc_engine *e, int T_in) { return e ? T_in / e->stride : 0; }
+int mibc_batch_granularity(const mibc_engine *e) { return (e && e->d.tx_d_model > 0) ? 32 : 64; }
+
+void *mibc_host_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+void mibc_host_free(void *p) { std::free(p); }
+void *mibc_device_alloc(mibc_engine *, size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+void mibc_device_free(mibc_engine *, void *p) { std::free(p); }
+int mibc_memcpy_h2d(mibc_engine *, void *dst, const void *src, size_t bytes) {
+    std::memcpy(dst, src, bytes);
+    return MIBC_OK;
+}
+int mibc_memcpy_d2h(mibc_engine *, void *dst, const void *src, size_t bytes) {
+    std::memcpy(dst, src, bytes);
+    return MIBC_OK;
+}
+
+int mibc_call(mibc_engine *e, const uint16_t *in_host, int N, int T_in, const mibc_decode_opts *o, int8_t *out_host) {
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    if (!in_host || !out_host || !o) return MIBC_ERR_ARG;
+    return run_fixed(e, in_host, nullptr, N, T_in, out_host);
+}
+int mibc_call_i16(mibc_engine *e, const int16_t *in_host, const float *ss, int N, int T_in, const mibc_decode_opts *o,
+                  int8_t *out_host) {
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    if (!in_host || !out_host || !o || !ss) return MIBC_ERR_ARG;
+    return run_fixed(e, in_host, ss, N, T_in, out_host);
+}
+int mibc_call_var(mibc_engine *e, const void *in_host, const float *ss, int N, int T_in, const mibc_var_chunk *ch, int n_chunks,
+                  const mibc_decode_opts *o, int8_t *out_host) {
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    if (!in_host || !out_host || !o) return MIBC_ERR_ARG;
+    rc = check_var(e, N, T_in, ch, n_chunks);
+    if (rc != MIBC_OK) return rc;
+    return run_var(e, in_host, ss, N, T_in, std::vector<mibc_var_chunk>(ch, ch + n_chunks), out_host);
+}
+
+int mibc_call_async(mibc_engine *e, int slot, const void *in_host, const float *ss, int N, int T_in, const mibc_decode_opts *o,
+                    int8_t *out_host) {
+    if (!e || !in_host || !out_host || !o || slot < 0 || slot > 1) return MIBC_ERR_ARG;
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    if (e->busy[slot]) return fail(e, MIBC_ERR_ARG, "slot submitted again before mibc_call_wait");
+    e->busy[slot] = true;
+    e->slot[slot] = std::async(std::launch::async, [=] { return run_fixed(e, in_host, ss, N, T_in, out_host); });
+    return MIBC_OK;
+}
+int mibc_call_var_async(mibc_engine *e, int slot, const void *in_host, const float *ss, int N, int T_in, const mibc_var_chunk *ch,
+                        int n_chunks, const mibc_decode_opts *o, int8_t *out_host) {
+    if (!e || !in_host || !out_host || !o || slot < 0 || slot > 1) return MIBC_ERR_ARG;
+    int rc = check_call(e, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    rc = check_var(e, N, T_in, ch, n_chunks);
+    if (rc != MIBC_OK) return rc;
+    if (e->busy[slot]) return fail(e, MIBC_ERR_ARG, "slot submitted again before mibc_call_wait");
+    std::vector<mibc_var_chunk> table(ch, ch + n_chunks);       // consumed before the call returns
+    e->busy[slot] = true;
+    e->slot[slot] = std::async(std::launch::async, [=] { return run_var(e, in_host, ss, N, T_in, table, out_host); });
+    return MIBC_OK;
+}
+int mibc_call_poll(mibc_engine *e, int slot) {
+    if (!e || slot < 0 || slot > 1 || !e->busy[slot]) return 1;
+    return e->slot[slot].wait_for(std::chrono::seconds(0)) == std::future_status::ready ? 1 : 0;
+}
+int mibc_call_wait(mibc_engine *e, int slot) {
+    if (!e || slot < 0 || slot > 1) return MIBC_ERR_ARG;
+    if (!e->busy[slot]) return fail(e, MIBC_ERR_ARG, "mibc_call_wait: nothing submitted on this slot");
+    const int rc = e->slot[slot].get();
+    e->busy[slot] = false;
+    return rc;
+}
+
+int mibc_scaler_stats(mibc_engine *e, const int16_t *sig, const int64_t *off, int n_reads, int strategy, const float *p4,
+                      float *ss, float *raw) {
+    if (!e || !sig || !off || !ss || n_reads < 0) return MIBC_ERR_ARG;
+    for (int r = 0; r < n_reads; ++r) {
+        std::vector<int16_t> v(sig + off[r], sig + off[r + 1]);
+        if (v.empty()) return fail(e, MIBC_ERR_ARG, "mibc_scaler_stats: empty read");
+        std::sort(v.begin(), v.end());
+        const size_t n = v.size();
+        if (strategy == MIBC_SCALE_QUANTILE) {
+            if (!p4) return MIBC_ERR_ARG;
+            const float qa = float(v[size_t(p4[0] * float(n - 1))]), qb = float(v[size_t(p4[1] * float(n - 1))]);
+            ss[2 * r] = std::max(10.0f, p4[2] * (qa + qb));
+            ss[2 * r + 1] = std::max(1.0f, p4[3] * (qb - qa));
+            if (raw) {
+                raw[2 * r] = qa;
+                raw[2 * r + 1] = qb;
+            }
+        } else {
+            const int16_t med = v[(n - 1) / 2];
+            std::vector<int16_t> dev(n);
+            for (size_t i = 0; i < n; ++i) {
+                const int16_t dd = int16_t(v[i] - med);           // int16 arithmetic of the tensor expression: wraps
+                dev[i] = int16_t(dd < 0 ? -dd : dd);
+            }
+            std::sort(dev.begin(), dev.end());
+            ss[2 * r] = float(med);
+            ss[2 * r + 1] = float(dev[(n - 1) / 2]) * 1.4826f + 1e-9f;
+            if (raw) {
+                raw[2 * r] = float(med);
+                raw[2 * r + 1] = float(dev[(n - 1) / 2]);
+            }
+        }
+    }
+    return MIBC_OK;
+}
+int mibc_scale_reads(mibc_engine *e, const int16_t *sig, const int64_t *off, int n_reads, const float *ss, uint16_t *out) {
+    if (!e || !sig || !off || !ss || !out) return MIBC_ERR_ARG;
+    for (int r = 0; r < n_reads; ++r)
+        for (int64_t i = off[r]; i < off[r + 1]; ++i) out[i] = f32_to_f16_bits((float(sig[i]) - ss[2 * r]) / ss[2 * r + 1]);
+    return MIBC_OK;
+}
+
+int mibc_time_forward(mibc_engine *e, int N, int T_in, float *ms) {
+    if (!e || !ms) return MIBC_ERR_ARG;
+    *ms = 0.05f + 1e-6f * float(N) * float(T_in) * (N >= 256 ? 0.8f : 1.0f);   // a knee at 256 rows
+    return MIBC_OK;
+}
+
+}  // extern "C"

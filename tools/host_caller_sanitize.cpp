@@ -1,0 +1,223 @@
+// tools/host_caller_sanitize.cpp — the WHOLE host layer over the C-ABI test double (tools/fake_mibc.cpp), no GPU: functional
+// cross-checks + ThreadSanitizer / AddressSanitizer (tools/sanitize_host.sh).
+//   1. fixed chunk sizes: SimplexBasecaller over HipModelRunner / HipCaller (one caller per device, two chunk-size batch
+//      dimensions, per-device FIFO, GPU thread with two asynchronous slots) must return exactly what the same node returns over
+//      plain stand-in runners applying the engine double's call function directly — for f16 reads and for raw int16 reads with
+//      per-read (shift, scale);
+//   2. variable chunk sizes (HipModelRunner row packing, mibc_call_var_async on the two slots): every read must equal a direct
+//      evaluation of its chunk plan (generate_variable_chunks -> call each chunk alone -> stitch_chunks);
+//   3. two devices ("hip:all" with FAKE_MIBC_DEVICES=2), and scaler_node(HipCaller&) from two threads WHILE the node is calling
+//      (the engine mutex serialises it with the GPU thread).
+#include "mibc_host.h"
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <thread>
+
+using namespace dorado_amd::host;
+
+static void fake_call(const uint16_t *x, size_t n, size_t stride, std::string &seq, std::string &qs, std::vector<uint8_t> &moves) {
+    const size_t T = n / stride;
+    moves.assign(T, 0);
+    seq.clear();
+    qs.clear();
+    for (size_t t = 0; t < T; ++t) {
+        uint32_t h = 2166136261u ^ uint32_t(n);
+        const size_t a = t >= 2 ? (t - 2) * stride : 0, b = std::min(n, (t + 3) * stride);
+        for (size_t k = a; k < b; ++k) {
+            h = (h ^ (x[k] & 0xffu)) * 16777619u;
+            h = (h ^ (x[k] >> 8)) * 16777619u;
+        }
+        if ((h >> 9) % 5 < 2) {
+            moves[t] = 1;
+            seq.push_back("ACGT"[(h >> 3) & 3]);
+            qs.push_back(char('!' + (h >> 12) % 41));
+        }
+    }
+}
+
+class PlainRunner final : public ModelRunnerBase {
+public:
+    PlainRunner(size_t chunk, size_t batch, int stride) : m_chunk(chunk), m_batch(batch), m_stride(stride), m_rows(batch) {
+        std::memset(&m_desc, 0, sizeof(m_desc));
+    }
+    void accept_chunk(int idx, const uint16_t *f16, size_t n) override { m_rows[size_t(idx)].assign(f16, f16 + n); }
+    std::vector<DecodedChunk> call_chunks(int n) override {
+        std::vector<DecodedChunk> out((size_t)n);
+        for (int i = 0; i < n; ++i)
+            fake_call(m_rows[size_t(i)].data(), m_chunk, size_t(m_stride), out[size_t(i)].sequence, out[size_t(i)].qstring, out[size_t(i)].moves);
+        return out;
+    }
+    const mibc_model_desc &config() const override { return m_desc; }
+    size_t chunk_size() const override { return m_chunk; }
+    size_t batch_size() const override { return m_batch; }
+    void terminate() override {}
+    void restart() override {}
+    std::string get_name() const override { return "plain"; }
+    NamedStats sample_stats() const override { return {}; }
+
+private:
+    mibc_model_desc m_desc;
+    size_t m_chunk, m_batch;
+    int m_stride;
+    std::vector<std::vector<uint16_t>> m_rows;
+};
+
+static void die(const char *what) {
+    std::printf("FAILED: %s\n", what);
+    std::exit(1);
+}
+
+static bool same(const std::vector<CalledRead> &a, const std::vector<CalledRead> &b) {
+    if (a.size() != b.size()) return false;
+    for (size_t i = 0; i < a.size(); ++i)
+        if (a[i].seq != b[i].seq || a[i].qstring != b[i].qstring || a[i].moves != b[i].moves) return false;
+    return true;
+}
+
+int main() {
+    mibc_model_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.n_convs = 3;
+    d.conv_stride[0] = 1; d.conv_stride[1] = 1; d.conv_stride[2] = 6;
+    d.lstm_size = 256; d.lstm_layers = 5; d.state_len = 3; d.outsize = 320; d.tx_d_model = 0;
+    const int stride = 6, cs = 1200, overlap = 120;
+    const mibc_decode_opts opts{32, 100.0f, 2.0f, 0.0f, 1.0f};
+    const float *noweights = nullptr;
+    std::mt19937 rng(11);
+    auto make_reads = [&](size_t n, size_t maxlen) {
+        std::vector<std::vector<uint16_t>> reads(n);
+        for (auto &r : reads) {
+            r.resize(1 + rng() % maxlen);
+            for (auto &v : r) v = uint16_t(rng());
+        }
+        return reads;
+    };
+    const std::vector<int> sizes = simplex_chunk_sizes(d, cs, overlap);
+    std::printf("chunk sizes %d / %d\n", sizes[0], sizes.size() > 1 ? sizes[1] : 0);
+
+    // ---- 1. fixed chunk sizes: HipCaller path == plain runners
+    {
+        auto reads = make_reads(2500, 7000);
+        std::vector<RunnerPtr> plain;
+        for (int r = 0; r < 2; ++r)
+            for (int s : sizes) plain.push_back(std::make_unique<PlainRunner>(size_t(s), 64, stride));
+        SimplexBasecaller ref_node(std::move(plain), overlap, stride);
+        const auto want = ref_node.basecall(reads);
+
+        auto per_dev = create_basecall_runners(d, &noweights, 0, "hip:0", 2, sizes, 64, opts);
+        std::vector<RunnerPtr> flat;
+        for (auto &dev : per_dev)
+            for (auto &r : dev) flat.push_back(std::move(r));
+        if (flat.size() != 2 * sizes.size()) die("runner count");
+        SimplexBasecaller node(std::move(flat), overlap, stride);
+        const auto got = node.basecall(reads);
+        if (!same(got, want)) die("fixed: HipCaller path differs from plain runners");
+        const auto st = node.sample_stats();
+        std::printf("fixed: %zu reads identical, %.0f batches (%.0f partial)\n", reads.size(), st.at("batches_called"), st.at("partial_batches_called"));
+
+        // raw int16 reads + (shift, scale): must equal the f16 path on the scaled reads... the double scales with the same
+        // arithmetic the engine documents, so compare against plain runners fed the scaled reads
+        std::vector<std::vector<int16_t>> raw(400);
+        std::vector<SimplexBasecaller::RawRead> rr;
+        std::vector<std::vector<uint16_t>> scaled(raw.size());
+        std::vector<std::pair<float, float>> ss(raw.size());
+        for (size_t i = 0; i < raw.size(); ++i) {
+            raw[i].resize(1 + rng() % 6000);
+            for (auto &v : raw[i]) v = int16_t(300 + rng() % 600);
+            ss[i] = {400.0f + float(rng() % 100), 50.0f + float(rng() % 60)};
+        }
+        // scale through a caller (mibc_scale_reads of the double) to get the f16 reads
+        {
+            HipCaller c(d, &noweights, 0, 0, cs, 64, opts);
+            for (size_t i = 0; i < raw.size(); ++i) scaled[i] = c.scale_reads({{raw[i].data(), raw[i].size()}}, {ss[i]})[0];
+        }
+        for (size_t i = 0; i < raw.size(); ++i) rr.push_back({raw[i].data(), raw[i].size(), ss[i].first, ss[i].second});
+        std::vector<RunnerPtr> plain2;
+        for (int r = 0; r < 2; ++r)
+            for (int s : sizes) plain2.push_back(std::make_unique<PlainRunner>(size_t(s), 64, stride));
+        SimplexBasecaller ref2(std::move(plain2), overlap, stride);
+        const auto want2 = ref2.basecall(scaled);
+        const auto got2 = node.basecall_raw(rr);
+        if (!same(got2, want2)) die("raw int16 reads differ from the prescaled f16 reads");
+        std::printf("raw int16: %zu reads identical to the prescaled path\n", raw.size());
+    }
+
+    // ---- 2. variable chunk sizes
+    {
+        auto reads = make_reads(1500, 9000);
+        CallerParams cp;
+        cp.variable_chunk_sizes = true;
+        auto per_dev = create_basecall_runners(d, &noweights, 0, "hip:0", 2, std::vector<int>{cs}, 64, opts, cp);
+        std::vector<RunnerPtr> flat;
+        for (auto &dev : per_dev)
+            for (auto &r : dev) flat.push_back(std::move(r));
+        if (!flat.at(0)->variable_chunk_sizes()) die("variable: runners are not variable");
+        SimplexBasecaller node(std::move(flat), overlap, stride);
+        const auto got = node.basecall_variable(reads);
+        size_t bases = 0;
+        for (size_t r = 0; r < reads.size(); ++r) {
+            const auto iv = generate_variable_chunks(reads[r].size(), size_t(cs), size_t(stride), size_t(overlap));
+            std::vector<Chunk> chunks(iv.size());
+            std::vector<const Chunk *> cc;
+            for (size_t i = 0; i < iv.size(); ++i) {
+                const size_t len = iv[i].second - iv[i].first, padded = (len + stride - 1) / stride * stride;
+                std::vector<uint16_t> x(padded);
+                for (size_t p = 0; p < padded; ++p) x[p] = reads[r][iv[i].first + p % len];
+                chunks[i].input_offset = iv[i].first;
+                chunks[i].raw_chunk_size = len;
+                fake_call(x.data(), padded, size_t(stride), chunks[i].seq, chunks[i].qstring, chunks[i].moves);
+                cc.push_back(&chunks[i]);
+            }
+            const StitchedRead st = stitch_chunks(cc, reads[r].size(), stride);
+            if (st.seq != got[r].seq || st.qstring != got[r].qstring || st.moves != got[r].moves) die("variable: a read differs from its chunk plan evaluated directly");
+            bases += st.seq.size();
+        }
+        const auto st = node.sample_stats();
+        std::printf("variable: %zu reads identical, %zu bases, %.0f engine batches\n", reads.size(), bases, st.at("batches_called"));
+    }
+
+    // ---- 3. two devices + scaler_node beside the node
+    {
+        setenv("FAKE_MIBC_DEVICES", "2", 1);
+        auto reads = make_reads(2000, 5000);
+        auto per_dev = create_basecall_runners(d, &noweights, 0, "hip:all", 2, sizes, 64, opts);
+        if (per_dev.size() != 2) die("hip:all did not give two devices");
+        std::vector<RunnerPtr> flat;
+        for (auto &dev : per_dev)
+            for (auto &r : dev) flat.push_back(std::move(r));
+        SimplexBasecaller node(std::move(flat), overlap, stride);
+        std::vector<RunnerPtr> plain;
+        for (int r = 0; r < 2; ++r)
+            for (int s : sizes) plain.push_back(std::make_unique<PlainRunner>(size_t(s), 64, stride));
+        SimplexBasecaller ref_node(std::move(plain), overlap, stride);
+        const auto want = ref_node.basecall(reads);
+        HipCaller side(d, &noweights, 0, 1, cs, 64, opts);      // a second caller on device 1, used for scaling beside the node
+        std::atomic<bool> stop{false};
+        std::atomic<long> scaled{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < 2; ++t)
+            th.emplace_back([&, t] {
+                std::mt19937 r2(50 + t);
+                while (!stop.load()) {
+                    std::vector<int16_t> x(2000 + r2() % 9000);
+                    for (size_t i = 0; i < x.size(); ++i) x[i] = int16_t((i < 2500 ? 480 : 830) + int(r2() % 100));
+                    SignalNormalisationParams p;
+                    p.strategy = (scaled.load() & 1) ? ScalingStrategy::QUANTILE : ScalingStrategy::MED_MAD;
+                    const ScaledRead s = scaler_node(side, p, t == 0, false, x.data(), x.size(), ReadCalibration{0.17f, -240.0f}, true);
+                    if (s.signal_f16.empty()) die("scaler_node returned nothing");
+                    ++scaled;
+                }
+            });
+        const auto got = node.basecall(reads);
+        stop.store(true);
+        for (auto &t : th) t.join();
+        if (!same(got, want)) die("two devices: differs from plain runners");
+        std::printf("two devices: %zu reads identical; %ld reads scaled beside the node\n", reads.size(), scaled.load());
+    }
+    std::printf("host_caller_sanitize: all checks passed\n");
+    return 0;
+}
