@@ -79,14 +79,15 @@ extern "C" {
 
 // reads: n_reads scaled f16 reads back to back, read_len[n_reads].  variable: BasecallerCreationParams::variable_chunk_sizes.
 // Outputs per read (row pitch `pitch`): seq / qstr NUL padded, moves; seq_len / moves_len.  The reads come back in completion
-// order; they are matched to their input by read_id.  stats5 = {batches called, partial batches called, samples processed,
+// order; they are matched to their input by read_id.  stats8 = {batches called, partial batches called, samples processed,
 // samples incl. padding} of the node's sample_stats(), and whether the runners report variable_chunk_sizes() (the adapter
-// applies the reference's model rule, api/runner_creation.cpp:24-44: lstm_size in (128, 1024], else fixed chunks).
+// applies the reference's model rule, api/runner_creation.cpp:24-44: lstm_size in (128, 1024], else fixed chunks), then the
+// runners' own counters summed: engine batches of variable runners, overflow batches (chunks that found no row), 0.
 int adapter_run_basecaller_node(const mibc_model_desc *md, const float *const *weights, const int64_t *wnumel, int n_weights,
                                 const char *device, int num_runners, int chunk_size, int overlap, int batch_size, int variable,
                                 float qscale, float qbias, const uint16_t *reads, const int64_t *read_len, int n_reads, int pitch,
                                 char *seq_out, char *qstr_out, uint8_t *moves_out, int64_t *seq_len, int64_t *moves_len,
-                                double *stats5) {
+                                double *stats8) {
     try {
         auto cfg = adapter_test_make_cfg(md, qscale, qbias, chunk_size, overlap, batch_size);
         std::vector<at::Tensor> ws = adapter_test_make_weights(weights, wnumel, n_weights);
@@ -94,7 +95,9 @@ int adapter_run_basecaller_node(const mibc_model_desc *md, const float *const *w
                                                         0.0f, false, false, variable != 0};
         auto [runners, num_devices] = basecall::create_hip_basecall_runners(params, ws, size_t(num_runners));
         (void)num_devices;
-        stats5[4] = runners.at(0)->variable_chunk_sizes() ? 1.0 : 0.0;
+        stats8[4] = runners.at(0)->variable_chunk_sizes() ? 1.0 : 0.0;
+        std::vector<basecall::ModelRunnerBase *> raw_runners;   // owned by the node from here on; alive until it is destroyed
+        for (auto &r : runners) raw_runners.push_back(r.get());
         BasecallerNode node(std::move(runners), size_t(overlap), "hip_model", 1000, "BasecallerNode", 0);
         CaptureSink sink;
         Pipeline::connect(node, sink);
@@ -129,10 +132,17 @@ int adapter_run_basecaller_node(const mibc_model_desc *md, const float *const *w
             const auto it = st.find(k);
             return it == st.end() ? -1.0 : it->second;
         };
-        stats5[0] = get("batches_called");
-        stats5[1] = get("partial_batches_called");
-        stats5[2] = get("samples_processed");
-        stats5[3] = get("samples_incl_padding");
+        stats8[0] = get("batches_called");
+        stats8[1] = get("partial_batches_called");
+        stats8[2] = get("samples_processed");
+        stats8[3] = get("samples_incl_padding");
+        stats8[5] = stats8[6] = stats8[7] = 0.0;
+        for (auto *r : raw_runners) {
+            const auto rs = r->sample_stats();
+            const auto a = rs.find("var_engine_batches"), b = rs.find("var_overflow_batches");
+            if (a != rs.end()) stats8[5] += a->second;
+            if (b != rs.end()) stats8[6] += b->second;
+        }
         return 0;
     } catch (const std::exception &e) {
         adapter_test_set_error(e.what());

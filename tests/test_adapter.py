@@ -201,7 +201,7 @@ def test_reference_basecaller_node_drives_the_engine(variable):
     pitch = max(lens) // cfg.stride + 8
     seq, qs, mv = (np.zeros((n, pitch), np.uint8) for _ in range(3))
     sl, ml = np.zeros(n, np.int64), np.zeros(n, np.int64)
-    st = (C.c_double * 5)()
+    st = (C.c_double * 8)()
     sig = np.ascontiguousarray(np.concatenate(reads).astype(np.float16))
     rl = np.array(lens, np.int64)
     rc = L.adapter_run_basecaller_node(C.byref(d), arr, numel, len(ws), b"hip:0", 2, cfg.chunk_size, cfg.overlap, 64, variable,
@@ -286,3 +286,4 @@ def test_reference_node_over_the_whole_host_layer_without_a_gpu():
         m = res[mode]
         assert m["differing_reads"] == 0, (mode, m)
         assert m["runners_variable"] == is_var and m["reads"] >= 1500 and m["bases"] > 2e5, (mode, m)
+    assert res["variable"]["var_engine_batches"] > 0 and res["variable"]["var_overflow_batches"] > 0

@@ -76,7 +76,7 @@ def node(idx, variable=1):
     pitch = max(ll) // cfg.stride + 8
     seq, qs, mv = (np.zeros((n, pitch), np.uint8) for _ in range(3))
     sl, ml = np.zeros(n, np.int64), np.zeros(n, np.int64)
-    st = (C.c_double * 5)()
+    st = (C.c_double * 8)()
     sig = np.ascontiguousarray(np.concatenate(rr).astype(np.float16))
     rl = np.array(ll, np.int64)
     rc = L.adapter_run_basecaller_node(C.byref(d), arr, numel, len(ws), b"hip:0", 2, cfg.chunk_size, cfg.overlap, 64, variable,
