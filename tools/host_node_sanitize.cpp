@@ -4,6 +4,11 @@
 // that call a chunk by a pure function of its samples; the ScalerNode mirror (host::scaler_node) runs through its ScalerOps seam
 // from eight threads; the row packer of the variable-chunk path places random chunk sets.
 #include "mibc_host.h"
+#include "tensor_loader.h"
+
+#include <dirent.h>
+#include <fstream>
+#include <unistd.h>
 #include <cstdio>
 #include <cstring>
 #include <atomic>
@@ -78,7 +83,62 @@ static void packer_cases() {
     std::printf("row packer: %ld chunks placed\n", placed);
 }
 
-int main() {
+// the ".tensor" parser reads files from disk (ZIP central directory + a pickle subset): mutated copies of the reference's fixtures
+// must either load or throw — never read outside the file (the address / undefined-behaviour sanitizers watch)
+static void fuzz_tensor_loader(const std::string &root) {
+    const std::string dir = root + "/tests/golden/tensor";
+    const char *tmp = std::getenv("TMPDIR");
+    const std::string scratch = std::string(tmp ? tmp : "/tmp") + "/mibc_fuzz_" + std::to_string(long(getpid())) + ".tensor";
+    std::mt19937 rng(77);
+    long ok = 0, threw = 0, files = 0;
+    DIR *d = opendir(dir.c_str());
+    if (!d) {
+        std::printf("tensor loader fuzz: %s not found, skipped\n", dir.c_str());
+        return;
+    }
+    while (dirent *e = readdir(d)) {
+        const std::string name = e->d_name;
+        if (name.size() < 8 || name.substr(name.size() - 7) != ".tensor") continue;
+        std::ifstream f(dir + "/" + name, std::ios::binary);
+        std::vector<char> orig((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        if (orig.empty()) continue;
+        ++files;
+        for (int it = 0; it < 400; ++it) {
+            std::vector<char> m = orig;
+            const int kind = int(rng() % 4);
+            if (kind == 0) {
+                for (int k = 0, nk = 1 + int(rng() % 8); k < nk; ++k) m[rng() % m.size()] = char(rng());
+            } else if (kind == 1) {
+                m.resize(rng() % m.size());
+            } else if (kind == 2) {   // hit the tail: end-of-central-directory record and the directory itself
+                const size_t span = std::min<size_t>(m.size(), 400);
+                for (int k = 0; k < 4; ++k) m[m.size() - 1 - rng() % span] = char(rng());
+            } else {                  // splice a block from elsewhere in the file
+                const size_t len = 1 + rng() % std::min<size_t>(64, m.size()), a = rng() % (m.size() - len + 1), b = rng() % (m.size() - len + 1);
+                std::memmove(m.data() + a, m.data() + b, len);
+            }
+            {
+                std::ofstream o(scratch, std::ios::binary | std::ios::trunc);
+                o.write(m.data(), std::streamsize(m.size()));
+            }
+            try {
+                const auto ts = load_tensor_file(scratch);
+                size_t bytes = 0;
+                for (auto &t : ts) bytes += t.data.size() + t.to_float().size();
+                ok += bytes >= 0;
+            } catch (const std::exception &) {
+                ++threw;
+            }
+        }
+    }
+    closedir(d);
+    std::remove(scratch.c_str());
+    std::printf("tensor loader fuzz: %ld files, %ld mutants loaded, %ld rejected\n", files, ok, threw);
+    if (files == 0) { std::printf("FAILED: no .tensor fixtures\n"); std::exit(1); }
+}
+
+int main(int argc, char **argv) {
+    fuzz_tensor_loader(argc > 1 ? argv[1] : ".");
     scaler_threads();
     packer_cases();
     std::mt19937 rng(5);

@@ -2,7 +2,8 @@
 # Host-layer logic under sanitizers, no GPU:  bash tools/sanitize_host.sh [thread|address]   (default: both)
 # Builds dorado_amd/host/*.cpp against the C-ABI test double tools/fake_mibc.cpp (never against libmibc.so) with
 # -fsanitize=thread and with -fsanitize=address,undefined (+ leak check) into $TMPDIR and runs
-#   tools/host_node_sanitize.cpp    the node over plain stand-in runners, scaler_node through its ops seam from 8 threads, row packer
+#   tools/host_node_sanitize.cpp    the node over plain stand-in runners, scaler_node through its ops seam from 8 threads, row packer,
+#                                   mutation fuzz of the .tensor parser on the reference's fixtures (tests/golden/tensor)
 #   tools/host_caller_sanitize.cpp  the whole layer: HipCaller (GPU thread, device FIFO, two async slots), HipModelRunner (variable
 #                                   packing, overflow batches), fixed / raw int16 / variable / two devices, scaler_node beside the node,
 #                                   each cross-checked against a direct evaluation
@@ -20,7 +21,7 @@ for kind in ${1:-thread address}; do
   done
   wait
   for drv in host_node_sanitize host_caller_sanitize; do
-    TSAN_OPTIONS="halt_on_error=1 exitcode=66" ASAN_OPTIONS="detect_leaks=1" $O/${drv}_$kind
+    TSAN_OPTIONS="halt_on_error=1 exitcode=66" ASAN_OPTIONS="detect_leaks=1" $O/${drv}_$kind $R
   done
   echo "sanitize_host: $kind clean"
 done
