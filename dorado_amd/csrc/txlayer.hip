@@ -95,7 +95,8 @@ struct TxLayerArgs {
     int FF;
     unsigned long long *trace;   // test-only: cycle stamps of workgroup 0 / wave 0 on its second tile (nullptr in production)
     // DBG template parameter = timing ablations (wrong results): 1 = every request fetches stage 0 (always L2-hot), 2 = no
-    // requests at all; 64 = cycle stamps into trace (results unchanged)
+    // requests at all, 4 = every fourth fragment straight from L2 into VGPRs instead of through LDS; 64 = cycle stamps into trace
+    // (results unchanged)
 };
 
 // MODE 3 = whole tail; 1 = out-proj + norm 1 only (x <- x1); 2 = MLP + norm 2 only (x holds x1); 6 = MLP only, x <- the raw
@@ -138,7 +139,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto issue_piece = [&](int q) __attribute__((always_inline)) {
         const int soff = ((DBG & 1) ? 0 : st_issue) * TL_STAGE_BYTES + q * 1024;
         const unsigned dst = dma_dst + (unsigned)(g_issue & 3) * TL_STAGE_BYTES + q * 1024;
-        if (!(DBG & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_vptr)(size_t)dst, 16, voff_w, soff, 0, 0);
+        // DBG 4: the fragments of every fourth MFMA slot come straight from L2 (below) — their share of the stage is not staged
+        if (!(DBG & 2) && !((DBG & 4) && (q & 3) == 3))
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_vptr)(size_t)dst, 16, voff_w, soff, 0, 0);
         if (q == 7) {
             ++g_issue;
             st_issue = (st_issue + 1 == stages_per_tile) ? 0 : st_issue + 1;
@@ -156,13 +159,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     LDSP(const half8_t) fcur = (LDSP(const half8_t))smem3 + lane;
     LDSP(const half8_t) fnext = fcur;
     auto boundary = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // (DBG 4: 6 staged pieces per stage, and the 8 direct fragment loads issued since are younger than the stage waited for)
+        if (DBG & 4) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         fnext = (LDSP(const half8_t))(smem3 + (unsigned)(g_use & 3) * TL_STAGE_BYTES) + lane;
         ++g_use;
     };
     half8_t fr[TL_FD];
+    // DBG 4 (timing ablation, results wrong; VERDICT r3 / DESIGN 6b item 4): tx_layer is bound by the LDS port — every weight
+    // fragment is read by all four waves, 4 KB per MFMA slot + the 1 KB the DMA writes against the 4 KB (128 B/clk x 32) the LDS
+    // delivers.  Here every fourth slot's fragment is loaded by each wave straight from L2 into VGPRs, TL_GD x 4 slots ahead, and
+    // neither staged nor read from LDS: 3.75 KB of LDS traffic per slot, 1.75 KB through the CU's L2 port (2 KB per slot peak).
+    constexpr int TL_GD = 4;
+    tl_u4 gfr[TL_GD];
+    int goff = 0;
+    auto load_direct = [&]() __attribute__((always_inline)) -> tl_u4 {
+        const tl_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, goff, 0);
+        goff += 4096;
+        if (goff >= stages_per_tile * TL_STAGE_BYTES) goff = 0;
+        return v;
+    };
+    if constexpr ((DBG & 4) != 0) {
+#pragma unroll
+        for (int i = 0; i < TL_GD; ++i) gfr[i] = load_direct();
+    }
     issue_stage();
     issue_stage();
     boundary();
@@ -175,12 +197,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto run_stage = [&](auto &&mf) __attribute__((always_inline)) {
         cl_static_for<32>([&](auto i_c) __attribute__((always_inline)) {
             constexpr int i = decltype(i_c)::value;
-            const half8_t a = fr[i % TL_FD];
+            constexpr bool direct = (DBG & 4) != 0 && (i & 3) == 3;
+            half8_t a = fr[i % TL_FD];
+            if constexpr (direct) a = __builtin_bit_cast(half8_t, gfr[(i >> 2) % TL_GD]);
             mf(i_c, a);                                              // everything below runs in this MFMA's shadow
             if (i == 32 - TL_FD) boundary();
             if (i >= 32 - TL_FD) issue_piece(i - (32 - TL_FD));      // the request for stage s + 2, one piece per MFMA slot:
             if (i < 8 - TL_FD) issue_piece(i + TL_FD);               // TL_FD pieces here, the rest in the next stage
-            fr[i % TL_FD] = (i + TL_FD < 32) ? fcur[(i + TL_FD) * 64] : fnext[(i + TL_FD - 32) * 64];
+            if constexpr (direct) gfr[(i >> 2) % TL_GD] = load_direct();   // for slot i + 4 TL_GD (slot i + TL_FD is direct too)
+            else fr[i % TL_FD] = (i + TL_FD < 32) ? fcur[(i + TL_FD) * 64] : fnext[(i + TL_FD - 32) * 64];
             __builtin_amdgcn_sched_barrier(0);      // one fragment read per MFMA slot: hipcc otherwise batches 8-12 reads
         });
         fcur = fnext;
@@ -619,6 +644,9 @@ extern "C" int mibc_launch_tx_layer(hipStream_t s, const half_t *attn, half_t *x
     if (mode == 2 && dbg == 2) TL_LAUNCH_DBG(2, 2);
     if (mode == 2 && dbg == 64) TL_LAUNCH_DBG(2, 64);
     if (mode == 2 && dbg == 66) TL_LAUNCH_DBG(2, 66);
+    if (mode == 2 && dbg == 4) TL_LAUNCH_DBG(2, 4);
+    if (mode == 2 && dbg == 68) TL_LAUNCH_DBG(2, 68);
+    if (mode == 3 && dbg == 4) TL_LAUNCH_DBG(3, 4);
     if (mode == 3 && dbg == 64) TL_LAUNCH_DBG(3, 64);
     if (dbg != 0) return 1;
     if (mode == 1) { TL_LAUNCH(1); return 0; }
