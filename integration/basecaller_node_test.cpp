@@ -83,11 +83,12 @@ extern "C" {
 // samples incl. padding} of the node's sample_stats(), and whether the runners report variable_chunk_sizes() (the adapter
 // applies the reference's model rule, api/runner_creation.cpp:24-44: lstm_size in (128, 1024], else fixed chunks), then the
 // runners' own counters summed: engine batches of variable runners, overflow batches (chunks that found no row), 0.
+// restart_after > 0: the node is terminated and restarted after that many reads (NodeSmokeTest.cpp's restart case).
 int adapter_run_basecaller_node(const mibc_model_desc *md, const float *const *weights, const int64_t *wnumel, int n_weights,
                                 const char *device, int num_runners, int chunk_size, int overlap, int batch_size, int variable,
                                 float qscale, float qbias, const uint16_t *reads, const int64_t *read_len, int n_reads, int pitch,
                                 char *seq_out, char *qstr_out, uint8_t *moves_out, int64_t *seq_len, int64_t *moves_len,
-                                double *stats8) {
+                                double *stats8, int restart_after) {
     try {
         auto cfg = adapter_test_make_cfg(md, qscale, qbias, chunk_size, overlap, batch_size);
         std::vector<at::Tensor> ws = adapter_test_make_weights(weights, wnumel, n_weights);
@@ -105,6 +106,12 @@ int adapter_run_basecaller_node(const mibc_model_desc *md, const float *const *w
         node.restart();
         size_t pos = 0;
         for (int r = 0; r < n_reads; ++r) {
+            if (restart_after > 0 && r == restart_after) {
+                // NodeSmokeTest.cpp's restart case: drain and stop the node and its runners (BasecallerNode::terminate ->
+                // ModelRunnerBase::terminate), start them again (restart()), carry on with the remaining reads
+                node.terminate(TerminateOptions{});
+                node.restart();
+            }
             auto read = std::make_unique<SimplexRead>();
             read->read_common.raw_data =
                     at::from_blob(const_cast<uint16_t *>(reads + pos), {read_len[r]}, at::kHalf).clone();

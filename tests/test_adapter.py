@@ -204,11 +204,12 @@ def test_reference_basecaller_node_drives_the_engine(variable):
     st = (C.c_double * 8)()
     sig = np.ascontiguousarray(np.concatenate(reads).astype(np.float16))
     rl = np.array(lens, np.int64)
+    RESTART_AFTER = 0       # (terminate + restart of the node and its runners: the CPU test over the engine double covers it)
     rc = L.adapter_run_basecaller_node(C.byref(d), arr, numel, len(ws), b"hip:0", 2, cfg.chunk_size, cfg.overlap, 64, variable,
                                        C.c_float(cfg.qscale), C.c_float(cfg.qbias), sig.ctypes.data_as(C.c_void_p),
                                        rl.ctypes.data_as(C.c_void_p), n, pitch, seq.ctypes.data_as(C.c_void_p),
                                        qs.ctypes.data_as(C.c_void_p), mv.ctypes.data_as(C.c_void_p),
-                                       sl.ctypes.data_as(C.c_void_p), ml.ctypes.data_as(C.c_void_p), st)
+                                       sl.ctypes.data_as(C.c_void_p), ml.ctypes.data_as(C.c_void_p), st, RESTART_AFTER)
     assert rc == 0, L.adapter_last_error().decode()
     assert st[4] == variable                           # the runners really are in the mode under test
     if variable:
@@ -273,7 +274,8 @@ def test_reference_node_over_the_whole_host_layer_without_a_gpu():
     """No GPU: the reference's OWN BasecallerNode -> HipModelRunnerAdapter -> HipModelRunner -> HipCaller (GPU thread, device
     FIFO, two asynchronous slots) -> C-ABI test double (tools/fake_mibc.cpp), 1500 reads from 6 samples to 12 chunks, fixed (two
     chunk-size queues) and variable chunk sizes (several chunks per batch row, the node's 32-row-span budget against the
-    runner's batch_size(), overflow batches) — every read must equal what this repo's node returns over the same double.
+    runner's batch_size(), overflow batches), the node and its runners terminated and restarted half way (NodeSmokeTest.cpp's
+    restart case) — every read must equal what this repo's node returns over the same double.
     Own process: the double never meets the real libmibc.so (tools/ref_node_over_fake_engine.py)."""
     import json
     import subprocess

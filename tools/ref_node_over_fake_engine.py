@@ -55,12 +55,13 @@ for variable in (0, 1):
     st = (C.c_double * 8)()
     sig = np.ascontiguousarray(np.concatenate(reads))
     rl = np.array(lens, np.int64)
+    RESTART_AFTER = n // 2             # NodeSmokeTest.cpp's restart case: terminate + restart of node and runners half way
     batch = 128 if variable else 64     # 128 rows: batch_size() = 96 rows' worth of steps > 128 one-chunk rows of such reads
     rc = L.adapter_run_basecaller_node(C.byref(d), arr, numel, len(ws), b"hip:0", 2, cfg.chunk_size, cfg.overlap, batch, variable,
                                        C.c_float(cfg.qscale), C.c_float(cfg.qbias), sig.ctypes.data_as(C.c_void_p),
                                        rl.ctypes.data_as(C.c_void_p), n, pitch, seq.ctypes.data_as(C.c_void_p),
                                        qs.ctypes.data_as(C.c_void_p), mv.ctypes.data_as(C.c_void_p),
-                                       sl.ctypes.data_as(C.c_void_p), ml.ctypes.data_as(C.c_void_p), st)
+                                       sl.ctypes.data_as(C.c_void_p), ml.ctypes.data_as(C.c_void_p), st, RESTART_AFTER)
     if rc != 0:
         print(json.dumps({"error": L.adapter_last_error().decode(), "variable": variable}))
         sys.exit(1)

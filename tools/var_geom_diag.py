@@ -66,6 +66,9 @@ L = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 L.adapter_last_error.restype = C.c_char_p
 
 
+RESTART_AFTER = 0
+
+
 def node(idx, variable=1):
     rr = [reads[i] for i in idx]
     ll = [lens[i] for i in idx]
@@ -83,7 +86,7 @@ def node(idx, variable=1):
                                        C.c_float(cfg.qscale), C.c_float(cfg.qbias), sig.ctypes.data_as(C.c_void_p),
                                        rl.ctypes.data_as(C.c_void_p), n, pitch, seq.ctypes.data_as(C.c_void_p),
                                        qs.ctypes.data_as(C.c_void_p), mv.ctypes.data_as(C.c_void_p),
-                                       sl.ctypes.data_as(C.c_void_p), ml.ctypes.data_as(C.c_void_p), st)
+                                       sl.ctypes.data_as(C.c_void_p), ml.ctypes.data_as(C.c_void_p), st, RESTART_AFTER)
     assert rc == 0, L.adapter_last_error().decode()
     return [seq[r, :sl[r]].tobytes().decode() for r in range(n)]
 
