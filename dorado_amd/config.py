@@ -1,6 +1,7 @@
 """Host-side mirror of the reference's model configuration for the hot path.
 
-Follows dorado/config/BasecallModelConfig.cpp:214-323 (load_lstm_model_config),
+Follows dorado/config/BasecallModelConfig.cpp:214-323 (load_lstm_model_config: v4-type and pre-v4 LSTM configs), :366-462
+(load_tx_model_config), :153-197 (signal normalisation), :63-148 (qscore, run_info / sample type),
 dorado/config/common.cpp:53-87 (conv parsing, swish->swish_clamp when followed by a clamp),
 dorado/config/BatchParams.cpp:89-105 (normalise) and
 dorado/utils/include/utils/parameters.h:7-15 (defaults: chunk 10000, overlap 500).
@@ -80,6 +81,39 @@ class TxParams:
     up_scale_factor: int = 2
     crf_scale: float = 5.0
     crf_blank_score: float = 2.0
+    up_size: int = 512                  # upsample.d_model
+    crf_insize: int = 512
+    crf_n_base: int = 4
+    crf_expand_blanks: bool = True
+    crf_permute: tuple = (1, 0, 2)
+
+
+@dataclasses.dataclass
+class SignalNorm:
+    """config::SignalNormalisationParams (config/include/config/BasecallModelConfig.h:13-44): what ScalerNode is created with."""
+
+    strategy: str = "quantile"          # ScalingStrategy: "med_mad" | "quantile" | "pa"
+    quantile_a: float = 0.2
+    quantile_b: float = 0.9
+    shift_multiplier: float = 0.51
+    scale_multiplier: float = 0.53
+    standardise: bool = False
+    mean: float = 0.0
+    stdev: float = 1.0
+
+
+# models/models.cpp simplex::deprecated (load_model_config refuses them by NAME: BasecallModelConfig.cpp:503-507,
+# models.cpp:1792-1814); the names are data of the reference's model catalogue
+DEPRECATED_SIMPLEX_MODELS = frozenset("""
+dna_r9.4.1_e8_fast@v3.4 dna_r9.4.1_e8_hac@v3.3 dna_r9.4.1_e8_sup@v3.3 dna_r9.4.1_e8_sup@v3.6
+dna_r10.4.1_e8.2_260bps_fast@v3.5.2 dna_r10.4.1_e8.2_260bps_hac@v3.5.2 dna_r10.4.1_e8.2_260bps_sup@v3.5.2
+dna_r10.4.1_e8.2_400bps_fast@v3.5.2 dna_r10.4.1_e8.2_400bps_hac@v3.5.2 dna_r10.4.1_e8.2_400bps_sup@v3.5.2
+dna_r10.4.1_e8.2_260bps_fast@v4.0.0 dna_r10.4.1_e8.2_260bps_hac@v4.0.0 dna_r10.4.1_e8.2_260bps_sup@v4.0.0
+dna_r10.4.1_e8.2_400bps_fast@v4.0.0 dna_r10.4.1_e8.2_400bps_hac@v4.0.0 dna_r10.4.1_e8.2_400bps_sup@v4.0.0
+dna_r10.4.1_e8.2_260bps_fast@v4.1.0 dna_r10.4.1_e8.2_260bps_hac@v4.1.0 dna_r10.4.1_e8.2_260bps_sup@v4.1.0
+dna_r10.4.1_e8.2_400bps_fast@v4.1.0 dna_r10.4.1_e8.2_400bps_hac@v4.1.0 dna_r10.4.1_e8.2_400bps_sup@v4.1.0
+rna002_70bps_fast@v3 rna002_70bps_hac@v3
+""".split())
 
 
 @dataclasses.dataclass
@@ -104,6 +138,9 @@ class ModelConfig:
     overlap: int = DEFAULT_OVERLAP
     name: str = "synthetic"
     tx: Optional[TxParams] = None
+    signal_norm: SignalNorm = dataclasses.field(default_factory=SignalNorm)
+    sample_type: str = "DNA"            # models::SampleType: "DNA" | "RNA002" | "RNA004" (run_info.sample_type or the model name)
+    mean_qscore_start_pos: int = -1     # qscore.mean_qscore_start_pos, else 60 (BasecallModelConfig.cpp:23-39)
     lstm_quant: bool = False   # opt-in: the reference's int8 LSTM path (nn/LSTMStack.cpp:127-211), csrc/lstm_q8.hip
     # synthetic weights only (dorado_amd/synth.py; no effect on a loaded model): gain on the transformer's CRF projection.
     # With gain 1 the random-init sup@v5 model calls NO base with q >= 10 (nothing discriminating to compare identities
@@ -141,10 +178,14 @@ class ModelConfig:
         # BasecallModelConfig.h:152-159: stride_inner = stride * scale_factor; granularity x16 for Tx
         stride = self.stride * (self.tx.up_scale_factor if self.tx else 1)
         gran = stride * (16 if self.tx else 1)
-        self.overlap = (self.overlap // stride) * stride
-        self.chunk_size = (self.chunk_size // gran) * gran
-        if self.chunk_size <= self.overlap:
-            raise ValueError("chunk_size must be greater than overlap")
+        self.overlap = max(1, self.overlap // stride) * stride            # a multiple of the stride, greater than 0
+        self.chunk_size = (max(self.overlap + gran - 1, self.chunk_size) // gran) * gran   # ... and greater than the overlap
+
+    def has_normalised_basecaller_params(self) -> bool:
+        """BasecallModelConfig::has_normalised_basecaller_params (BasecallModelConfig.cpp:475-499)."""
+        stride = self.stride * (self.tx.up_scale_factor if self.tx else 1)
+        gran = stride * (16 if self.tx else 1)
+        return self.chunk_size % gran == 0 and self.overlap % stride == 0 and self.chunk_size > self.overlap
 
     def n_weights(self) -> int:
         if self.tx:
@@ -312,69 +353,148 @@ def tiny(C: int = 64, state_len: int = 3, stride: int = 6) -> ModelConfig:
     return cfg
 
 
-def load_model_config(path: str) -> ModelConfig:
-    """Parse `<path>/config.toml` (v4-type LSTM models) the way
-    BasecallModelConfig.cpp:214-323 does."""
+def _signal_norm(t) -> SignalNorm:
+    """parse_signal_normalisation_params (BasecallModelConfig.cpp:153-197)."""
+    sn = SignalNorm()
+    if "scaling" in t:
+        st = t["scaling"]["strategy"]
+        if st not in ("med_mad", "quantile", "pa"):
+            raise ValueError(f"Unknown scaling strategy: `{st}`")
+        sn.strategy = st
+    if "normalisation" in t:
+        n = t["normalisation"]
+        sn.quantile_a, sn.quantile_b = float(n["quantile_a"]), float(n["quantile_b"])
+        sn.shift_multiplier, sn.scale_multiplier = float(n["shift_multiplier"]), float(n["scale_multiplier"])
+    if "standardisation" in t:
+        n = t["standardisation"]
+        sn.standardise = int(n["standardise"]) > 0
+        if sn.standardise:
+            sn.mean, sn.stdev = float(n["mean"]), float(n["stdev"])
+        if sn.standardise and sn.strategy != "pa":
+            raise ValueError("Signal standardisation is implemented only for `scaling.strategy = pa`")
+        if sn.stdev <= 0.0:
+            raise ValueError(f"Config error: `standardisation.stdev` must be greater than 0, got: {sn.stdev}")
+    return sn
+
+
+def _sample_type(t, model_name: str) -> str:
+    """parse_run_info (BasecallModelConfig.cpp:117-139) + models::get_sample_type_from_model_name (kits.cpp:448-458)."""
+    st = "UNKNOWN"
+    ri = t.get("run_info", {})
+    if "sample_type" in ri:
+        up = str(ri["sample_type"]).upper()
+        st = up if up in ("DNA", "RNA002", "RNA004") else "UNKNOWN"
+    if st == "UNKNOWN":
+        st = "RNA004" if "rna004" in model_name else "RNA002" if "rna002" in model_name else "DNA" if "dna" in model_name else "UNKNOWN"
+    if st == "UNKNOWN":
+        raise ValueError("Failed to determine model sample type from model name or config")
+    return st
+
+
+def _conv(seg, clamp_follows: bool) -> ConvParams:
+    """parse_conv_params (config/common.cpp:53-87): swish followed by a clamp sublayer is swish_clamp."""
+    act = seg["activation"]
+    if act == "swish":
+        a = ACT_SWISH_CLAMP if clamp_follows else ACT_SWISH
+    elif act == "tanh":
+        a = ACT_TANH
+    else:
+        raise ValueError(f"Unknown activation: `{act}`")
+    return ConvParams(int(seg["insize"]), int(seg["size"]), int(seg["winlen"]), int(seg["stride"]), a)
+
+
+def is_tx_model_config(path: str) -> bool:
+    """BasecallModelConfig.cpp:343-347."""
     import tomli
 
     with open(os.path.join(path, "config.toml"), "rb") as f:
         t = tomli.load(f)
-    enc = t["encoder"]
-    if "type" not in enc:
-        raise NotImplementedError("pre-v4 model configs are not supported yet")
-    if any(s.get("type") in ("upsample",) for s in enc["sublayers"]) or "transformer_encoder" in enc:
-        raise NotImplementedError("transformer configs are handled in a later round")
-    subs = enc["sublayers"]
-    convs: List[ConvParams] = []
-    lstm_layers = 0
-    out_features = None
-    bias = False
-    scale = 1.0
-    blank_score = 2.0
-    clamp = any(s["type"] == "clamp" for s in subs)
-    for i, s in enumerate(subs):
-        ty = s["type"]
-        if ty == "convolution":
-            nxt_clamp = i + 1 < len(subs) and subs[i + 1]["type"] == "clamp"
-            act = s["activation"]
-            if act == "swish":
-                a = ACT_SWISH_CLAMP if nxt_clamp else ACT_SWISH
-            elif act == "tanh":
-                a = ACT_TANH
-            else:
-                raise ValueError(f"Unknown activation: `{act}`")
-            convs.append(ConvParams(s["insize"], s["size"], s["winlen"], s["stride"], a))
-        elif ty == "lstm":
-            lstm_layers += 1
-        elif ty == "linear":
-            out_features = int(s["out_features"])
-        elif ty == "linearcrfencoder":
-            blank_score = float(s["blank_score"])
-            scale = float(s.get("scale", 1.0))
-    lstm_size = convs[-1].size
-    for s in subs:
-        if s["type"] == "linear":
-            bias = bool(s.get("bias", lstm_size > 128))
-    if len(convs) != 3:
-        raise ValueError(f"Expected 3 convolution layers but found: {len(convs)}")
-    q = t.get("qscore", {})
-    cfg = ModelConfig(
-        convs=convs,
-        lstm_size=lstm_size,
-        lstm_layers=lstm_layers,
-        state_len=int(t["global_norm"]["state_len"]),
-        bias=bias,
-        clamp=clamp,
-        scale=scale,
-        blank_score=blank_score,
-        out_features=out_features,
-        num_features=int(t["input"]["features"]),
-        qscale=float(q.get("scale", 1.0)),
-        qbias=float(q.get("bias", 0.0)),
-        sample_rate=int(t.get("run_info", {}).get("sample_rate", -1)),
-        name=os.path.basename(os.path.normpath(path)),
+    return isinstance(t.get("model", {}).get("encoder", {}), dict) and "transformer_encoder" in t.get("model", {}).get("encoder", {})
+
+
+def load_model_config(path: str, allow_deprecated: bool = False) -> ModelConfig:
+    """Parse `<path>/config.toml` the way config::load_model_config does (BasecallModelConfig.cpp:501-507): models of the
+    reference's deprecated catalogue are refused by name (allow_deprecated=True parses them anyway — the v4.0 / v4.1 LSTM
+    configs are still well-formed), transformer configs go through the load_tx_model_config rules (:410-462), everything else
+    through load_lstm_model_config (:214-323; v4-type sublayer lists and the pre-v4 flat encoder table).
+    The transformer's lstm_size is 0 here (the reference stores -1 "to force a downstream issue"); `bias` and `scale` keep the
+    struct defaults (true, 1.0) for transformer models exactly as there."""
+    import tomli
+
+    name = os.path.basename(os.path.normpath(os.path.realpath(path)))
+    if name in DEPRECATED_SIMPLEX_MODELS and not allow_deprecated:
+        raise ValueError(f"Deprecated model: '{name}'. Its chemistry has been deprecated since Dorado version 1.0.0.")
+    with open(os.path.join(path, "config.toml"), "rb") as f:
+        t = tomli.load(f)
+    q = t.get("qscore")
+    common = dict(
+        qscale=float(q["scale"]) if q else 1.0,
+        qbias=float(q["bias"]) if q else 0.0,
+        mean_qscore_start_pos=(int(q["mean_qscore_start_pos"]) if "mean_qscore_start_pos" in q else 60) if q else -1,
+        sample_rate=int(t["run_info"]["sample_rate"]) if "run_info" in t else -1,
+        signal_norm=_signal_norm(t),
+        sample_type=_sample_type(t, name),
+        name=name,
     )
-    bc = t.get("basecaller", {})
+    if common["mean_qscore_start_pos"] < 0 and q:
+        raise ValueError("model config error - qscore.mean_qscore_start_pos cannot be < 0")
+    menc = t.get("model", {}).get("encoder", {})
+    if isinstance(menc, dict) and "transformer_encoder" in menc:
+        # ---- load_tx_model_config
+        enc, layer, ups, crf = menc["transformer_encoder"], menc["transformer_encoder"]["layer"], menc["upsample"], menc["crf"]
+        if "rotary_base" in layer and "theta" in layer:
+            raise ValueError("Model Config Error. [model.encoder.transformer_encoder] 'rotary_base' and 'theta' are mutually exclusive.")
+        tx = TxParams(
+            d_model=int(layer["d_model"]), nhead=int(layer["nhead"]), depth=int(enc["depth"]),
+            dim_feedforward=int(layer["dim_feedforward"]), attn_window=(int(layer["attn_window"][0]), int(layer["attn_window"][1])),
+            deepnorm_alpha=float(layer["deepnorm_alpha"]),
+            theta=float(layer.get("theta", layer.get("rotary_base", TxParams.theta))),
+            max_seq_len=int(layer.get("max_seq_len", TxParams.max_seq_len)),
+            up_scale_factor=int(ups["scale_factor"]), up_size=int(ups["d_model"]),
+            crf_scale=float(crf["scale"]), crf_blank_score=float(crf["blank_score"]), crf_insize=int(crf["insize"]),
+            crf_n_base=int(crf["n_base"]), crf_expand_blanks=bool(crf["expand_blanks"]), crf_permute=tuple(int(v) for v in crf["permute"]),
+        )
+        convs = [_conv(s_, False) for s_ in menc["conv"]["sublayers"] if s_["type"] == "convolution"]   # no swish clamp in Tx models
+        state_len = int(crf["state_len"])
+        cfg = ModelConfig(convs=convs, lstm_size=0, lstm_layers=0, state_len=state_len, bias=True, clamp=False, scale=1.0,
+                          out_features=tx.crf_n_base ** (state_len + 1), num_features=convs[0].insize, tx=tx, **common)
+    else:
+        # ---- load_lstm_model_config
+        enc = t["encoder"]
+        num_features = int(t["input"]["features"])
+        bias, clamp, scale, blank_score, out_features = True, False, 1.0, 2.0, None    # the struct's defaults
+        if "type" in enc:       # v4-type model
+            subs = enc["sublayers"]
+            bias = False
+            clamp = any(s_["type"] == "clamp" for s_ in subs)
+            convs = [_conv(s_, i + 1 < len(subs) and subs[i + 1]["type"] == "clamp") for i, s_ in enumerate(subs)
+                     if s_["type"] == "convolution"]
+            lstm_size = convs[-1].size
+            lstm_layers = sum(1 for s_ in subs if s_["type"] == "lstm")
+            if any(s_["type"] == "flstm" for s_ in subs):
+                raise NotImplementedError("factorised-LSTM model configs: the engine has no FLSTM stack (not a BASELINE model)")
+            for s_ in subs:
+                if s_["type"] == "linear":
+                    out_features = int(s_["out_features"])
+                    bias = bool(s_.get("bias", lstm_size > 128))
+                elif s_["type"] == "linearcrfencoder":
+                    blank_score = float(s_["blank_score"])
+                    scale = float(s_.get("scale", 1.0))
+        else:                   # pre-v4 model
+            stride, lstm_size = int(enc["stride"]), int(enc["features"])
+            blank_score, scale = float(enc["blank_score"]), float(enc["scale"])
+            first_conv = int(enc.get("first_conv_size", 4))
+            convs = [ConvParams(num_features, first_conv, 5, 1, ACT_SWISH), ConvParams(first_conv, 16, 5, 1, ACT_SWISH),
+                     ConvParams(16, lstm_size, 19, stride, ACT_SWISH)]
+            lstm_layers = 5
+        if len(convs) != 3:
+            raise ValueError(f"Expected 3 convolution layers but found: {len(convs)}")
+        if convs[0].size not in (4, 16):
+            raise ValueError(f"Invalid CRF model configuration - first convolution layer must be size 4 or 16. Got: {convs[0].size}")
+        cfg = ModelConfig(convs=convs, lstm_size=lstm_size, lstm_layers=lstm_layers, state_len=int(t["global_norm"]["state_len"]),
+                          bias=bias, clamp=clamp, scale=scale, blank_score=blank_score, out_features=out_features,
+                          num_features=num_features, **common)
+    bc = t.get("basecaller", {})          # BatchParams::update(path): chunksize / overlap; batchsize is ignored (BatchParams.cpp:25-55)
     if "chunksize" in bc:
         cfg.chunk_size = int(bc["chunksize"])
     if "overlap" in bc:

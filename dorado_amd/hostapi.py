@@ -259,6 +259,15 @@ def rna_trim(raw_i16, has_rna_based_adapters=False):
 SCALING_STRATEGIES = {"med_mad": 0, "quantile": 1, "pa": 2}   # config::ScalingStrategy order
 
 
+def scaler_kwargs(cfg: ModelConfig) -> dict:
+    """What ScalerNode is constructed with for a model (ScalerNode(config.signal_norm_params, config.sample_type, ...),
+    e.g. cli/basecaller.cpp), as keyword arguments of scaler_node / scaler_node_ops: from config.load_model_config's
+    signal_norm and sample_type."""
+    sn = cfg.signal_norm
+    return {"strategy": sn.strategy, "quantile": (sn.quantile_a, sn.quantile_b, sn.shift_multiplier, sn.scale_multiplier),
+            "standardisation": (sn.standardise, sn.mean, sn.stdev), "is_rna_model": cfg.sample_type in ("RNA002", "RNA004")}
+
+
 def scaler_node(cfg: ModelConfig, weights, raw_i16, strategy="quantile", quantile=(0.2, 0.9, 0.51, 0.53),
                 standardisation=(False, 0.0, 1.0), is_rna_model=False, has_rna_based_adapters=False,
                 scaling=1.0, offset=0.0, open_pore_level=float("nan"), flow_cell_product_code="", device="hip:0",

@@ -127,7 +127,9 @@ def test_fast_config_matches_reference_toml():
     p = "/root/reference/tests/data/model_configs/dna_r10.4.1_e8.2_260bps_fast@v4.0.0"
     if not os.path.isdir(p):
         pytest.skip("reference tree not present")
-    a, b = config.load_model_config(p), config.fast_v40()
+    with pytest.raises(ValueError, match="Deprecated model"):      # BasecallModelConfigTest.cpp:159-163: refused by name
+        config.load_model_config(p)
+    a, b = config.load_model_config(p, allow_deprecated=True), config.fast_v40()
     assert [(c.insize, c.size, c.winlen, c.stride, c.activation) for c in a.convs] == \
         [(c.insize, c.size, c.winlen, c.stride, c.activation) for c in b.convs]
     assert (a.lstm_size, a.lstm_layers, a.state_len, a.clamp, a.out_features) == \
@@ -363,3 +365,99 @@ def test_host_layer_under_sanitizers():
     r = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_host.sh")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "sanitize_host: thread clean" in r.stdout and "sanitize_host: address clean" in r.stdout
+
+
+REF_CONFIGS = "/root/reference/tests/data/model_configs"
+needs_ref_configs = pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="reference tree not present")
+
+
+@needs_ref_configs
+def test_tx_config_matches_reference_config_test():
+    """BasecallModelConfigTest.cpp:47-152 (sup@v5.0.0 transformer model load) and :21-45 (normalise BatchParams)."""
+    cfg = config.load_model_config(os.path.join(REF_CONFIGS, "dna_r10.4.1_e8.2_400bps_sup@v5.0.0"))
+    assert cfg.is_tx and cfg.bias is True and cfg.num_features == 1 and cfg.stride == 6 and cfg.scale == 1.0
+    assert cfg.state_len == 5 and cfg.outsize == 4096 and cfg.clamp is False and cfg.out_features == 4096
+    assert cfg.sample_type == "DNA" and cfg.qbias == 0.0 and cfg.qscale == 1.0 and cfg.sample_rate == 5000
+    assert cfg.stride * cfg.tx.up_scale_factor == 12 and cfg.tx.up_scale_factor == 2          # stride_inner, scale_factor
+    sn = cfg.signal_norm
+    assert (sn.strategy, sn.standardise) == ("pa", True)
+    assert np.float32(sn.mean) == np.float32(93.6376) and np.float32(sn.stdev) == np.float32(22.6004)
+    assert (sn.quantile_a, sn.quantile_b, sn.shift_multiplier, sn.scale_multiplier) == (0.2, 0.9, 0.51, 0.53)
+    assert [(c.insize, c.size, c.winlen, c.stride, c.activation) for c in cfg.convs] == \
+        [(1, 64, 5, 1, 0), (64, 64, 5, 1, 0), (64, 128, 9, 3, 0), (128, 128, 9, 2, 0), (128, 512, 5, 2, 0)]
+    t = cfg.tx
+    assert (t.d_model, t.depth, t.dim_feedforward, t.attn_window, t.nhead) == (512, 18, 2048, (127, 128), 8)
+    assert (t.crf_insize, t.crf_n_base, t.crf_blank_score, t.crf_scale, t.crf_expand_blanks) == (512, 4, 2.0, 5.0, True)
+    assert (t.up_scale_factor, t.up_size) == (2, 512)
+    assert (cfg.chunk_size, cfg.overlap) == (12288, 600) and cfg.has_normalised_basecaller_params()
+    # the engine's own description of the same model (what bench.py runs) agrees with the parsed file
+    ref = config.sup_v50()
+    assert cfg.to_desc().tx_d_model == ref.to_desc().tx_d_model and cfg.n_weights() == ref.n_weights()
+    for f in ("tx_nhead", "tx_depth", "tx_dim_ff", "tx_win_upper", "tx_win_lower", "up_scale_factor", "state_len", "outsize"):
+        assert getattr(cfg.to_desc(), f) == getattr(ref.to_desc(), f), f
+    # :30-45 known non-normalised chunk size
+    cfg.chunk_size = 1921
+    assert not cfg.has_normalised_basecaller_params()
+    cfg.normalise_basecaller_params()
+    assert cfg.has_normalised_basecaller_params() and cfg.chunk_size == 1920
+
+
+@needs_ref_configs
+def test_lstm_configs_match_reference_config_tests():
+    """BasecallModelConfigTest.cpp:165-224 (hac@v4.2.0), :226-283 (hac@v4.3.0 pa), :285-343 (hac@v4.3.0 quantile),
+    :350-408 (rna004 sup@v3.0.1, a pre-v4 flat encoder table), :410-423 (sample_type), :154-163 / :345-348 (deprecated)."""
+    c = config.load_model_config(os.path.join(REF_CONFIGS, "dna_r10.4.1_e8.2_400bps_hac@v4.2.0"))
+    assert (c.bias, c.stride, c.lstm_size, c.blank_score, c.scale, c.state_len, c.outsize, c.clamp, c.out_features) == \
+        (True, 6, 384, 2.0, 1.0, 4, 1024, True, 128)
+    assert np.float32(c.qbias) == np.float32(-0.2) and np.float32(c.qscale) == np.float32(0.95) and c.sample_rate == 5000
+    assert c.signal_norm.strategy == "quantile" and not c.signal_norm.standardise and c.sample_type == "DNA"
+    assert [(v.insize, v.size, v.winlen, v.stride, v.activation) for v in c.convs] == \
+        [(1, 16, 5, 1, 1), (16, 16, 5, 1, 1), (16, 384, 19, 6, 1)]            # swish_clamp: every conv is followed by a clamp
+
+    c = config.load_model_config(os.path.join(REF_CONFIGS, "dna_r10.4.1_e8.2_400bps_hac@v4.3.0"))
+    assert (c.bias, c.lstm_size, c.out_features, c.clamp) == (False, 384, None, True)
+    sn = c.signal_norm
+    assert (sn.strategy, sn.standardise) == ("pa", True) and np.float32(sn.mean) == np.float32(91.88) and np.float32(sn.stdev) == np.float32(22.65)
+
+    c = config.load_model_config(os.path.join(REF_CONFIGS, "dna_r10.4.1_e8.2_400bps_hac@v4.3.0_quantile"))
+    assert (c.qbias, c.qscale, c.sample_rate) == (0.0, 1.0, -1) and c.signal_norm.strategy == "quantile" and not c.signal_norm.standardise
+
+    c = config.load_model_config(os.path.join(REF_CONFIGS, "rna004_130bps_sup@v3.0.1"))
+    assert (c.bias, c.num_features, c.stride, c.lstm_size, c.blank_score, c.scale, c.state_len, c.outsize, c.clamp, c.out_features) == \
+        (True, 1, 5, 768, 2.0, 5.0, 5, 4096, False, None)
+    assert c.sample_type == "RNA004" and c.sample_rate == 4000
+    assert np.float32(c.qbias) == np.float32(-0.1) and np.float32(c.qscale) == np.float32(0.9)
+    sn = c.signal_norm
+    assert sn.strategy == "quantile" and [np.float32(v) for v in (sn.quantile_a, sn.quantile_b, sn.scale_multiplier, sn.shift_multiplier)] == \
+        [np.float32(v) for v in (0.22, 0.88, 0.595, 0.485)]
+    assert [(v.insize, v.size, v.winlen, v.stride, v.activation) for v in c.convs] == [(1, 4, 5, 1, 0), (4, 16, 5, 1, 0), (16, 768, 19, 5, 0)]
+
+    assert config.load_model_config(os.path.join(REF_CONFIGS, "sample_type_d_e8.2_400bps_sup@v5.0.0")).sample_type == "DNA"
+    assert config.load_model_config(os.path.join(REF_CONFIGS, "sample_type_130bps_sup@v3.0.1")).sample_type == "RNA004"
+    for dep in ("dna_r9.4.1_e8_hac@v3.3", "dna_r10.4.1_e8.2_260bps_fast@v4.0.0", "rna002_70bps_fast@v3"):
+        with pytest.raises(ValueError, match="Deprecated model"):
+            config.load_model_config(os.path.join(REF_CONFIGS, dep))
+
+
+def test_config_loader_errors(tmp_path):
+    """The checks of parse_signal_normalisation_params (:176-193), parse_tx_encoder_params (:383-391), parse_convs
+    (common.cpp:53-87), load_lstm_model_config (:305-314) and parse_run_info (:131-138)."""
+    base = """[input]\nfeatures = 1\n[global_norm]\nstate_len = 3\n[run_info]\nsample_rate = 5000\n[encoder]\nstride = 5\nfeatures = 96\nscale = 5.0\nblank_score = 2.0\n"""
+
+    def write(name, text):
+        d = tmp_path / name
+        d.mkdir()
+        (d / "config.toml").write_text(text)
+        return str(d)
+    assert config.load_model_config(write("dna_ok@v1", base)).lstm_size == 96
+    with pytest.raises(ValueError, match="sample type"):
+        config.load_model_config(write("mystery@v1", base))                               # neither run_info.sample_type nor the name
+    assert config.load_model_config(write("mystery@v2", base.replace("sample_rate = 5000", 'sample_rate = 5000\nsample_type = "rna004"'))).sample_type == "RNA004"
+    with pytest.raises(ValueError, match="only for `scaling.strategy = pa`"):
+        config.load_model_config(write("dna_a@v1", base + "[standardisation]\nstandardise = 1\nmean = 90.0\nstdev = 20.0\n"))
+    with pytest.raises(ValueError, match="must be greater than 0"):
+        config.load_model_config(write("dna_b@v1", base + '[scaling]\nstrategy = "pa"\n[standardisation]\nstandardise = 1\nmean = 90.0\nstdev = 0.0\n'))
+    with pytest.raises(ValueError, match="Unknown scaling strategy"):
+        config.load_model_config(write("dna_c@v1", base + '[scaling]\nstrategy = "zscore"\n'))
+    with pytest.raises(ValueError, match="first convolution layer must be size 4 or 16"):
+        config.load_model_config(write("dna_d@v1", base.replace("blank_score = 2.0", "blank_score = 2.0\nfirst_conv_size = 8")))

@@ -142,3 +142,24 @@ def test_scaler_node_on_device_vs_reference_fixture():
     name, x, kw, want = next(c for c in _cases() if c[0] == "dna_peak" and c[2]["strategy"] == "quantile" and not c[2]["is_rna_model"])
     short = hostapi.scaler_node(cfg, ws, x, device="hip:0", want_signal=False, **kw)
     assert short["n_out"] == want["n"] and short["num_trimmed_samples"] == want["trimmed"] > 10
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tests/data/model_configs"), reason="reference tree not present")
+def test_scaler_parameters_come_from_the_model_config():
+    """config.toml -> SignalNormalisationParams + sample type -> ScalerNode: the parsed hac@v4.3.0 (pa, standardised) and
+    rna004 sup@v3.0.1 (quantile with edited multipliers, RNA) configs drive the host orchestration exactly as the explicit
+    parameters do in the reference run."""
+    base = "/root/reference/tests/data/model_configs"
+    rng = np.random.default_rng(8)
+    x = np.concatenate([rng.normal(480, 30, 2600), rng.normal(830, 90, 5000)]).round().astype(np.int16)
+    cal = dict(scaling=0.1462, offset=-228.0, open_pore_level=204.7, flow_cell_product_code="FLO-PRO114M")
+    for name, want_strategy, want_rna in (("dna_r10.4.1_e8.2_400bps_hac@v4.3.0", "pa", False), ("rna004_130bps_sup@v3.0.1", "quantile", True)):
+        kw = hostapi.scaler_kwargs(config.load_model_config(os.path.join(base, name)))
+        assert kw["strategy"] == want_strategy and kw["is_rna_model"] == want_rna
+        got = hostapi.scaler_node_ops(_oracle_stats, O.shift_scale_i16_to_f16, x, **kw, **cal)
+        ref = O.ref_scaler_node(x, kw["strategy"], kw["quantile"], kw["standardisation"], kw["is_rna_model"], cal["scaling"],
+                                cal["offset"], cal["open_pore_level"], cal["flow_cell_product_code"]) if os.path.exists(O.REF_SCALER_SO) \
+            else O.scaler_node(x, **kw, **cal)
+        assert (got["signal"].view(np.uint16) == ref["signal"].view(np.uint16)).all()
+        assert got["num_trimmed_samples"] == ref["num_trimmed_samples"] and np.float32(got["scale_pa"]) == np.float32(ref["scale_pa"])
+        assert (got["num_trimmed_samples"] > 1000) == want_rna          # the RNA model cuts the adapter, the DNA model trims 10
