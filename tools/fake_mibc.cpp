@@ -153,7 +153,8 @@ int mibc_device_count(void) {
     return s ? std::atoi(s) : 1;
 }
 int mibc_device_memory(int, size_t *free_bytes, size_t *total_bytes) {
-    *free_bytes = size_t(200) << 30;
+    const char *s = std::getenv("FAKE_MIBC_FREE_MB");      // what the automatic batch size is sized against
+    *free_bytes = s ? size_t(std::atol(s)) << 20 : size_t(200) << 30;
     *total_bytes = size_t(288) << 30;
     return MIBC_OK;
 }

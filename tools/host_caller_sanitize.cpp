@@ -218,6 +218,36 @@ int main() {
         if (!same(got, want)) die("two devices: differs from plain runners");
         std::printf("two devices: %zu reads identical; %ld reads scaled beside the node\n", reads.size(), scaled.load());
     }
+    // ---- 4. automatic batch size (CudaCaller::determine_batch_dims, CudaCaller.cpp:382-627, as HipCaller::choose_batch_size
+    //         restates it) against the double's memory figures (64 B x T_in per chunk + 64 MB fixed) and time model
+    //         (0.05 ms + 1e-6 ms per row-sample, 20 % cheaper from 256 rows on)
+    {
+        auto chosen = [&](int requested, bool sweep, const char *free_mb) {
+            if (free_mb) setenv("FAKE_MIBC_FREE_MB", free_mb, 1);
+            else unsetenv("FAKE_MIBC_FREE_MB");
+            CallerParams cp;
+            cp.run_batchsize_benchmarks = sweep;
+            HipCaller c(d, &noweights, 0, 0, std::vector<int>{cs}, requested, opts, cp);
+            return std::make_pair(c.batch_size(), c.batch_timings().size());
+        };
+        // explicit request: rounded up to the granularity
+        if (chosen(100, false, nullptr).first != 128) die("auto batch: explicit request not rounded to the granule");
+        // plenty of memory, no sweep: the engine's knee (256 granules)
+        if (chosen(0, false, nullptr).first != 256 * 64) die("auto batch: knee");
+        // memory cap: 0.8 x 1200 MB - 1 GB - 64 MB fixed is negative -> one granule with a warning (the reference falls back too)
+        if (chosen(0, false, "1200").first != 64) die("auto batch: fallback to one granule");
+        // cap in between: 0.8 x 1500 MB - 1024 MB - 64 MB = 112 MB over 64 x 1200 B per chunk = 1529 -> 1472 (23 granules)
+        if (chosen(0, false, "1500").first != 1472) die("auto batch: memory cap");
+        // timing sweep: ladder 32768 .. 1024, all within 5 % of the best time per chunk -> the smallest of the ladder
+        const auto sw = chosen(0, true, nullptr);
+        if (sw.first != 1024 || sw.second != 6) die("auto batch: timing sweep did not pick the smallest batch within the penalty");
+        // sweep under a cap of 640 rows: 640, 320, 128, 64 -> 320 is 5.5 % slower per chunk than 640 -> 640
+        // (0.8 x F - 1088 MB = 640 x 76800 B  ->  F = 1418.6 MB)
+        const auto sc = chosen(0, true, "1419");
+        if (sc.first != 640) { std::printf("got %d\n", sc.first); die("auto batch: sweep under a memory cap"); }
+        unsetenv("FAKE_MIBC_FREE_MB");
+        std::printf("auto batch size: request / knee / fallback / memory cap / sweep / capped sweep as specified\n");
+    }
     std::printf("host_caller_sanitize: all checks passed\n");
     return 0;
 }
