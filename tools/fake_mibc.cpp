@@ -38,6 +38,18 @@ struct mibc_engine {
 
 static thread_local std::string g_err;
 static std::atomic<long> g_engines{0};
+// fault injection for the host layer's error paths: FAKE_MIBC_FAIL_ASYNC_EVERY=k -> every k-th asynchronous batch completes
+// with MIBC_ERR_HIP (nothing written); FAKE_MIBC_FAIL_SYNC=1 -> the synchronous calls (the host's one retry) fail as well
+static std::atomic<long> g_async_calls{0};
+static bool async_should_fail() {
+    const char *s = std::getenv("FAKE_MIBC_FAIL_ASYNC_EVERY");
+    const long k = s ? std::atol(s) : 0;
+    return k > 0 && (++g_async_calls % k) == 0;
+}
+static bool sync_should_fail() {
+    const char *s = std::getenv("FAKE_MIBC_FAIL_SYNC");
+    return s && std::atoi(s) != 0;
+}
 
 static int fail(mibc_engine *e, int rc, const char *msg) {
     if (e) e->err = msg;
@@ -211,6 +223,7 @@ int mibc_call(mibc_engine *e, const uint16_t *in_host, int N, int T_in, const mi
     int rc = check_call(e, N, T_in);
     if (rc != MIBC_OK) return rc;
     if (!in_host || !out_host || !o) return MIBC_ERR_ARG;
+    if (sync_should_fail()) return fail(e, MIBC_ERR_HIP, "injected failure of a synchronous call");
     return run_fixed(e, in_host, nullptr, N, T_in, out_host);
 }
 int mibc_call_i16(mibc_engine *e, const int16_t *in_host, const float *ss, int N, int T_in, const mibc_decode_opts *o,
@@ -218,6 +231,7 @@ int mibc_call_i16(mibc_engine *e, const int16_t *in_host, const float *ss, int N
     int rc = check_call(e, N, T_in);
     if (rc != MIBC_OK) return rc;
     if (!in_host || !out_host || !o || !ss) return MIBC_ERR_ARG;
+    if (sync_should_fail()) return fail(e, MIBC_ERR_HIP, "injected failure of a synchronous call");
     return run_fixed(e, in_host, ss, N, T_in, out_host);
 }
 int mibc_call_var(mibc_engine *e, const void *in_host, const float *ss, int N, int T_in, const mibc_var_chunk *ch, int n_chunks,
@@ -227,6 +241,7 @@ int mibc_call_var(mibc_engine *e, const void *in_host, const float *ss, int N, i
     if (!in_host || !out_host || !o) return MIBC_ERR_ARG;
     rc = check_var(e, N, T_in, ch, n_chunks);
     if (rc != MIBC_OK) return rc;
+    if (sync_should_fail()) return fail(e, MIBC_ERR_HIP, "injected failure of a synchronous call");
     return run_var(e, in_host, ss, N, T_in, std::vector<mibc_var_chunk>(ch, ch + n_chunks), out_host);
 }
 
@@ -237,7 +252,8 @@ int mibc_call_async(mibc_engine *e, int slot, const void *in_host, const float *
     if (rc != MIBC_OK) return rc;
     if (e->busy[slot]) return fail(e, MIBC_ERR_ARG, "slot submitted again before mibc_call_wait");
     e->busy[slot] = true;
-    e->slot[slot] = std::async(std::launch::async, [=] { return run_fixed(e, in_host, ss, N, T_in, out_host); });
+    const bool inject = async_should_fail();
+    e->slot[slot] = std::async(std::launch::async, [=] { return inject ? int(MIBC_ERR_HIP) : run_fixed(e, in_host, ss, N, T_in, out_host); });
     return MIBC_OK;
 }
 int mibc_call_var_async(mibc_engine *e, int slot, const void *in_host, const float *ss, int N, int T_in, const mibc_var_chunk *ch,
@@ -250,7 +266,8 @@ int mibc_call_var_async(mibc_engine *e, int slot, const void *in_host, const flo
     if (e->busy[slot]) return fail(e, MIBC_ERR_ARG, "slot submitted again before mibc_call_wait");
     std::vector<mibc_var_chunk> table(ch, ch + n_chunks);       // consumed before the call returns
     e->busy[slot] = true;
-    e->slot[slot] = std::async(std::launch::async, [=] { return run_var(e, in_host, ss, N, T_in, table, out_host); });
+    const bool inject = async_should_fail();
+    e->slot[slot] = std::async(std::launch::async, [=] { return inject ? int(MIBC_ERR_HIP) : run_var(e, in_host, ss, N, T_in, table, out_host); });
     return MIBC_OK;
 }
 int mibc_call_poll(mibc_engine *e, int slot) {
@@ -262,6 +279,7 @@ int mibc_call_wait(mibc_engine *e, int slot) {
     if (!e->busy[slot]) return fail(e, MIBC_ERR_ARG, "mibc_call_wait: nothing submitted on this slot");
     const int rc = e->slot[slot].get();
     e->busy[slot] = false;
+    if (rc != MIBC_OK) e->err = "injected failure of an asynchronous batch";
     return rc;
 }
 

@@ -7,7 +7,9 @@
 //   2. variable chunk sizes (HipModelRunner row packing, mibc_call_var_async on the two slots): every read must equal a direct
 //      evaluation of its chunk plan (generate_variable_chunks -> call each chunk alone -> stitch_chunks);
 //   3. two devices ("hip:all" with FAKE_MIBC_DEVICES=2), and scaler_node(HipCaller&) from two threads WHILE the node is calling
-//      (the engine mutex serialises it with the GPU thread).
+//      (the engine mutex serialises it with the GPU thread);
+//   3b. injected engine failures: retried batches give the same reads, a double failure reaches the caller as an exception;
+//   4. the automatic batch size against hand-computed values.
 #include "mibc_host.h"
 
 #include <atomic>
@@ -218,6 +220,47 @@ int main() {
         if (!same(got, want)) die("two devices: differs from plain runners");
         std::printf("two devices: %zu reads identical; %ld reads scaled beside the node\n", reads.size(), scaled.load());
     }
+    // ---- 3b. error paths (CudaCaller.cpp:698-704: a failed batch is retried once, synchronously; a second failure reaches the
+    //          caller): every third asynchronous batch fails -> the retries must give the same reads; with the synchronous
+    //          calls failing too the node must throw, not hang or return garbage
+    {
+        unsetenv("FAKE_MIBC_DEVICES");
+        auto reads = make_reads(1200, 6000);
+        std::vector<RunnerPtr> plain;
+        for (int r = 0; r < 2; ++r)
+            for (int s : sizes) plain.push_back(std::make_unique<PlainRunner>(size_t(s), 64, stride));
+        SimplexBasecaller ref_node(std::move(plain), overlap, stride);
+        const auto want = ref_node.basecall(reads);
+        auto make_node2 = [&](bool variable) {
+            CallerParams cp;
+            cp.variable_chunk_sizes = variable;
+            auto per_dev = create_basecall_runners(d, &noweights, 0, "hip:0", 2, variable ? std::vector<int>{cs} : sizes, 64, opts, cp);
+            std::vector<RunnerPtr> flat;
+            for (auto &dev : per_dev)
+                for (auto &r : dev) flat.push_back(std::move(r));
+            return std::make_unique<SimplexBasecaller>(std::move(flat), overlap, stride);
+        };
+        setenv("FAKE_MIBC_FAIL_ASYNC_EVERY", "3", 1);
+        if (!same(make_node2(false)->basecall(reads), want)) die("retried batches differ");
+        const auto var_ok = [&] {
+            unsetenv("FAKE_MIBC_FAIL_ASYNC_EVERY");
+            return make_node2(true)->basecall_variable(reads);
+        }();
+        setenv("FAKE_MIBC_FAIL_ASYNC_EVERY", "3", 1);
+        if (!same(make_node2(true)->basecall_variable(reads), var_ok)) die("retried variable batches differ");
+        setenv("FAKE_MIBC_FAIL_SYNC", "1", 1);
+        bool threw = false;
+        try {
+            (void)make_node2(false)->basecall(reads);
+        } catch (const std::exception &e) {
+            threw = std::string(e.what()).find("mibc_call") != std::string::npos;
+        }
+        if (!threw) die("a batch that fails twice must reach the caller as an exception");
+        unsetenv("FAKE_MIBC_FAIL_SYNC");
+        unsetenv("FAKE_MIBC_FAIL_ASYNC_EVERY");
+        std::printf("error paths: every third batch failed and was retried (fixed + variable): reads identical; double failure throws\n");
+    }
+
     // ---- 4. automatic batch size (CudaCaller::determine_batch_dims, CudaCaller.cpp:382-627, as HipCaller::choose_batch_size
     //         restates it) against the double's memory figures (64 B x T_in per chunk + 64 MB fixed) and time model
     //         (0.05 ms + 1e-6 ms per row-sample, 20 % cheaper from 256 rows on)
