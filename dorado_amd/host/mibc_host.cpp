@@ -768,6 +768,71 @@ ScaledRead scaler_node(const ScalerOps &ops, const SignalNormalisationParams &p,
     return r;
 }
 
+std::vector<ScaledRead> scaler_node(HipCaller &caller, const SignalNormalisationParams &p, bool is_rna_model,
+                                    const std::vector<ScalerInput> &reads, bool want_signal) {
+    const size_t R = reads.size();
+    std::vector<ScaledRead> out(R);
+    std::vector<const int16_t *> base(R);     // the read behind the RNA adapter cut
+    std::vector<size_t> len(R);
+    std::vector<int> trim(R, 0);
+    for (size_t r = 0; r < R; ++r) {
+        if (!reads[r].raw || reads[r].n_samples == 0) throw std::invalid_argument("scaler_node: empty read");
+        base[r] = reads[r].raw;
+        len[r] = reads[r].n_samples;
+        if (is_rna_model) {
+            const RnaTrim t = rna_trim(reads[r].raw, reads[r].n_samples, reads[r].has_rna_based_adapters);
+            trim[r] = t.trim_start;
+            out[r].rna_adapter_end_signal_pos = t.rna_adapter_end_signal_pos;
+            base[r] += t.trim_start;
+            len[r] -= size_t(t.trim_start);
+        }
+    }
+    if (p.strategy == ScalingStrategy::PA) {
+        for (size_t r = 0; r < R; ++r) out[r].scaling = pa_read_scaling(p, reads[r].cal);
+    } else {   // one launch over all reads
+        std::vector<std::pair<const int16_t *, size_t>> spans(R);
+        for (size_t r = 0; r < R; ++r) {
+            const size_t skip = std::min(size_t(out[r].rna_adapter_end_signal_pos), len[r]);
+            spans[r] = {base[r] + skip, len[r] - skip};
+        }
+        const auto ss = caller.scaler_stats(spans, p);
+        for (size_t r = 0; r < R; ++r) out[r].scaling = finish_read_scaling(ss[r].first, ss[r].second, reads[r].cal);
+    }
+    // the sample map: whole reads (want_signal) or the prefixes the DNA trim looks at, one launch
+    std::vector<std::pair<const int16_t *, size_t>> spans;
+    std::vector<std::pair<float, float>> pairs;
+    std::vector<size_t> slot(R, size_t(-1));
+    for (size_t r = 0; r < R; ++r) {
+        const bool dna_heuristic = !is_rna_model && !p.standardisation.standardise;
+        const size_t n_scaled = want_signal ? len[r] : dna_heuristic ? size_t(std::min(8000, int(len[r] / 2))) : 0;
+        if (n_scaled == 0) continue;
+        slot[r] = spans.size();
+        spans.push_back({base[r], n_scaled});
+        pairs.push_back({out[r].scaling.device_shift(), out[r].scaling.scale});
+    }
+    auto scaled = caller.scale_reads(spans, pairs);
+    static const std::vector<uint16_t> none;
+    for (size_t r = 0; r < R; ++r) {
+        std::vector<uint16_t> *sig = slot[r] != size_t(-1) ? &scaled[slot[r]] : nullptr;
+        int t = trim[r];
+        if (!is_rna_model) {
+            if (p.standardisation.standardise) t = 10;
+            else t = trim_signal(sig ? sig->data() : none.data(), std::min(8000, int(len[r] / 2)));
+            if (size_t(t) < len[r]) {
+                if (want_signal && sig) sig->erase(sig->begin(), sig->begin() + t);
+                out[r].first_sample = size_t(t);
+            } else {
+                t = 0;
+            }
+        } else {
+            out[r].first_sample = size_t(t);
+        }
+        out[r].num_trimmed_samples = t;
+        if (want_signal && sig) out[r].signal_f16 = std::move(*sig);
+    }
+    return out;
+}
+
 // ------------------------------------------------------------------ HipModelRunner
 static std::atomic<int> g_runner_id{0};
 

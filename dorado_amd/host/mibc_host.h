@@ -170,6 +170,18 @@ class HipCaller;
 ScaledRead scaler_node(HipCaller &caller, const SignalNormalisationParams &p, bool is_rna_model, bool has_rna_based_adapters,
                        const int16_t *raw, size_t n_samples, const ReadCalibration &cal, bool want_signal);
 
+// Many reads at once — the form the device wants: ONE statistics launch and ONE sample-map launch for the whole set (per-read
+// calls cost two device round trips each); host decisions (adapter cut, trim) per read around them.  Same results as the
+// per-read form, read by read.
+struct ScalerInput {
+    const int16_t *raw;
+    size_t n_samples;
+    ReadCalibration cal;
+    bool has_rna_based_adapters = false;
+};
+std::vector<ScaledRead> scaler_node(HipCaller &caller, const SignalNormalisationParams &p, bool is_rna_model,
+                                    const std::vector<ScalerInput> &reads, bool want_signal);
+
 // The fields of basecall::BasecallerCreationParams that shape a caller (basecall/include/basecall/ModelRunnerBase.h:43-52;
 // model_config / device / pipeline_type arrive as constructor arguments).
 struct CallerParams {

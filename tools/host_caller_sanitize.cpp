@@ -220,6 +220,42 @@ int main() {
         if (!same(got, want)) die("two devices: differs from plain runners");
         std::printf("two devices: %zu reads identical; %ld reads scaled beside the node\n", reads.size(), scaled.load());
     }
+    // ---- 3a. scaler_node for a whole read set (one statistics launch + one sample-map launch) == read by read
+    {
+        HipCaller c(d, &noweights, 0, 0, cs, 64, opts);
+        std::vector<std::vector<int16_t>> raw(150);
+        std::vector<ScalerInput> in;
+        for (size_t i = 0; i < raw.size(); ++i) {
+            const size_t n = 1 + rng() % 15000, cut = rng() % n;
+            raw[i].resize(n);
+            for (size_t k = 0; k < n; ++k) raw[i][k] = int16_t((k < cut ? 480 : 800) + int(rng() % 140) - 70 + (k < 60 ? 500 : 0));
+            in.push_back({raw[i].data(), n, ReadCalibration{0.15f + 0.0001f * float(i), -230.0f, 201.0f + float(i % 5), "FLO-PRO114M"}, i % 7 == 0});
+        }
+        long checked = 0;
+        for (int strat = 0; strat < 3; ++strat)
+            for (int rna = 0; rna < 2; ++rna)
+                for (int sig = 0; sig < 2; ++sig) {
+                    SignalNormalisationParams p;
+                    p.strategy = strat == 0 ? ScalingStrategy::MED_MAD : strat == 1 ? ScalingStrategy::QUANTILE : ScalingStrategy::PA;
+                    p.standardisation.standardise = strat == 2 && rna == 0;
+                    p.standardisation.mean = 90.0f;
+                    p.standardisation.stdev = 22.0f;
+                    const auto all = scaler_node(c, p, rna != 0, in, sig != 0);
+                    for (size_t i = 0; i < in.size(); ++i) {
+                        const ScaledRead one = scaler_node(c, p, rna != 0, in[i].has_rna_based_adapters, in[i].raw, in[i].n_samples, in[i].cal, sig != 0);
+                        const ScaledRead &b = all[i];
+                        if (one.signal_f16 != b.signal_f16 || one.num_trimmed_samples != b.num_trimmed_samples ||
+                            one.rna_adapter_end_signal_pos != b.rna_adapter_end_signal_pos || one.first_sample != b.first_sample ||
+                            one.scaling.shift != b.scaling.shift || one.scaling.scale != b.scaling.scale ||
+                            one.scaling.scale_pa != b.scaling.scale_pa || one.scaling.shift_pa != b.scaling.shift_pa ||
+                            one.scaling.open_pore_adjustment != b.scaling.open_pore_adjustment)
+                            die("scaler_node over a read set differs from the per-read form");
+                        ++checked;
+                    }
+                }
+        std::printf("scaler_node read sets: %ld read x configuration results identical to the per-read form\n", checked);
+    }
+
     // ---- 3b. error paths (CudaCaller.cpp:698-704: a failed batch is retried once, synchronously; a second failure reaches the
     //          caller): every third asynchronous batch fails -> the retries must give the same reads; with the synchronous
     //          calls failing too the node must throw, not hang or return garbage
