@@ -270,7 +270,7 @@ def auto_batch(eng, cfg, t_in, device):
 
 
 def run_config(capi, synth, cfg, model_key, device, steps, warmup, batch=0, seed=0xD0AD0, timed_barrier=None,
-               with_cpu=False, cpu_kind="hac", check_parity=True, cpu_full=False):
+               with_cpu=False, cpu_kind="hac", check_parity=True, cpu_full=False, decode_overlap=False):
     """Times `steps` steps of one configuration on this rank's GPU.  Returns (result dict, elapsed seconds)."""
     t_in = cfg.chunk_size
     ws = synth.make_weights(cfg, seed=42)
@@ -284,6 +284,8 @@ def run_config(capi, synth, cfg, model_key, device, steps, warmup, batch=0, seed
     d_out = eng.device_alloc(3 * n * T)
     eng.h2d(d_in, x)
     eng.set_profile(1)
+    if decode_overlap:
+        eng.set_decode_overlap(True)
     for _ in range(warmup):
         eng.call_device(d_in, n, t_in, d_out)
     eng.sync()
@@ -291,16 +293,25 @@ def run_config(capi, synth, cfg, model_key, device, steps, warmup, batch=0, seed
         timed_barrier()
     t0 = time.perf_counter()
     lstm_ms, stage = [], None
-    for _ in range(steps):
+    ovl = bool(decode_overlap)
+    for i in range(steps):
         eng.call_device(d_in, n, t_in, d_out)
-        # HIP-event stage times of THIS step on the engine's stream (waits for the step's last event, which the
-        # next step would have to wait for anyway: one stream, in order)
-        stage = eng.stage_ms()
-        lstm_ms.extend(stage["lstm_layer"][: max(1, cfg.lstm_layers)])
+        # HIP-event stage times of the PREVIOUS step (the engine alternates two event sets): the host waits for step
+        # i - 1 while step i is already enqueued, so the per-step read leaves no bubble in the stream
+        if i > 0 and not ovl:
+            stage = eng.stage_ms(prev=True)
+            lstm_ms.extend(stage["lstm_layer"][: max(1, cfg.lstm_layers)])
     eng.sync()
     if timed_barrier:
         timed_barrier()
     el = time.perf_counter() - t0
+    if ovl:
+        # decoder on its own stream: stage events are off in that mode — one more, untimed, serial step supplies them
+        eng.set_decode_overlap(False)
+        eng.call_device(d_in, n, t_in, d_out)
+        eng.sync()
+    stage = eng.stage_ms()           # the last step (complete: the stream has been synchronised)
+    lstm_ms.extend(stage["lstm_layer"][: max(1, cfg.lstm_layers)])
 
     out = np.zeros((3, n, T), np.int8)
     eng.d2h(out, d_out)
@@ -376,6 +387,9 @@ def main():
     ap.add_argument("--host-device", default="",
                     help="device string of the through-host measurement (default: this rank's GPU; 'hip:all' = ONE "
                          "process, one HipCaller per visible device fed from shared chunk queues)")
+    ap.add_argument("--decode-overlap", type=int, default=0,
+                    help="1 = decoder on its own stream with double-buffered scores (mibc_set_decode_overlap): A/B switch, "
+                         "measured and NOT adopted (DESIGN.md 5)")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="cpu_baseline in the exact SURVEY 8d configuration (real chunk length, batch 64 / 16 per runner): "
                          "minutes to hours of host time")
@@ -414,7 +428,8 @@ def main():
                                          seed=0xD0AD0 + rank, timed_barrier=barrier,
                                          with_cpu=single and not args.no_cpu_baseline,
                                          cpu_kind="sup" if args.model in ("sup", "sup5") else "hac",
-                                         check_parity=not args.profile_run, cpu_full=args.cpu_baseline_full)
+                                         check_parity=not args.profile_run, cpu_full=args.cpu_baseline_full,
+                                         decode_overlap=bool(args.decode_overlap))
     if world > 1:
         tt = torch.tensor([el], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -47,7 +47,7 @@ EXPORTS = [
     "mibc_reserve", "mibc_output_steps", "mibc_batch_granularity", "mibc_host_alloc",
     "mibc_host_free", "mibc_device_alloc", "mibc_device_free", "mibc_memcpy_h2d",
     "mibc_memcpy_d2h", "mibc_forward", "mibc_decode", "mibc_call_device", "mibc_call",
-    "mibc_sync", "mibc_quantize_lstm_weights", "mibc_time_forward", "mibc_get_stage_ms", "mibc_set_profile", "mibc_debug_tap",
+    "mibc_sync", "mibc_set_decode_overlap", "mibc_quantize_lstm_weights", "mibc_time_forward", "mibc_get_stage_ms", "mibc_get_stage_ms_prev", "mibc_set_profile", "mibc_debug_tap",
     "mibc_forward_i16", "mibc_call_device_i16", "mibc_call_i16", "mibc_scaler_stats", "mibc_scale_reads",
     "mibc_svb16_decode", "mibc_forward_var", "mibc_call_device_var", "mibc_call_var",
     "mibc_call_async", "mibc_call_wait", "mibc_call_poll", "mibc_call_var_async",
@@ -129,6 +129,7 @@ def lib():
         L.mibc_sync.argtypes = [C.c_void_p]
         L.mibc_time_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.mibc_get_stage_ms.argtypes = [C.c_void_p, C.POINTER(StageMsC)]
+        L.mibc_get_stage_ms_prev.argtypes = [C.c_void_p, C.POINTER(StageMsC)]
         L.mibc_set_profile.argtypes = [C.c_void_p, C.c_int]
         L.mibc_quantize_lstm_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.mibc_debug_tap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
@@ -247,9 +248,18 @@ class Engine:
     def set_profile(self, level: int):
         lib().mibc_set_profile(self._h, level)
 
-    def stage_ms(self) -> dict:
+    def set_decode_overlap(self, on: bool = True):
+        """Decoder on its own stream, scores double-buffered: the decoder of a batch runs under the network of the next."""
+        self._check(lib().mibc_set_decode_overlap(self._h, C.c_int(int(on))), "mibc_set_decode_overlap")
+
+    def stage_ms(self, prev: bool = False) -> dict:
+        """HIP-event stage times of the last profiled call; prev=True: of the one before it (the host can read call i - 1
+        while call i is already enqueued — no pipeline bubble)."""
         s = StageMsC()
-        self._check(lib().mibc_get_stage_ms(self._h, C.byref(s)), "mibc_get_stage_ms")
+        if prev:
+            self._check(lib().mibc_get_stage_ms_prev(self._h, C.byref(s)), "mibc_get_stage_ms_prev")
+        else:
+            self._check(lib().mibc_get_stage_ms(self._h, C.byref(s)), "mibc_get_stage_ms")
         return {"conv": s.conv, "lstm": s.lstm, "head": s.head, "decode": s.decode,
                 "total": s.total, "lstm_layer": [s.lstm_layer[i] for i in range(8)]}
 

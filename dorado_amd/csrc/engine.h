@@ -172,15 +172,27 @@ struct mibc_engine {
         size_t var_bytes = 0;
     } aslot[2];
     hipStream_t s_in = nullptr, s_out = nullptr;
+    // mibc_set_decode_overlap: decoder stream, second scores buffer, per-parity events (head done -> decoder may read;
+    // decoder done -> the head two (sub-)batches later may overwrite)
+    int decode_overlap = 0;
+    hipStream_t s_dec = nullptr;
+    half_t *scores2 = nullptr;
+    hipEvent_t ev_head[2] = {nullptr, nullptr}, ev_dec[2] = {nullptr, nullptr};
+    bool dec_pending[2] = {false, false};
+    unsigned dec_parity = 0;
     // last call
     half_t *lstm_out = nullptr;
     int last_N = 0, last_T = 0, last_T_in = 0;
     int profile = 0, taps = 0;
     enum { EV_START, EV_CONV, EV_LSTM0, EV_HEAD_BASE = EV_LSTM0 + 8, EV_END = EV_HEAD_BASE + 1, EV_N };
-    hipEvent_t ev[16] = {};
+    // two sets of stage events, alternating per profiled call: the host reads the set of call i - 1 (mibc_get_stage_ms_prev)
+    // while call i is already enqueued, so per-step stage times cost no pipeline bubble
+    hipEvent_t ev[2][16] = {};
     float head_ms = 0, dec_ms = 0;
-    std::vector<hipEvent_t> sub_ev;  // per decode sub-batch: head start, head end, decode end
-    bool timed = false;
+    std::vector<hipEvent_t> sub_ev[2];  // per decode sub-batch: head start, head end, decode end
+    bool timed[2] = {false, false};
+    int prof_N[2] = {0, 0};
+    int ps = 0;                         // set of the profiled call enqueued last
     // ---- transformer model (engine_tx.hip) ----
     bool is_tx = false;
     struct TxConv {

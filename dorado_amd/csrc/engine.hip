@@ -151,7 +151,8 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
         e->K = 4 * S_;
         auto body = [&]() -> int {
             HIP_OK(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-            for (auto &ev : e->ev) HIP_OK(e, hipEventCreate(&ev));
+            for (auto &set : e->ev)
+                for (auto &ev : set) HIP_OK(e, hipEventCreate(&ev));
             const int rc = tx_create(e, d, weights, n_weights);
             if (rc != MIBC_OK) return rc;
             const char *tp = getenv("MIBC_TAPS");
@@ -210,7 +211,8 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
     // every failure past this point goes through finish_create -> mibc_destroy (no leaked stream / events / weights)
     auto body = [&]() -> int {
     HIP_OK(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    for (auto &ev : e->ev) HIP_OK(e, hipEventCreate(&ev));
+    for (auto &set : e->ev)
+                for (auto &ev : set) HIP_OK(e, hipEventCreate(&ev));
 
     int wi = 0;
     // conv1 [16][1][5] -> [k][co]; conv2 [16][16][5] -> [k][ci][co]
@@ -250,7 +252,9 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
     // LSTM layers: [W_ih | W_hh] in MFMA-fragment order + summed biases in D-register order
     // the reference quantises EVERY LSTM layer when the convolution in front hands over tanh outputs (nn/ConvStack.cpp:72:
     // CUTLASS_TNC_I8 for Activation::TANH — the v4.3 LSTM-CRF models), and keeps the first layer in f16 otherwise (:73, LSTMStack.cpp:199-207)
-    const bool q_all = d.lstm_quant && d.n_convs >= 3 && d.conv_act[d.n_convs - 1] == MIBC_ACT_TANH;
+    // (the reference selects that layout for 128 < lstm_size <= 1024 only, nn/ConvStack.cpp:69-73; at lstm_size <= 128 its
+    // quantised path is the NTC forward_quantized scheme, a different one: first layer f16 here)
+    const bool q_all = d.lstm_quant && d.n_convs >= 3 && d.conv_act[d.n_convs - 1] == MIBC_ACT_TANH && e->C > 128;
     for (int l = 0; l < d.lstm_layers; ++l) {
         const float *Wih = weights[wi++], *Whh = weights[wi++], *bih = weights[wi++],
                     *bhh = weights[wi++];
@@ -452,8 +456,10 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
 
 static void free_ws(mibc_engine *e) {
     if (e->is_tx) tx_free_ws(e);
-    void *ptrs[] = {e->in_stage, e->a2p, e->xa, e->xb, e->scores, e->mid, e->a1_tap, e->bwd,
+    void *ptrs[] = {e->in_stage, e->a2p, e->xa, e->xb, e->scores, e->scores2, e->mid, e->a1_tap, e->bwd,
                     e->prob_tap, e->trace, e->path_state, e->out3, e->ss_stage, e->cl_flags, e->cl_cstate};
+    e->scores2 = nullptr;
+    e->dec_pending[0] = e->dec_pending[1] = false;
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     e->cl_flags = nullptr;
@@ -464,8 +470,10 @@ static void free_ws(mibc_engine *e) {
     e->path_state = nullptr;
     e->out3 = nullptr;
     e->ss_stage = nullptr;
-    for (auto ev : e->sub_ev) (void)hipEventDestroy(ev);
-    e->sub_ev.clear();
+    for (auto &set : e->sub_ev) {
+        for (auto ev : set) (void)hipEventDestroy(ev);
+        set.clear();
+    }
     e->N_res = 0;
     e->T_in_cap = 0;
     e->T_in_res = 0;
@@ -476,6 +484,14 @@ extern "C" void mibc_destroy(mibc_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->s_dec) {
+        (void)hipStreamSynchronize(e->s_dec);
+        (void)hipStreamDestroy(e->s_dec);
+        for (int p = 0; p < 2; ++p) {
+            if (e->ev_head[p]) (void)hipEventDestroy(e->ev_head[p]);
+            if (e->ev_dec[p]) (void)hipEventDestroy(e->ev_dec[p]);
+        }
+    }
     free_ws(e);
     if (e->is_tx) tx_destroy(e);
     void *ptrs[] = {e->w1, e->b1, e->w2, e->b2, e->b3, e->w3, e->head_w1, e->head_w2, e->head_b1, e->w3f, e->head_w1f,
@@ -513,8 +529,9 @@ extern "C" void mibc_destroy(mibc_engine *e) {
     if (e->lstm_zero) (void)hipFree(e->lstm_zero);
     if (e->cl_err) (void)hipFree(e->cl_err);
     if (e->cl_err_host) (void)hipHostFree(e->cl_err_host);
-    for (auto &ev : e->ev)
-        if (ev) (void)hipEventDestroy(ev);
+    for (auto &set : e->ev)
+        for (auto &ev : set)
+            if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -526,7 +543,11 @@ extern "C" int mibc_output_steps(const mibc_engine *e, int T_in) {
 }
 
 extern "C" int mibc_batch_granularity(const mibc_engine *e) {
-    return e->is_tx ? 1 : mibc_lstm_rows_per_wg(e->C);
+    if (e->is_tx) return 1;
+    // the quantised wide layers exist only as the 256-row cluster kernel (no per-workgroup int8 instance for C >= 512): every
+    // batch size derived from the granularity (mibc_reserve, HipCaller::choose_batch_size) is then a whole number of clusters
+    if (e->d.lstm_quant && e->C >= 512) return 256;
+    return mibc_lstm_rows_per_wg(e->C);
 }
 
 static int decode_sub_default(const mibc_engine *e) {
@@ -607,6 +628,7 @@ extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
     HIP_OK(e, hipSetDevice(e->device));
     if (e->N_res >= N_max && e->T_in_cap >= T_in) return set_geometry(e, T_in);
     HIP_OK(e, hipStreamSynchronize(e->stream));
+    if (e->s_dec) HIP_OK(e, hipStreamSynchronize(e->s_dec));
     free_ws(e);
     const size_t T = (size_t)mibc_output_steps(e, T_in);
     if (T < 1) return fail(e, MIBC_ERR_ARG, "chunk too short");
@@ -638,6 +660,7 @@ extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
         }
     }
     if (alloc((void **)&e->scores, Nd * T * e->K * 2)) return MIBC_ERR_MEM;
+    if (e->decode_overlap && alloc((void **)&e->scores2, Nd * T * e->K * 2)) return MIBC_ERR_MEM;
     if (e->d.out_features > 0)
         if (alloc((void **)&e->mid, Nd * T * e->d.out_features * 2)) return MIBC_ERR_MEM;
     if (alloc((void **)&e->bwd, Nd * (T + 1) * e->S * 4)) return MIBC_ERR_MEM;
@@ -649,8 +672,10 @@ extern "C" int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
         if (alloc((void **)&e->prob_tap, Nd * T * 4)) return MIBC_ERR_MEM;
     }
     const int nsub = (N_max + e->Nd - 1) / e->Nd;
-    e->sub_ev.resize((size_t)nsub * 3);
-    for (auto &ev : e->sub_ev) HIP_OK(e, hipEventCreate(&ev));
+    for (auto &set : e->sub_ev) {
+        set.resize((size_t)nsub * 3);
+        for (auto &ev : set) HIP_OK(e, hipEventCreate(&ev));
+    }
     e->N_res = N_max;
     e->T_in_cap = T_in;
     e->T_in_res = 0;
@@ -691,11 +716,45 @@ extern "C" int mibc_memcpy_d2h(mibc_engine *e, void *dst, const void *src, size_
     HIP_OK(e, hipStreamSynchronize(e->stream));
     return check_cluster_error(e);
 }
+// decode overlap: everything the decoder stream still has in flight becomes a dependency of `st` (the engine's stream before a
+// serial stage touches the scores buffers / the caller's output; a copy stream before it reads the output planes)
+static int overlap_join(mibc_engine *e, hipStream_t st) {
+    for (int p = 0; p < 2; ++p)
+        if (e->dec_pending[p]) HIP_OK(e, hipStreamWaitEvent(st, e->ev_dec[p], 0));
+    return MIBC_OK;
+}
+
 extern "C" int mibc_sync(mibc_engine *e) {
     HIP_OK(e, hipSetDevice(e->device));
     HIP_OK(e, hipStreamSynchronize(e->stream));
+    if (e->s_dec) {
+        HIP_OK(e, hipStreamSynchronize(e->s_dec));
+        e->dec_pending[0] = e->dec_pending[1] = false;
+    }
     return check_cluster_error(e);
 }
+
+extern "C" int mibc_set_decode_overlap(mibc_engine *e, int on) {
+    if (!e) return MIBC_ERR_ARG;
+    HIP_OK(e, hipSetDevice(e->device));
+    int rc = mibc_sync(e);
+    if (rc != MIBC_OK) return rc;
+    if (on && !e->s_dec) {
+        HIP_OK(e, hipStreamCreateWithFlags(&e->s_dec, hipStreamNonBlocking));
+        for (int p = 0; p < 2; ++p) {
+            HIP_OK(e, hipEventCreateWithFlags(&e->ev_head[p], hipEventDisableTiming));
+            HIP_OK(e, hipEventCreateWithFlags(&e->ev_dec[p], hipEventDisableTiming));
+        }
+    }
+    if (on && !e->scores2 && e->scores) {      // a workspace is already reserved: add the second scores buffer of the same size
+        const size_t T = (size_t)mibc_output_steps(e, e->T_in_cap);
+        const size_t Nd = (size_t)((e->N_res < e->Nd) ? e->N_res : e->Nd);
+        if (hipMalloc((void **)&e->scores2, Nd * T * e->K * 2) != hipSuccess) return fail(e, MIBC_ERR_MEM, "decode overlap: second scores buffer");
+    }
+    e->decode_overlap = on ? 1 : 0;
+    return MIBC_OK;
+}
+
 extern "C" int mibc_set_profile(mibc_engine *e, int level) {
     e->profile = level;
     return MIBC_OK;
@@ -707,7 +766,8 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     const int T = mibc_output_steps(e, T_in);
     const bool prof = e->profile > 0;
     MibcRange r_enc(e, "mibc:encoder");
-    if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_START], e->stream));
+    if (prof) e->ps ^= 1;
+    if (prof) HIP_OK(e, hipEventRecord(e->ev[e->ps][mibc_engine::EV_START], e->stream));
     if (mibc_launch_conv12(e->stream, in_dev, e->w1, e->b1, e->w2, e->b2, e->a2p, e->a1_tap, e->in_ss, e->in_smask, N, T_in,
                            e->Tpitch, e->pad3, d.conv_act[0], d.conv_act[1]) != 0)
         return fail(e, MIBC_NOT_SUPPORTED, "conv activation combination not supported");
@@ -744,11 +804,13 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     g.act = d.conv_act[2];
     if (!conv3_done && mibc_launch_gemm_tn(e->stream, &g) != 0)
         return fail(e, MIBC_NOT_SUPPORTED, "conv3 gemm shape");
-    if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_CONV], e->stream));
+    if (prof) HIP_OK(e, hipEventRecord(e->ev[e->ps][mibc_engine::EV_CONV], e->stream));
     half_t *cur = e->xa, *nxt = e->xb;
     // lstm_quant: every layer int8 when conv3 hands over tanh outputs (the reference's CUTLASS_TNC_I8 layout, nn/ConvStack.cpp:72),
     // else the first layer in f16 (LSTMStack.cpp:199-207); conv3's f16 output is converted once (round(127 v), v in (-1, 1))
-    const bool q_all = d.lstm_quant && d.n_convs >= 3 && d.conv_act[d.n_convs - 1] == MIBC_ACT_TANH;
+    // (the reference selects that layout for 128 < lstm_size <= 1024 only, nn/ConvStack.cpp:69-73; at lstm_size <= 128 its
+    // quantised path is the NTC forward_quantized scheme, a different one: first layer f16 here)
+    const bool q_all = d.lstm_quant && d.n_convs >= 3 && d.conv_act[d.n_convs - 1] == MIBC_ACT_TANH && e->C > 128;
     if (q_all) {
         if (mibc_launch_q8_convert(e->stream, cur, (int8_t *)nxt, (size_t)T * N * e->C) != 0) return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
         half_t *t = cur;
@@ -780,7 +842,7 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
                 e->cl_used = true;
                 if (mibc_launch_q8_convert(e->stream, nxt, (int8_t *)cur, (size_t)T * N * e->C) != 0)
                     return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
-                if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_LSTM0 + l], e->stream));
+                if (prof) HIP_OK(e, hipEventRecord(e->ev[e->ps][mibc_engine::EV_LSTM0 + l], e->stream));
                 continue;      // layer 1 reads `cur` (int8): the ping-pong is not swapped after layer 0
             }
             const bool last = (l + 1 == d.lstm_layers);
@@ -800,7 +862,7 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
                 // so the ping-pong is NOT swapped after this layer
                 if (qrc == 0) qrc = mibc_launch_q8_convert(e->stream, nxt, (int8_t *)cur, (size_t)T * N * e->C);
                 if (qrc != 0) return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
-                if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_LSTM0 + l], e->stream));
+                if (prof) HIP_OK(e, hipEventRecord(e->ev[e->ps][mibc_engine::EV_LSTM0 + l], e->stream));
                 continue;
             }
             qrc = mibc_launch_lstm_layer_q8(e->stream, e->C, (const int8_t *)cur, nxt, e->lstm_wq[l], e->lstm_bn[l], e->lstm_deq[l],
@@ -815,7 +877,7 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
         } else if (mibc_launch_lstm_layer(e->stream, e->C, cur, nxt, e->lstm_w[l], e->lstm_w16[l], e->lstm_bn[l], T, N,
                                           reverse) != 0)
             return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
-        if (prof && l < 8) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_LSTM0 + l], e->stream));
+        if (prof && l < 8) HIP_OK(e, hipEventRecord(e->ev[e->ps][mibc_engine::EV_LSTM0 + l], e->stream));
         half_t *t = cur;
         cur = nxt;
         nxt = t;
@@ -943,11 +1005,11 @@ extern "C" int mibc_forward(mibc_engine *e, const uint16_t *in_dev, int N, int T
         rc = e->is_tx ? tx_run_head(e, N, n0, ns, so) : run_head(e, N, T, n0, ns, so);
         if (rc != MIBC_OK) return rc;
     }
-    if (e->profile > 0) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_END], e->stream));
+    if (e->profile > 0) HIP_OK(e, hipEventRecord(e->ev[e->ps][mibc_engine::EV_END], e->stream));
     e->last_N = N;
     e->last_T = T;
     e->last_T_in = T_in;
-    e->timed = false;
+    e->timed[e->ps] = false;
     HIP_OK(e, hipGetLastError());
     return MIBC_OK;
 }
@@ -960,6 +1022,10 @@ extern "C" int mibc_decode(mibc_engine *e, const uint16_t *scores_dev, int N, in
     if (e->N_res <= 0 || T != e->T_res) return fail(e, MIBC_ERR_ARG, "mibc_reserve first (T mismatch)");
     if (N > e->N_res) return fail(e, MIBC_ERR_ARG, "mibc_decode: N exceeds the reserved batch");
     HIP_OK(e, hipSetDevice(e->device));
+    {
+        const int jrc = overlap_join(e, e->stream);   // the decoder's scratch (guides, trace) is shared with the decoder stream
+        if (jrc != MIBC_OK) return jrc;
+    }
     for (int n0 = 0; n0 < N; n0 += e->Nd) {
         const int ns = (N - n0 < e->Nd) ? (N - n0) : e->Nd;
         const int rc = mibc_launch_decode(e->stream, (const half_t *)scores_dev + (size_t)n0 * T * e->K,
@@ -975,36 +1041,72 @@ extern "C" int mibc_decode(mibc_engine *e, const uint16_t *scores_dev, int N, in
     return MIBC_OK;
 }
 
+// head of sub-batch [n0, n0 + ns) on the engine's stream into the scores buffer of the current parity, its decoder on the
+// decoder stream.  The head waits for the decoder that last read this buffer (two sub-batches ago).
+static int head_and_decode_overlapped(mibc_engine *e, int N, int T, int n0, int ns, const mibc_decode_opts *o, int8_t *out_dev) {
+    const int p = (int)(e->dec_parity++ & 1u);
+    half_t *sc = p ? e->scores2 : e->scores;
+    if (e->dec_pending[p]) HIP_OK(e, hipStreamWaitEvent(e->stream, e->ev_dec[p], 0));
+    const int rc = e->is_tx ? tx_run_head(e, N, n0, ns, sc) : run_head(e, N, T, n0, ns, sc);
+    if (rc != MIBC_OK) return rc;
+    HIP_OK(e, hipEventRecord(e->ev_head[p], e->stream));
+    HIP_OK(e, hipStreamWaitEvent(e->s_dec, e->ev_head[p], 0));
+    if (mibc_launch_decode(e->s_dec, sc, ns, T, e->S, o->beam_width, o->beam_cut, o->blank_score, clamp_value(e), o->q_shift,
+                           o->q_scale, e->bwd, e->trace, e->path_state, out_dev + (size_t)n0 * T, (size_t)N * T, e->prob_tap) != 0)
+        return fail(e, MIBC_NOT_SUPPORTED, "decoder: beam_width must be 1..32");
+    HIP_OK(e, hipEventRecord(e->ev_dec[p], e->s_dec));
+    e->dec_pending[p] = true;
+    return MIBC_OK;
+}
+
 extern "C" int mibc_call_device(mibc_engine *e, const uint16_t *in_dev, int N, int T_in,
                                 const mibc_decode_opts *o, int8_t *out_dev) {
     if (!o) return MIBC_ERR_ARG;
     int rc = check_call(e, N, T_in);
     if (rc != MIBC_OK) return rc;
     const int T = mibc_output_steps(e, T_in);
-    const bool prof = e->profile > 0;
+    const bool ovl = e->decode_overlap && e->scores2 && !e->taps;
+    const bool prof = e->profile > 0 && !ovl;
     rc = e->is_tx ? tx_run_network(e, (const half_t *)in_dev, N, T_in)
                   : run_encoder(e, (const half_t *)in_dev, N, T_in);
+    if (rc != MIBC_OK) return rc;
+    if (ovl) {
+        // (the caller's out_dev is written on the decoder stream: mibc_sync, or overlap_join on the stream that reads it)
+        for (int n0 = 0; n0 < N; n0 += e->Nd) {
+            const int ns = (N - n0 < e->Nd) ? (N - n0) : e->Nd;
+            rc = head_and_decode_overlapped(e, N, T, n0, ns, o, out_dev);
+            if (rc != MIBC_OK) return rc;
+        }
+        e->last_N = N;
+        e->last_T = T;
+        e->last_T_in = T_in;
+        e->timed[e->ps] = false;
+        HIP_OK(e, hipGetLastError());
+        return MIBC_OK;
+    }
+    rc = overlap_join(e, e->stream);   // overlap switched off with decoders in flight
     if (rc != MIBC_OK) return rc;
     int si = 0;
     for (int n0 = 0; n0 < N; n0 += e->Nd, ++si) {
         const int ns = (N - n0 < e->Nd) ? (N - n0) : e->Nd;
-        if (prof) HIP_OK(e, hipEventRecord(e->sub_ev[si * 3 + 0], e->stream));
+        if (prof) HIP_OK(e, hipEventRecord(e->sub_ev[e->ps][si * 3 + 0], e->stream));
         rc = e->is_tx ? tx_run_head(e, N, n0, ns, e->scores) : run_head(e, N, T, n0, ns, e->scores);
         if (rc != MIBC_OK) return rc;
-        if (prof) HIP_OK(e, hipEventRecord(e->sub_ev[si * 3 + 1], e->stream));
+        if (prof) HIP_OK(e, hipEventRecord(e->sub_ev[e->ps][si * 3 + 1], e->stream));
         MibcRange r_dec(e, "beam_search");
         if (mibc_launch_decode(e->stream, e->scores, ns, T, e->S, o->beam_width, o->beam_cut,
                                o->blank_score, clamp_value(e), o->q_shift, o->q_scale, e->bwd, e->trace,
                                e->path_state, out_dev + (size_t)n0 * T, (size_t)N * T,
                                e->prob_tap) != 0)
             return fail(e, MIBC_NOT_SUPPORTED, "decoder: beam_width must be 1..32");
-        if (prof) HIP_OK(e, hipEventRecord(e->sub_ev[si * 3 + 2], e->stream));
+        if (prof) HIP_OK(e, hipEventRecord(e->sub_ev[e->ps][si * 3 + 2], e->stream));
     }
-    if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_END], e->stream));
+    if (prof) HIP_OK(e, hipEventRecord(e->ev[e->ps][mibc_engine::EV_END], e->stream));
     e->last_N = N;
     e->last_T = T;
     e->last_T_in = T_in;
-    e->timed = prof;
+    e->timed[e->ps] = prof;
+    e->prof_N[e->ps] = N;
     HIP_OK(e, hipGetLastError());
     return MIBC_OK;
 }
@@ -1017,6 +1119,8 @@ extern "C" int mibc_call(mibc_engine *e, const uint16_t *in_host, int N, int T_i
     HIP_OK(e, hipMemcpyAsync(e->in_stage, in_host, (size_t)N * T_in * 2, hipMemcpyHostToDevice,
                              e->stream));
     rc = mibc_call_device(e, (const uint16_t *)e->in_stage, N, T_in, o, e->out3);
+    if (rc != MIBC_OK) return rc;
+    rc = overlap_join(e, e->stream);
     if (rc != MIBC_OK) return rc;
     HIP_OK(e, hipMemcpyAsync(out_host, e->out3, (size_t)3 * N * T, hipMemcpyDeviceToHost, e->stream));
     HIP_OK(e, hipStreamSynchronize(e->stream));
@@ -1075,6 +1179,8 @@ extern "C" int mibc_call_async(mibc_engine *e, int slot, const void *in_host, co
     if (rc != MIBC_OK) return rc;
     HIP_OK(e, hipEventRecord(a.ev_done, e->stream));
     HIP_OK(e, hipStreamWaitEvent(e->s_out, a.ev_done, 0));
+    rc = overlap_join(e, e->s_out);          // decode overlap: the output planes are complete when the decoder stream says so
+    if (rc != MIBC_OK) return rc;
     HIP_OK(e, hipMemcpyAsync(out_host, a.out3, (size_t)3 * N * T, hipMemcpyDeviceToHost, e->s_out));
     HIP_OK(e, hipEventRecord(a.ev_out, e->s_out));
     a.n = N;
@@ -1328,7 +1434,9 @@ static int var_run(mibc_engine *e, const void *in_dev, const float *shift_scale_
                    const VarPlan &vp, const char *dev_blob, const mibc_decode_opts *o, int8_t *out_dev) {
     const int T = mibc_output_steps(e, T_in);
     var_point(e, vp, dev_blob, shift_scale_dev);
-    int rc = run_encoder(e, (const half_t *)in_dev, N, T_in);
+    int rc = overlap_join(e, e->stream);      // variable batches stay serial: they use the first scores buffer on this stream
+    if (rc != MIBC_OK) return rc;
+    rc = run_encoder(e, (const half_t *)in_dev, N, T_in);
     if (rc == MIBC_OK) {
         // gaps of the output planes stay zero
         if (hipMemsetAsync(out_dev, 0, (size_t)3 * N * T, e->stream) != hipSuccess) rc = MIBC_ERR_HIP;
@@ -1352,7 +1460,7 @@ static int var_run(mibc_engine *e, const void *in_dev, const float *shift_scale_
     e->last_N = N;
     e->last_T = T;
     e->last_T_in = T_in;
-    e->timed = false;
+    e->timed[e->ps] = false;
     HIP_OK(e, hipGetLastError());
     return MIBC_OK;
 }
@@ -1434,43 +1542,48 @@ extern "C" int mibc_call_var_async(mibc_engine *e, int slot, const void *in_host
     return MIBC_OK;
 }
 
-extern "C" int mibc_get_stage_ms(mibc_engine *e, mibc_stage_ms *out) {
+static int stage_ms_of(mibc_engine *e, int set, mibc_stage_ms *out) {
     if (!e || !out) return MIBC_ERR_ARG;
     memset(out, 0, sizeof(*out));
-    if (!e->timed) return fail(e, MIBC_ERR_ARG, "no profiled mibc_call_device yet (mibc_set_profile(1))");
+    if (!e->timed[set]) return fail(e, MIBC_ERR_ARG, "no profiled mibc_call_device yet (mibc_set_profile(1))");
     HIP_OK(e, hipSetDevice(e->device));
-    HIP_OK(e, hipEventSynchronize(e->ev[mibc_engine::EV_END]));
+    HIP_OK(e, hipEventSynchronize(e->ev[set][mibc_engine::EV_END]));
     float ms = 0;
-    HIP_OK(e, hipEventElapsedTime(&ms, e->ev[mibc_engine::EV_START], e->ev[mibc_engine::EV_CONV]));
+    HIP_OK(e, hipEventElapsedTime(&ms, e->ev[set][mibc_engine::EV_START], e->ev[set][mibc_engine::EV_CONV]));
     out->conv = ms;
-    hipEvent_t prev = e->ev[mibc_engine::EV_CONV];
+    hipEvent_t prev = e->ev[set][mibc_engine::EV_CONV];
     if (e->is_tx) {  // the whole encoder stack + upsample is reported in the "lstm" slot
-        HIP_OK(e, hipEventElapsedTime(&ms, prev, e->ev[mibc_engine::EV_LSTM0]));
+        HIP_OK(e, hipEventElapsedTime(&ms, prev, e->ev[set][mibc_engine::EV_LSTM0]));
         out->lstm = out->lstm_layer[0] = ms;
     }
     for (int l = 0; !e->is_tx && l < e->d.lstm_layers && l < 8; ++l) {
-        HIP_OK(e, hipEventElapsedTime(&ms, prev, e->ev[mibc_engine::EV_LSTM0 + l]));
+        HIP_OK(e, hipEventElapsedTime(&ms, prev, e->ev[set][mibc_engine::EV_LSTM0 + l]));
         out->lstm_layer[l] = ms;
         out->lstm += ms;
-        prev = e->ev[mibc_engine::EV_LSTM0 + l];
+        prev = e->ev[set][mibc_engine::EV_LSTM0 + l];
     }
-    const int nsub = (e->last_N + e->Nd - 1) / e->Nd;
+    const int nsub = (e->prof_N[set] + e->Nd - 1) / e->Nd;
     for (int si = 0; si < nsub; ++si) {
-        HIP_OK(e, hipEventElapsedTime(&ms, e->sub_ev[si * 3 + 0], e->sub_ev[si * 3 + 1]));
+        HIP_OK(e, hipEventElapsedTime(&ms, e->sub_ev[set][si * 3 + 0], e->sub_ev[set][si * 3 + 1]));
         out->head += ms;
-        HIP_OK(e, hipEventElapsedTime(&ms, e->sub_ev[si * 3 + 1], e->sub_ev[si * 3 + 2]));
+        HIP_OK(e, hipEventElapsedTime(&ms, e->sub_ev[set][si * 3 + 1], e->sub_ev[set][si * 3 + 2]));
         out->decode += ms;
     }
-    HIP_OK(e, hipEventElapsedTime(&ms, e->ev[mibc_engine::EV_START], e->ev[mibc_engine::EV_END]));
+    HIP_OK(e, hipEventElapsedTime(&ms, e->ev[set][mibc_engine::EV_START], e->ev[set][mibc_engine::EV_END]));
     out->total = ms;
     return MIBC_OK;
 }
+extern "C" int mibc_get_stage_ms(mibc_engine *e, mibc_stage_ms *out) { return e ? stage_ms_of(e, e->ps, out) : MIBC_ERR_ARG; }
+// stage times of the profiled call BEFORE the one enqueued last (blocks only until that earlier call has finished)
+extern "C" int mibc_get_stage_ms_prev(mibc_engine *e, mibc_stage_ms *out) { return e ? stage_ms_of(e, e->ps ^ 1, out) : MIBC_ERR_ARG; }
 
 // min of 2 timed forward runs (network only), like CudaCaller.cpp:552-569
 extern "C" int mibc_time_forward(mibc_engine *e, int N, int T_in, float *ms_out) {
     int rc = check_call(e, N, T_in);
     if (rc != MIBC_OK) return rc;
     const int T = mibc_output_steps(e, T_in);
+    rc = overlap_join(e, e->stream);
+    if (rc != MIBC_OK) return rc;
     HIP_OK(e, hipMemsetAsync(e->in_stage, 0, (size_t)N * T_in * 2, e->stream));
     float best = 1e30f;
     hipEvent_t a, b;

@@ -283,7 +283,8 @@ int tx_run_network(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     auto &tx = e->tx;
     const mibc_model_desc &d = e->d;
     const bool prof = e->profile > 0;
-    if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_START], e->stream));
+    if (prof) e->ps ^= 1;
+    if (prof) HIP_OK(e, hipEventRecord(e->ev[e->ps][mibc_engine::EV_START], e->stream));
     // conv1 -> cbuf[0] (with conv2's pad rows)
     if (mibc_launch_conv1_tx(e->stream, in_dev, tx.c1w, tx.c1b, tx.cbuf[0], e->in_ss, N, T_in, tx.ctp[0],
                              tx.convs[0].pad, d.conv_size[0], d.conv_act[0]) != 0)
@@ -316,7 +317,7 @@ int tx_run_network(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
         g.ncols_valid = (cv.cout_pad != cv.cout) ? cv.cout : 0;
         if (mibc_launch_gemm_tn(e->stream, &g) != 0) return fail(e, MIBC_NOT_SUPPORTED, "tx conv gemm shape");
     }
-    if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_CONV], e->stream));
+    if (prof) HIP_OK(e, hipEventRecord(e->ev[e->ps][mibc_engine::EV_CONV], e->stream));
     const int T = tx.T_tok, C = tx.D;
     const long R = (long)N * T;
     for (int l = 0; l < tx.depth; ++l) {
@@ -347,7 +348,7 @@ int tx_run_network(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
     }
     // upsample: [R][C] -> [R][sf*C] == [N][sf*T][C]
     if (gemm(e, tx.x, tx.wup, tx.bup, tx.up, R, tx.sf * C, C, -1) != 0) return fail(e, MIBC_NOT_SUPPORTED, "tx upsample");
-    if (prof) HIP_OK(e, hipEventRecord(e->ev[mibc_engine::EV_LSTM0], e->stream));
+    if (prof) HIP_OK(e, hipEventRecord(e->ev[e->ps][mibc_engine::EV_LSTM0], e->stream));
     e->lstm_out = tx.x;
     HIP_OK(e, hipGetLastError());
     return MIBC_OK;

@@ -201,7 +201,10 @@ int HipCaller::choose_batch_size(int chunk_size, int requested) {
                 "falling back to batch %d\n", m_device, double(m_params.memory_limit_fraction), free_b >> 20, g);
         return g;
     }
-    const long want = (m_desc.tx_d_model > 0) ? 1024 : 256L * g;
+    // the knee: one LSTM workgroup (g rows) on each of the 256 CUs; cluster kernels: one 256-row cluster per lstm_size / 128 CUs
+    // (the quantised wide layers report g = 256 = one cluster, so 256 g would be 8 x too many)
+    const long want = (m_desc.tx_d_model > 0) ? 1024
+                      : (g >= 256 && m_desc.lstm_size >= 512) ? (256L / (m_desc.lstm_size / 128)) * 256L : 256L * g;
     long n = std::min(want, cap);
     if (m_params.run_batchsize_benchmarks || requested < 0) {
         // time the network alone on a short chunk (288 output steps, :497-503) for a descending ladder of batch sizes
@@ -887,7 +890,10 @@ size_t HipModelRunner::batch_size() const {
     const size_t N = rows();
     if (!variable_chunk_sizes()) return N;
     size_t b = size_t(double(N) * double(m_caller->variable_batch_fill()));
-    b = b >= 32 ? b / 32 * 32 : std::max<size_t>(1, b);         // BasecallerNode fills whole 32-row spans (:304, 421-426)
+    // BasecallerNode fills whole 32-row spans and flushes on size only when chunks_size == batch_size * (cs / stride + 2)
+    // exactly (:303-305, 421-426): always a multiple of 32, at least one span (rows() is a multiple of 32 for every LSTM width:
+    // the engine's granularity is 32 or 64)
+    b = std::max<size_t>(32, b / 32 * 32);
     return std::min(b, N);
 }
 

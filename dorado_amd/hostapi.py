@@ -265,7 +265,10 @@ def scaler_kwargs(cfg: ModelConfig) -> dict:
     signal_norm and sample_type."""
     sn = cfg.signal_norm
     return {"strategy": sn.strategy, "quantile": (sn.quantile_a, sn.quantile_b, sn.shift_multiplier, sn.scale_multiplier),
-            "standardisation": (sn.standardise, sn.mean, sn.stdev), "is_rna_model": cfg.sample_type in ("RNA002", "RNA004")}
+            "standardisation": (sn.standardise, sn.mean, sn.stdev),
+            # ScalerNode.cpp:157: m_is_rna_model = (model_type == SampleType::RNA004) — RNA002 reads get no adapter cut and go
+            # through the DNA trim heuristic
+            "is_rna_model": cfg.sample_type == "RNA004"}
 
 
 def scaler_node(cfg: ModelConfig, weights, raw_i16, strategy="quantile", quantile=(0.2, 0.9, 0.51, 0.53),

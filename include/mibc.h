@@ -135,6 +135,12 @@ MIBC_API int mibc_call(mibc_engine *e, const uint16_t *in_host, int N, int T_in,
               int8_t *out_host); /* H2D + forward + decode + D2H, synchronous
                                     (CudaCaller::call_chunks, CudaCaller.cpp:224-271) */
 MIBC_API int mibc_sync(mibc_engine *e);
+/* Opt-in: run the decoder (backward / forward scans, posteriors, beam search) on its own stream with the scores buffer
+ * double-buffered, so that the decoder of one batch (HBM streaming, idle matrix pipes) runs under the network of the next
+ * (matrix pipe / L2 bound, 0.7 TB/s of HBM traffic), and — where a batch is decoded in sub-batches — under the head of the next
+ * sub-batch.  Results are unchanged.  Costs a second scores buffer; per-stage profiling (mibc_get_stage_ms) is not available
+ * while it is on.  Applies to mibc_call_device, mibc_call, mibc_call_async (the variable-chunk calls stay serial). */
+MIBC_API int mibc_set_decode_overlap(mibc_engine *e, int on);
 /* Two-phase form of mibc_call (the overlap CudaCaller gets from its runners' own streams, CudaCaller.cpp:645-719 +
  * decode/CUDADecoder.h:13-15): mibc_call_async enqueues H2D (copy stream) -> network + decode (engine stream) ->
  * D2H (second copy stream) for `slot` (0 or 1) and returns; mibc_call_wait blocks until that slot's output has
@@ -220,6 +226,9 @@ MIBC_API int mibc_svb16_decode(mibc_engine *e, const uint8_t *streams_dev, const
 /* ---- measurement (replaces CudaCaller.cpp:552-569 timing + gpu_profiling.h ranges) ---- */
 MIBC_API int mibc_time_forward(mibc_engine *e, int N, int T_in, float *ms); /* min of 2 runs, like :552-569 */
 MIBC_API int mibc_get_stage_ms(mibc_engine *e, mibc_stage_ms *out);         /* hipEvent times, last call */
+/* ... of the profiled call BEFORE the last one: blocks only until that earlier call has finished, so a caller that has
+ * already enqueued call i can read the stage times of call i - 1 without draining the stream (two event sets alternate) */
+MIBC_API int mibc_get_stage_ms_prev(mibc_engine *e, mibc_stage_ms *out);
 MIBC_API int mibc_set_profile(mibc_engine *e, int level);                   /* 0 off, 1 per-stage events, 2 + roctx ranges around the
                                                                       stages (utils::ScopedProfileRange,
                                                                       torch_utils/gpu_profiling.h:32-99) for rocprofv3

@@ -644,6 +644,18 @@ static int cmp_desc(const void *a, const void *b) {
     return (x < y) - (x > y);
 }
 
+/* What a decode exercised (for the fixtures' descriptions, tests/golden/make_golden_decoder_full.py): blocks, equal-hash stay /
+ * step folds, blocks whose first cut-off kept more than W candidates (bisection), bisections that ran out of guesses, blocks that
+ * ended with a full beam.  Summed over every call since the last orc_beam_stats(out, reset = 1); not thread-safe (the batch
+ * decode below is: it adds under a critical section). */
+static long g_bs_stats[5];
+ORC_API void orc_beam_stats(long *out5, int reset) {
+    for (int i = 0; i < 5; ++i) {
+        if (out5) out5[i] = g_bs_stats[i];
+        if (reset) g_bs_stats[i] = 0;
+    }
+}
+
 ORC_API float orc_beam_search(const float *scores, long block_stride, const float *back_guide,
                               const float *posts, int num_state_bits, int num_blocks,
                               int max_beam_width, float beam_cut, float fixed_stay_score,
@@ -696,6 +708,7 @@ ORC_API float orc_beam_search(const float *scores, long block_stride, const floa
     }
 
     uint8_t present[4096 / 8];
+    long st_merges = 0, st_bisect = 0, st_exhausted = 0, st_full = 0;
     for (int blk = 0; blk < num_blocks; ++blk) {
         const float *bs = scores + (size_t)blk * block_stride;
         const float *bg = back_guide + ((size_t)(blk + 1) << num_state_bits);
@@ -746,6 +759,7 @@ ORC_API float orc_beam_search(const float *scores, long block_stride, const floa
                             c_score[si] = ORC_FLT_LOWEST;
                         }
                         max_score = folded > max_score ? folded : max_score;
+                        ++st_merges;
                     }
                 }
             }
@@ -758,6 +772,7 @@ ORC_API float orc_beam_search(const float *scores, long block_stride, const floa
         for (int i = 0; i < cnt; ++i) ec += (c_score[i] >= cutoff);
         if (ec > W) {
             const int minw = (W * 8) / 10;
+            ++st_bisect;
             float lo = cutoff, hi = max_score;
             int guesses = 1;
             while ((ec > W || ec < minw) && guesses < 10) {
@@ -773,6 +788,7 @@ ORC_API float orc_beam_search(const float *scores, long block_stride, const floa
                 ++guesses;
             }
             if (guesses == 10) {
+                ++st_exhausted;
                 cutoff = hi;
                 ec = 0;
                 for (int i = 0; i < cnt; ++i) ec += (c_score[i] >= cutoff);
@@ -824,6 +840,15 @@ ORC_API float orc_beam_search(const float *scores, long block_stride, const floa
             bv_stay[off + i] = p_stay[i];
         }
         width = ec;
+        st_full += (ec == W);
+    }
+#pragma omp critical(orc_bs_stats)
+    {
+        g_bs_stats[0] += num_blocks;
+        g_bs_stats[1] += st_merges;
+        g_bs_stats[2] += st_bisect;
+        g_bs_stats[3] += st_exhausted;
+        g_bs_stats[4] += st_full;
     }
     const float final_score = p_score[0];
 

@@ -425,3 +425,63 @@ def generate_variable_chunks(num_samples, chunk_size, stride, overlap, use_ref=F
     if n < 0:
         raise ValueError("generate_variable_chunks: invalid arguments")
     return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
+
+
+# ---------------------------------------------------------------- the reference's whole simplex hot path on the CPU (round 5)
+_ref_pipeline = None
+REF_PIPELINE_SO = os.path.join(os.path.dirname(REF_SO), "libdorado_ref_pipeline.so")
+
+
+def have_ref_pipeline() -> bool:
+    return os.path.exists(REF_PIPELINE_SO)
+
+
+def ref_pipeline_lib():
+    """oracle/_ref/libdorado_ref_pipeline.so: ScalerNode.cpp -> BasecallerNode.cpp -> basecall/ModelRunner.cpp (CRFModel / TxModel,
+    CPUDecoder), all compiled in place (oracle/Makefile.ref, oracle/ref_pipeline.cpp)."""
+    global _ref_pipeline
+    if _ref_pipeline is None:
+        import torch  # noqa: F401  (libtorch must be loaded first)
+
+        _ref_pipeline = C.CDLL(REF_PIPELINE_SO)
+        _ref_pipeline.ref_pipeline_last_error.restype = C.c_char_p
+    return _ref_pipeline
+
+
+def ref_pipeline(cfg, weights, raws_i16, calibration, strategy="pa", quantile=(0.2, 0.9, 0.51, 0.53),
+                 standardisation=(False, 0.0, 1.0), is_rna_model=False, flow_cell_product_code="", batch_size=16,
+                 num_runners=4):
+    """Raw int16 reads through the REFERENCE's ScalerNode -> BasecallerNode -> CPU ModelRunner.  calibration: per read (scaling,
+    offset, open_pore_level).  -> list of dict(seq, qstr, moves, scale_pa, shift_pa, num_trimmed_samples,
+    rna_adapter_end_signal_pos, scaled_len)."""
+    raws = [np.ascontiguousarray(r, np.int16) for r in raws_i16]
+    n = len(raws)
+    sig = np.ascontiguousarray(np.concatenate(raws))
+    lens = np.array([r.size for r in raws], np.int64)
+    d = cfg.to_desc()
+    ws, arr = _wptrs(weights)
+    wn = np.array([w.size for w in ws], np.int64)
+    p7 = (C.c_float * 7)(*quantile, float(bool(standardisation[0])), standardisation[1], standardisation[2])
+    cal = np.ascontiguousarray(calibration, np.float32).reshape(n, 3)
+    stride = cfg.conv_stride // cfg.tx.up_scale_factor if cfg.tx is not None else cfg.stride
+    pitch = int(lens.max()) // stride + 16
+    seq = np.zeros((n, pitch), np.uint8)
+    qs = np.zeros((n, pitch), np.uint8)
+    mv = np.zeros((n, pitch), np.uint8)
+    sl, ml, scl = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.int64)
+    f2 = np.zeros((n, 2), np.float32)
+    i2 = np.zeros((n, 2), np.int32)
+    i64p = C.POINTER(C.c_int64)
+    L = ref_pipeline_lib()
+    rc = L.ref_pipeline_run(C.byref(d), arr, wn.ctypes.data_as(i64p), len(ws), C.c_float(cfg.qscale), C.c_float(cfg.qbias),
+                            C.c_int(cfg.chunk_size), C.c_int(cfg.overlap), C.c_int(batch_size), C.c_int(num_runners),
+                            C.c_int(SCALING_STRATEGIES[strategy]), p7, C.c_int(int(is_rna_model)),
+                            sig.ctypes.data_as(_i16p), lens.ctypes.data_as(i64p), C.c_int(n), _fp(cal),
+                            flow_cell_product_code.encode(), C.c_int(pitch), seq.ctypes.data_as(C.c_char_p),
+                            qs.ctypes.data_as(C.c_char_p), mv.ctypes.data_as(_u8p), sl.ctypes.data_as(i64p),
+                            ml.ctypes.data_as(i64p), _fp(f2), i2.ctypes.data_as(C.POINTER(C.c_int)), scl.ctypes.data_as(i64p))
+    if rc != 0:
+        raise RuntimeError(L.ref_pipeline_last_error().decode())
+    return [{"seq": seq[r, :sl[r]].tobytes().decode(), "qstr": qs[r, :sl[r]].tobytes().decode(), "moves": mv[r, :ml[r]].copy(),
+             "scale_pa": float(f2[r, 0]), "shift_pa": float(f2[r, 1]), "num_trimmed_samples": int(i2[r, 0]),
+             "rna_adapter_end_signal_pos": int(i2[r, 1]), "scaled_len": int(scl[r])} for r in range(n)]

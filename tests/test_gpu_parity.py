@@ -115,6 +115,33 @@ def test_decoder_alone_vs_reference_fixture_and_oracle(name, state_len):
     eng.close()
 
 
+@pytest.mark.parametrize("name,state_len", [("dec_full_s4", 4), ("dec_full_s5", 5)])
+def test_decoder_full_length_vs_reference_fixture(name, state_len):
+    """Round 5: FULL-LENGTH chunks — hac's decoder shape (T = 1666, K = 1024, clamped) and sup@v5's
+    (T = 2048, K = 4096, unclamped) — decoded by the device against the COMPILED REFERENCE's outputs directly (not through
+    oracle.c): moves and bases bit-exact, qstring +-1.  The scores (tests/parity_utils.structured_scores, regenerated from the
+    seed, CRC checked) drive thousands of equal-hash folds, > 1000 bisected cut-offs and > 200 full beams per fixture."""
+    import zlib
+    from parity_utils import structured_scores
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    L, n, T, seed = (int(v) for v in g["params"])
+    gain, clip, qsh, qsc = (float(v) for v in g["fparams"])
+    assert L == state_len
+    s16 = structured_scores(L, n, T, seed, gain, clip)
+    assert np.uint32(zlib.crc32(s16.tobytes())) == g["scores_crc"], "regenerated scores differ from the fixture's"
+    cfg = _cfg(128, state_len, 0)
+    cfg.clamp = clip > 0
+    cfg.qscale, cfg.qbias = qsc, qsh
+    eng = capi.Engine(cfg, synth.make_weights(cfg, seed=1))
+    dec = eng.decode(s16)
+    for i, (seq, qs, mv) in enumerate(dec):
+        n_b = int(g["seqlen"][i])
+        assert (mv == g["moves"][i]).all() and seq == g["seq"][i, :n_b].tobytes().decode(), f"chunk {i}: differs from the reference"
+        dq = np.abs(np.frombuffer(qs.encode(), np.uint8).astype(int) - g["qstr"][i, :n_b].astype(int))
+        assert dq.max() <= 1, f"chunk {i}: qstring off by {dq.max()}"
+    eng.close()
+
+
 def test_decoder_of_network_scores_fixture():
     """Scores produced by the REFERENCE network (f32) rounded to f16 -> GPU decoder == oracle(det)."""
     g = np.load(os.path.join(GOLDEN, "net_tiny128_s4.npz"))

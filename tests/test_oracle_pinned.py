@@ -139,6 +139,29 @@ def test_decoder_alone_matches_fixture(golden_dir, name, det):
         assert np.abs(want_q - got_q).max() <= 1
 
 
+@pytest.mark.parametrize("det", [0, 1])
+@pytest.mark.parametrize("name", ["dec_full_s4", "dec_full_s5"])
+def test_decoder_full_length_matches_reference_fixture(golden_dir, name, det):
+    """Round 5: FULL-LENGTH chunks (T = 1666 x 1024 transitions, T = 2048 x 4096) decoded by the compiled reference
+    (tests/golden/make_golden_decoder_full.py) — thousands of equal-hash folds, hundreds of bisected cut-offs and full beams per
+    fixture (beam_stats) — against the C restatement in both arithmetic modes: moves and bases identical, qstring +-1."""
+    import zlib
+    from parity_utils import structured_scores
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    L, n, T, seed = (int(v) for v in g["params"])
+    gain, clip, qsh, qsc = (float(v) for v in g["fparams"])
+    s16 = structured_scores(L, n, T, seed, gain, clip)
+    assert np.uint32(zlib.crc32(s16.tobytes())) == g["scores_crc"], "regenerated scores differ from the fixture's"
+    assert g["beam_stats"][1] > 5000 and g["beam_stats"][2] > 1000 and g["beam_stats"][4] > 200   # folds, bisections, full beams
+    dec = O.decode(s16.astype(np.float32), q_shift=qsh, q_scale=qsc, det=det)
+    for i, (seq, qs, mv) in enumerate(dec):
+        n_b = int(g["seqlen"][i])
+        assert seq == g["seq"][i, :n_b].tobytes().decode()
+        assert (mv == g["moves"][i]).all()
+        dq = np.abs(g["qstr"][i, :n_b].astype(np.int32) - np.frombuffer(qs.encode(), np.uint8).astype(np.int32))
+        assert dq.max() <= 1
+
+
 def test_det_math_accuracy():
     L = O.lib()
     xs = np.concatenate([-np.logspace(-6, 2, 400), [0.0]]).astype(np.float32)

@@ -163,3 +163,11 @@ def test_scaler_parameters_come_from_the_model_config():
         assert (got["signal"].view(np.uint16) == ref["signal"].view(np.uint16)).all()
         assert got["num_trimmed_samples"] == ref["num_trimmed_samples"] and np.float32(got["scale_pa"]) == np.float32(ref["scale_pa"])
         assert (got["num_trimmed_samples"] > 1000) == want_rna          # the RNA model cuts the adapter, the DNA model trims 10
+    # an RNA002 model is NOT an "rna model" for ScalerNode (ScalerNode.cpp:157: only SampleType::RNA004 is): no adapter cut,
+    # the DNA trim heuristic runs.  The two rna002 models are refused by name unless allow_deprecated.
+    import copy
+    c2 = copy.deepcopy(config.load_model_config(os.path.join(base, "rna004_130bps_sup@v3.0.1")))
+    c2.sample_type = "RNA002"
+    assert hostapi.scaler_kwargs(c2)["is_rna_model"] is False
+    c2.sample_type = "RNA004"
+    assert hostapi.scaler_kwargs(c2)["is_rna_model"] is True

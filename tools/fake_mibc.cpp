@@ -204,7 +204,10 @@ int mibc_reserve(mibc_engine *e, int N_max, int T_in) {
     return MIBC_OK;
 }
 int mibc_output_steps(const mibc_engine *e, int T_in) { return e ? T_in / e->stride : 0; }
-int mibc_batch_granularity(const mibc_engine *e) { return (e && e->d.tx_d_model > 0) ? 32 : 64; }
+int mibc_batch_granularity(const mibc_engine *e) {
+    if (e && e->d.tx_d_model > 0) return 32;
+    return (e && e->d.lstm_quant && e->d.lstm_size >= 512) ? 256 : 64;   // engine.hip: quantised wide layers = 256-row clusters
+}
 
 void *mibc_host_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
 void mibc_host_free(void *p) { std::free(p); }

@@ -325,7 +325,25 @@ int main() {
         const auto sc = chosen(0, true, "1419");
         if (sc.first != 640) { std::printf("got %d\n", sc.first); die("auto batch: sweep under a memory cap"); }
         unsetenv("FAKE_MIBC_FREE_MB");
-        std::printf("auto batch size: request / knee / fallback / memory cap / sweep / capped sweep as specified\n");
+        // quantised wide layers (lstm_quant, lstm_size >= 512) run only as 256-row clusters: the granularity is 256, so a
+        // request of 1100 becomes 1280 (not 1120), the knee is one cluster per lstm_size / 128 CUs, and a memory cap is a
+        // whole number of clusters
+        {
+            mibc_model_desc dq = d;
+            dq.lstm_size = 1024;
+            dq.lstm_quant = 1;
+            auto chosen_q = [&](int requested, const char *free_mb) {
+                if (free_mb) setenv("FAKE_MIBC_FREE_MB", free_mb, 1);
+                else unsetenv("FAKE_MIBC_FREE_MB");
+                HipCaller c(dq, &noweights, 0, 0, std::vector<int>{cs}, requested, opts, CallerParams{});
+                return c.batch_size();
+            };
+            if (chosen_q(1100, nullptr) != 1280) die("quantised wide layers: request not rounded to a 256-row cluster");
+            if (chosen_q(0, nullptr) != 32 * 256) die("quantised wide layers: knee");
+            if (chosen_q(0, "1500") != 1280) die("quantised wide layers: memory cap not a whole number of clusters");   // 1529 -> 1280
+            unsetenv("FAKE_MIBC_FREE_MB");
+        }
+        std::printf("auto batch size: request / knee / fallback / memory cap / sweep / capped sweep / quantised clusters as specified\n");
     }
     std::printf("host_caller_sanitize: all checks passed\n");
     return 0;
