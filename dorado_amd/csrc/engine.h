@@ -67,7 +67,8 @@ extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, h
 extern "C" int mibc_lstm_rows_per_wg(int C);
 // lstm_q8.hip: int8 layer (Xin int8 [T][N][C]; Xout int8 or f16) and the f16 -> int8 conversion behind the first layer
 extern "C" int mibc_launch_lstm_layer_q8(hipStream_t s, int C, const int8_t *Xin, void *Xout, const int8_t *Wq,
-                                         const float *biasn, const float *deqn, int T, int N, int reverse, int out_f16);
+                                         const float *biasn, const float *deqn, int T, int N, int reverse, int out_f16,
+                                         const unsigned long long *tmask = nullptr);
 extern "C" int mibc_launch_q8_convert(hipStream_t s, const half_t *in, int8_t *out, size_t n);
 // lstm_cluster.hip: hidden-split cluster kernel (C = 512 / 768 / 1024, N a multiple of 256); 1 = shape not covered
 extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin, half_t *Xout, const half_t *Wt,

@@ -834,7 +834,7 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
             // (nn/LSTMStack.cpp:199-207), layers 1 .. L-1 on the int8 instance of the cluster kernel; the last one writes f16
             // for the head and exchanges an int8 copy of h kept behind its int8 input (the input occupies only the first
             // T N C bytes of its f16-sized buffer)
-            if (e->in_tmask != nullptr) return fail(e, MIBC_NOT_SUPPORTED, "lstm_quant: variable chunks are not supported");
+            // (variable chunks: the masked instances of the same kernels — the reference's default GPU mode is both at once)
             if (N % 256 != 0 || e->cl_flags == nullptr)
                 return fail(e, MIBC_NOT_SUPPORTED, "lstm_quant with lstm_size >= 512 needs batches that are multiples of 256");
             if (l == 0 && !q_all) {
@@ -848,16 +848,17 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
             const bool last = (l + 1 == d.lstm_layers);
             signed char *hx = last ? (signed char *)cur + (size_t)T * N * e->C : nullptr;
             if (mibc_launch_lstm_layer_cl(e->stream, e->C, cur, nxt, (const half_t *)e->lstm_wclq[l], e->lstm_bclq[l], e->lstm_zero,
-                                          e->cl_cstate, e->cl_flags, e->cl_err, T, N, reverse, nullptr, last ? 2 : 1,
+                                          e->cl_cstate, e->cl_flags, e->cl_err, T, N, reverse, e->in_tmask, last ? 2 : 1,
                                           e->lstm_dqcl[l], hx) != 0)
                 return fail(e, MIBC_NOT_SUPPORTED, "lstm_quant: cluster launch");
             e->cl_used = true;
         } else if (d.lstm_quant) {
             // the reference's quantised path: first layer f16 + conversion of its output (LSTMStack.cpp:199-207), then int8
-            if (e->in_tmask != nullptr) return fail(e, MIBC_NOT_SUPPORTED, "lstm_quant: variable chunks are not supported");
             int qrc;
             if (l == 0 && !q_all) {
-                qrc = mibc_launch_lstm_layer(e->stream, e->C, cur, nxt, e->lstm_w[l], e->lstm_w16[l], e->lstm_bn[l], T, N, reverse);
+                qrc = e->in_tmask != nullptr
+                              ? mibc_launch_lstm_layer_masked(e->stream, e->C, cur, nxt, e->lstm_w16[l], e->lstm_bn[l], T, N, reverse, e->in_tmask)
+                              : mibc_launch_lstm_layer(e->stream, e->C, cur, nxt, e->lstm_w[l], e->lstm_w16[l], e->lstm_bn[l], T, N, reverse);
                 // f16 output of layer 0 (nxt) -> int8 into the buffer layer 0 read from (cur): layer 1 then reads `cur`,
                 // so the ping-pong is NOT swapped after this layer
                 if (qrc == 0) qrc = mibc_launch_q8_convert(e->stream, nxt, (int8_t *)cur, (size_t)T * N * e->C);
@@ -866,7 +867,7 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
                 continue;
             }
             qrc = mibc_launch_lstm_layer_q8(e->stream, e->C, (const int8_t *)cur, nxt, e->lstm_wq[l], e->lstm_bn[l], e->lstm_deq[l],
-                                            T, N, reverse, l + 1 == d.lstm_layers ? 1 : 0);
+                                            T, N, reverse, l + 1 == d.lstm_layers ? 1 : 0, e->in_tmask);
             if (qrc != 0) return fail(e, MIBC_NOT_SUPPORTED, "lstm_quant: batch must be a multiple of 64");
         } else if (cl_ok) {
             e->cl_used = true;

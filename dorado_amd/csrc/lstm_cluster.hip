@@ -90,7 +90,6 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
         int resident_clusters,
         const unsigned long long *__restrict__ tmask /* MASKED: [T][N/64] */,
         const float *__restrict__ deqcl /* Q8: [KCL][2][2][4][32] */, signed char *__restrict__ Hx /* Q8 == 2: [T][N][C] int8 h */) {
-    static_assert(!(Q8 && MASKED), "the quantised path has no variable-chunk instance");
     constexpr int KCL = C / 128;
     constexpr int EB = Q8 ? 1 : 2;         // bytes per activation / weight element
     constexpr int KSX = C * EB / 64;       // x-part slabs per pass (a slab row is 64 bytes: 32 halfs or 64 int8)
@@ -548,7 +547,7 @@ extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin
                                          const unsigned long long *tmask, int q8, const float *deqcl, signed char *hx) {
     if (Wt == nullptr || biascl == nullptr || zeros == nullptr || cbuf == nullptr || flags == nullptr || err == nullptr)
         return 1;
-    if (q8 != 0 && (tmask != nullptr || deqcl == nullptr || (q8 == 2 && hx == nullptr) || q8 < 0 || q8 > 2)) return 1;
+    if (q8 != 0 && (deqcl == nullptr || (q8 == 2 && hx == nullptr) || q8 < 0 || q8 > 2)) return 1;
     if ((C != 512 && C != 768 && C != 1024) || N < CL_ROWS || N % CL_ROWS != 0) return 1;
     const int KCL = C / 128;
     const int nclusters = N / CL_ROWS;
@@ -569,11 +568,17 @@ extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin
         hipLaunchKernelGGL((lstm_layer_cl_kernel<CC, M_>), grid, dim3(512), CL_LDS_BYTES, s, Xin, Xout, Wt, \
                            biascl, zeros, cbuf, flags, err, T, N, reverse, cpx, resident, tmask, nullptr, nullptr); \
     } while (0)
-#define CL_LAUNCH_Q8(CC, Q_)                                                                                \
+#define CL_LAUNCH_Q8M(CC, Q_, M_)                                                                           \
     do {                                                                                                    \
-        MIBC_LDS_ATTR_ONCE((lstm_layer_cl_kernel<CC, false, 0, Q_>), CL_LDS_BYTES);                         \
-        hipLaunchKernelGGL((lstm_layer_cl_kernel<CC, false, 0, Q_>), grid, dim3(512), CL_LDS_BYTES, s, Xin, Xout, Wt, \
-                           biascl, zeros, cbuf, flags, err, T, N, reverse, cpx, resident, nullptr, deqcl, hx); \
+        MIBC_LDS_ATTR_ONCE((lstm_layer_cl_kernel<CC, M_, 0, Q_>), CL_LDS_BYTES);                            \
+        hipLaunchKernelGGL((lstm_layer_cl_kernel<CC, M_, 0, Q_>), grid, dim3(512), CL_LDS_BYTES, s, Xin, Xout, Wt, \
+                           biascl, zeros, cbuf, flags, err, T, N, reverse, cpx, resident, tmask, deqcl, hx); \
+    } while (0)
+    // (tmask != nullptr: the masked int8 instances — the reference's default GPU mode, variable chunks over the quantised LSTM)
+#define CL_LAUNCH_Q8(CC, Q_)                                  \
+    do {                                                      \
+        if (tmask != nullptr) CL_LAUNCH_Q8M(CC, Q_, true);    \
+        else CL_LAUNCH_Q8M(CC, Q_, false);                    \
     } while (0)
     if (q8 == 1) {
         switch (C) {
@@ -618,4 +623,5 @@ extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin
     }
 #undef CL_LAUNCH
 #undef CL_LAUNCH_Q8
+#undef CL_LAUNCH_Q8M
 }

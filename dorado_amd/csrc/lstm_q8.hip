@@ -27,14 +27,17 @@ __device__ __forceinline__ int q8_quant(float v) {   // round(127 v), |v| <= 1
 }
 
 // OUT_F16: the last layer hands f16 to the CRF head (Xout f16 [T][N][C]); otherwise Xout is int8 [T][N][C].
-template <int C, int PF, bool OUT_F16>
+// MASKED (variable chunk sizes, round 5 — the reference's default GPU mode is the quantised LSTM WITH variable chunks,
+// basecall/CudaModelRunner.cpp:21-49 over nn/LSTMStack.cpp:127-211): bit r of tmask[t * gridDim.x + blockIdx.x] = "row r of this
+// workgroup is inside a chunk at step t"; outside, h and c are forced to 0 exactly as in lstm_layer_x8_kernel<.., MASKED>.
+template <int C, int PF, bool OUT_F16, bool MASKED = false>
 __global__ __launch_bounds__(512, 2) void lstm_layer_q8_kernel(
         const int8_t *__restrict__ Xin,   // [T][N][C] int8 = round(127 x)
         void *__restrict__ Xout_,
         const int8_t *__restrict__ Wq,    // [C/16][2C/64][4][64][16]: lane (l15, lq): row g C + 16 j + l15, k = 64 ks + 16 lq ..
         const float *__restrict__ biasn,  // [4C]: [(hidden/32)][4][32]  (b_ih + b_hh)
         const float *__restrict__ deqn,   // [4C]: same order, 1 / (127 * row scale)
-        int T, int N, int reverse) {
+        int T, int N, int reverse, const unsigned long long *__restrict__ tmask = nullptr) {
     constexpr int NB = 64;
     constexpr int NT = 512;
     constexpr int HT = C / 16 / 8;    // 16-unit hidden tiles per wave
@@ -99,6 +102,8 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_q8_kernel(
         const int8_t *hprev = (step & 1) ? hbuf1 : hbuf0;
         int8_t *hnext = (step & 1) ? hbuf0 : hbuf1;
 
+        unsigned long long vm = ~0ull;
+        if (MASKED) vm = tmask[(size_t)t * gridDim.x + blockIdx.x];
         int4v xpf[XPF];
         {
             const int8_t *xg = Xin + ((size_t)tn * N + n0) * C;
@@ -155,8 +160,12 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_q8_kernel(
                     const float fg = fast_sigmoid(fmaf((float)acc[1][rt][r], dv[1][r], bv[1][r]));
                     const float gg = fast_tanh(fmaf((float)acc[2][rt][r], dv[2][r], bv[2][r]));
                     const float og = fast_sigmoid(fmaf((float)acc[3][rt][r], dv[3][r], bv[3][r]));
-                    const float c = fmaf(fg, cst[jj][rt][r], ig * gg);
-                    const float hval = og * fast_tanh(c);
+                    float c = fmaf(fg, cst[jj][rt][r], ig * gg);
+                    float hval = og * fast_tanh(c);
+                    if (MASKED && !((vm >> (rt * 16 + l15)) & 1ull)) {
+                        c = 0.0f;
+                        hval = 0.0f;
+                    }
                     cst[jj][rt][r] = c;
                     pk |= (q8_quant(hval) & 0xff) << (8 * r);
                     hv[r] = (half_t)hval;
@@ -223,22 +232,34 @@ static size_t q8_lds_bytes() {
 }
 
 // int8 layer: Xin int8 [T][N][C]; Xout int8 [T][N][C] or (out_f16) f16 [T][N][C].  0 = launched, 1 = shape not covered.
+// tmask != nullptr: the masked (variable chunk sizes) instances.
 extern "C" int mibc_launch_lstm_layer_q8(hipStream_t s, int C, const int8_t *Xin, void *Xout, const int8_t *Wq,
-                                         const float *biasn, const float *deqn, int T, int N, int reverse, int out_f16) {
+                                         const float *biasn, const float *deqn, int T, int N, int reverse, int out_f16,
+                                         const unsigned long long *tmask) {
     if (N % 64 != 0 || Wq == nullptr) return 1;
     dim3 grid(N / 64);
-#define Q8(CC, PF_, O_)                                                                                                  \
+#define Q8(CC, PF_, O_, M_)                                                                                              \
     do {                                                                                                                 \
-        MIBC_LDS_ATTR_ONCE((lstm_layer_q8_kernel<CC, PF_, O_>), (q8_lds_bytes<CC, O_>()));                               \
-        hipLaunchKernelGGL((lstm_layer_q8_kernel<CC, PF_, O_>), grid, dim3(512), (q8_lds_bytes<CC, O_>()), s, Xin, Xout, Wq, \
-                           biasn, deqn, T, N, reverse);                                                                  \
+        MIBC_LDS_ATTR_ONCE((lstm_layer_q8_kernel<CC, PF_, O_, M_>), (q8_lds_bytes<CC, O_>()));                           \
+        hipLaunchKernelGGL((lstm_layer_q8_kernel<CC, PF_, O_, M_>), grid, dim3(512), (q8_lds_bytes<CC, O_>()), s, Xin, Xout, Wq, \
+                           biasn, deqn, T, N, reverse, tmask);                                                           \
         return 0;                                                                                                        \
     } while (0)
+#define Q8M(CC)                                                  \
+    do {                                                         \
+        if (tmask) {                                             \
+            if (out_f16) Q8(CC, 4, true, true);                  \
+            else Q8(CC, 4, false, true);                         \
+        }                                                        \
+        if (out_f16) Q8(CC, 4, true, false);                     \
+        else Q8(CC, 4, false, false);                            \
+    } while (0)
     switch (C) {
-        case 128: if (out_f16) Q8(128, 4, true); else Q8(128, 4, false);
-        case 256: if (out_f16) Q8(256, 4, true); else Q8(256, 4, false);
-        case 384: if (out_f16) Q8(384, 4, true); else Q8(384, 4, false);
+        case 128: Q8M(128);
+        case 256: Q8M(256);
+        case 384: Q8M(384);
         default: return 1;
     }
+#undef Q8M
 #undef Q8
 }

@@ -64,8 +64,10 @@ typedef struct mibc_model_desc {
      * utils::quantize_tensor) and int8 activations — for EVERY layer when the last convolution's activation is tanh (the
      * v4.3 LSTM-CRF models: nn/ConvStack.cpp:72 hands over CUTLASS_TNC_I8), else layers 2..L with the first layer in f16
      * (:73, LSTMStack.cpp:199-207).  LSTM models with
-     * lstm_size 128 / 256 / 384 (any batch) or 512 / 768 / 1024 (batches that are multiples of 256) and >= 2 layers; not
-     * combinable with variable chunks.  0 (default): f16 throughout — the path the parity contract is stated for. */
+     * lstm_size 128 / 256 / 384 (any batch) or 512 / 768 / 1024 (batches that are multiples of 256: mibc_batch_granularity()
+     * reports 256 then) and >= 2 layers; combinable with variable chunks (mibc_*_var: masked instances of the same kernels —
+     * the reference's default GPU mode is both at once, basecall/CudaModelRunner.cpp:21-49).
+     * 0 (default): f16 throughout — the path the parity contract is stated for. */
     int lstm_quant;
 } mibc_model_desc;
 

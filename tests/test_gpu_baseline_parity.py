@@ -273,3 +273,72 @@ def test_quantised_lstm_vs_reference():
     # identity 3787 / 3789
     assert ed_ref[1] <= 0.13 and e_ref[1] <= 0.13, (e_ref, ed_ref)
     assert ct >= 500 and cg / ct >= 0.999, (cg, ct)
+
+
+def test_whole_reads_vs_reference_pipeline():
+    """Round 5 (VERDICT r4 missing 5): WHOLE raw reads, hac@v4.3.0 BASELINE configuration, against the reference's own simplex hot
+    path chained end to end on the CPU — ScalerNode.cpp -> BasecallerNode.cpp (chunk.cpp, stitch.cpp) -> basecall/ModelRunner.cpp
+    (CRFModel f32, CPUDecoder), every stage compiled in place (oracle/ref_pipeline.cpp; fixture tests/golden/pipeline_hac.npz from
+    tests/golden/make_golden_pipeline.py): 32 raw int16 reads (26 of about five chunks + six edge lengths, 150 726 reference bases).
+    Here: raw reads -> host::scaler_node (statistics on the device) -> HipModelRunner::accept_chunk_i16 / mibc_call_async_i16
+    (scaling fused into conv1) -> host node (chunking, stitching).
+      exact:  num_trimmed_samples, read_common.scale / shift (f32), chunk offsets, move-table length, number of chunks;
+      bases:  identity on the bases the reference calls with q >= 20 >= 0.999 (>= 5000 such bases);
+              per-read identity vs the reference, median >= floor - 0.02, floor = median identity of the f16-emulation restatement
+              of the same pipeline vs the reference [0.963 on these synthetic weights, see make_golden_baseline.py]."""
+    import importlib.util
+    import zlib
+    from dorado_amd import hostapi
+    from parity_utils import align_matches
+    spec = importlib.util.spec_from_file_location("make_golden_pipeline", os.path.join(GOLDEN, "make_golden_pipeline.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    g = np.load(os.path.join(GOLDEN, "pipeline_hac.npz"))
+    cfg = config.hac_v43()
+    ws = synth.make_weights(cfg, seed=mk.WEIGHT_SEED)
+    raws, cal = mk.pipeline_reads()
+    assert np.uint32(zlib.crc32(np.concatenate(raws).tobytes())) == g["raw_crc"], "regenerated reads differ from the fixture's"
+    assert (cal == g["calibration"]).all()
+    n = len(raws)
+    ss, ts = [], []
+    for i, (raw, c) in enumerate(zip(raws, cal)):
+        sn = hostapi.scaler_node(cfg, ws, raw, strategy="pa", standardisation=mk.STANDARDISATION, scaling=float(c[0]),
+                                 offset=float(c[1]), open_pore_level=float(c[2]), flow_cell_product_code=mk.FLOW_CELL,
+                                 device="hip:0", want_signal=False)
+        assert sn["num_trimmed_samples"] == int(g["num_trimmed"][i]), i
+        assert sn["n_out"] == int(g["scaled_len"][i]), i
+        assert np.float32(sn["scale_pa"]) == g["scale_shift_pa"][i, 0] and np.float32(sn["shift_pa"]) == g["scale_shift_pa"][i, 1], i
+        ss.append((sn["shift"] + sn["open_pore_adjustment"], sn["scale"]))
+        ts.append(sn["num_trimmed_samples"])
+    got, stats = hostapi.basecall_raw_reads(cfg, ws, raws, np.array(ss, np.float32), ts, device="hip:0", num_runners=2, batch_size=64)
+    so = np.concatenate([[0], np.cumsum(g["seq_len"])])
+    mo = np.concatenate([[0], np.cumsum(g["moves_len"])])
+    fo = np.concatenate([[0], np.cumsum(g["f16_seq_len"])])
+    co = np.concatenate([[0], np.cumsum(g["chunk_counts"])])
+    id_ref, id_floor = [], []
+    conf_ok = conf_n = 0
+    for i, (seq, qs, mv, offs) in enumerate(got):
+        assert offs == g["chunk_offsets"][co[i]:co[i + 1]].tolist(), f"read {i}: chunk offsets"
+        assert len(mv) == int(g["moves_len"][i]), f"read {i}: move table length"
+        assert int(mv.sum()) == len(seq) == len(qs)
+        ref_seq = g["seq"][so[i]:so[i + 1]].tobytes().decode()
+        ref_q = g["qstr"][so[i]:so[i + 1]].astype(int) - 33
+        f16_seq = g["f16_seq"][fo[i]:fo[i + 1]].tobytes().decode()
+        ok, d = align_matches(seq.encode(), ref_seq.encode())
+        id_ref.append(1.0 - d / max(len(seq), len(ref_seq), 1))
+        id_floor.append(identity(f16_seq, ref_seq))
+        conf_ok += int((ok & (ref_q >= 20)).sum())
+        conf_n += int((ref_q >= 20).sum())
+    assert stats["samples_processed"] == int(g["scaled_len"].sum())
+    rep = {"reads": n, "reference_bases": int(g["seq_len"].sum()), "chunks": int(g["chunk_counts"].sum()),
+           "confident_identity": {"qmin": 20, "matched": conf_ok, "confident_ref_bases": conf_n},
+           "identity_vs_reference": {"min": float(np.min(id_ref)), "median": float(np.median(id_ref)), "mean": float(np.mean(id_ref))},
+           "identity_floor_f16_emulation_vs_reference": {"min": float(np.min(id_floor)), "median": float(np.median(id_floor)),
+                                                         "mean": float(np.mean(id_floor))},
+           "exact": "num_trimmed_samples, scale / shift (pA), chunk offsets, move-table lengths"}
+    os.makedirs(DUMP, exist_ok=True)
+    with open(os.path.join(DUMP, "parity_pipeline_hac.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    assert conf_n >= 5000
+    assert conf_ok / conf_n >= 0.999, rep
+    assert np.median(id_ref) >= np.median(id_floor) - 0.02, rep

@@ -55,12 +55,18 @@ def test_quant_rejects_unsupported_shapes():
     cfg.lstm_quant = True
     with pytest.raises(capi.MibcNotSupported):
         capi.Engine(cfg, synth.make_weights(cfg, seed=1))
-    # the wide (cluster) instance needs whole 256-row clusters
+    # the wide (cluster) instance needs whole 256-row clusters: the engine says so through its batch granularity (round 5,
+    # HipCaller::choose_batch_size rounds requests and memory caps to it) and refuses anything else as an argument error
     cfg = config.tiny(512, 5)
     cfg.lstm_quant = True
     eng = capi.Engine(cfg, synth.make_weights(cfg, seed=1))
-    with pytest.raises(capi.MibcNotSupported):
+    assert eng.batch_granularity() == 256
+    with pytest.raises(capi.MibcError):
         eng.forward(synth.make_signal(64, 306, seed=2))
+    eng.close()
+    cfg.lstm_quant = False
+    eng = capi.Engine(cfg, synth.make_weights(cfg, seed=1))
+    assert eng.batch_granularity() == 64
     eng.close()
 
 
