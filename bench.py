@@ -509,6 +509,15 @@ def main():
                     tv = hostapi.bench_through_host_variable(cfg, ws, sigs, lens, nwarm, device=args.host_device or f"hip:{local_rank}",
                                                              num_runners=2, batch_size=n)
                     tv["useful_fill"] = tv["samples_per_s"] / tv["samples_incl_padding_per_s"]
+                    # ... and the SAME reads through the fixed-chunk path (one chunk per batch row, short chunks repeat-padded):
+                    # whether variable chunk sizes pay on this engine is the ratio of the two useful rates
+                    tf = hostapi.bench_through_host_variable(cfg, ws, sigs, lens, nwarm, device=args.host_device or f"hip:{local_rank}",
+                                                             num_runners=2, batch_size=n, variable=False)
+                    tv["same_reads_fixed_chunks"] = {"samples_per_s": tf["samples_per_s"], "seconds": tf["seconds"],
+                                                     "batches": tf["batches"],
+                                                     "samples_incl_padding_per_s": tf["samples_incl_padding_per_s"],
+                                                     "useful_fill": tf["samples_per_s"] / tf["samples_incl_padding_per_s"]}
+                    tv["variable_over_fixed_useful_rate"] = tv["samples_per_s"] / tf["samples_per_s"]
                     tv["what"] = (f"{len(lens) - nwarm} reads, lengths log-normal(median 6000, sigma 0.9) + uniform 300..3000, "
                                   f"{float(lens[nwarm:].mean()):.0f} samples on average, cut by generate_variable_chunks, first-fit "
                                   f"row packing, mibc_call_var_async with two batches in flight; samples_per_s = read samples "

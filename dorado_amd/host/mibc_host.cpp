@@ -1523,10 +1523,23 @@ int mibch_basecall_reads_variable(const mibc_model_desc *desc, const float *cons
 // n_distinct signals) through SimplexBasecaller::basecall_variable — generate_variable_chunks, first-fit row packing,
 // mibc_call_var_async with two batches in flight per device, slicing, stitching.  n_warm reads first (untimed).
 // out8 = {read samples/s, seconds, engine batches, bases, batch rows x chunk size per second, devices, 0, 0}.
+// variable = 0: the SAME read set through the fixed-chunk path (SimplexBasecaller::basecall: generate_chunks, one chunk per batch
+// row, short chunks repeat-padded) — the comparison that says whether variable chunk sizes pay on this engine.
+int mibch_bench_through_host_mixed(const mibc_model_desc *desc, const float *const *weights, int n_weights,
+                                   const char *device_string, int num_runners, int chunk_size, int overlap, int batch_size,
+                                   const mibc_decode_opts *opts, const uint16_t *signals, int n_distinct, int64_t sig_len,
+                                   const int64_t *read_len, int64_t n_warm, int64_t n_reads, int variable, double *out8);
 int mibch_bench_through_host_variable(const mibc_model_desc *desc, const float *const *weights, int n_weights,
                                       const char *device_string, int num_runners, int chunk_size, int overlap, int batch_size,
                                       const mibc_decode_opts *opts, const uint16_t *signals, int n_distinct, int64_t sig_len,
                                       const int64_t *read_len, int64_t n_warm, int64_t n_reads, double *out8) {
+    return mibch_bench_through_host_mixed(desc, weights, n_weights, device_string, num_runners, chunk_size, overlap, batch_size, opts,
+                                          signals, n_distinct, sig_len, read_len, n_warm, n_reads, 1, out8);
+}
+int mibch_bench_through_host_mixed(const mibc_model_desc *desc, const float *const *weights, int n_weights,
+                                   const char *device_string, int num_runners, int chunk_size, int overlap, int batch_size,
+                                   const mibc_decode_opts *opts, const uint16_t *signals, int n_distinct, int64_t sig_len,
+                                   const int64_t *read_len, int64_t n_warm, int64_t n_reads, int variable, double *out8) {
     try {
         auto node = make_node(desc, weights, n_weights, device_string, num_runners, chunk_size, overlap, batch_size, opts);
         auto make_reads = [&](int64_t first, int64_t count) {
@@ -1538,13 +1551,13 @@ int mibch_bench_through_host_variable(const mibc_model_desc *desc, const float *
             }
             return reads;
         };
-        if (n_warm > 0) (void)node->basecall_variable(make_reads(0, n_warm));
+        if (n_warm > 0) (void)(variable ? node->basecall_variable(make_reads(0, n_warm)) : node->basecall(make_reads(0, n_warm)));
         auto reads = make_reads(n_warm, n_reads);
         double total = 0;
         for (auto &r : reads) total += double(r.size());
         auto st0 = node->sample_stats();
         const auto t0 = std::chrono::steady_clock::now();
-        auto called = node->basecall_variable(reads);
+        auto called = variable ? node->basecall_variable(reads) : node->basecall(reads);
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         auto st1 = node->sample_stats();
         size_t bases = 0;
@@ -1558,7 +1571,8 @@ int mibch_bench_through_host_variable(const mibc_model_desc *desc, const float *
         out8[3] = double(bases);
         out8[4] = (st1["samples_incl_padding"] - st0["samples_incl_padding"]) / sec;
         out8[5] = double(ids.size());
-        out8[6] = out8[7] = 0.0;
+        out8[6] = double(variable);
+        out8[7] = 0.0;
         return 0;
     } catch (const std::exception &e) {
         g_herr = e.what();

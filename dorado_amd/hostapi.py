@@ -194,9 +194,10 @@ def bench_through_host(cfg: ModelConfig, weights, reads_f16, n_warm, n_reads, de
 
 
 def bench_through_host_variable(cfg: ModelConfig, weights, signals_f16, read_lens, n_warm, device="hip:0", num_runners=2,
-                                batch_size=0, beam_width=32):
+                                batch_size=0, beam_width=32, variable=True):
     """Throughput of the variable-chunk host path (SimplexBasecaller::basecall_variable -> mibc_call_var_async): read r is
-    the first read_lens[r] samples of signals_f16[r % n_distinct]; the first n_warm reads are untimed.  Returns
+    the first read_lens[r] samples of signals_f16[r % n_distinct]; the first n_warm reads are untimed.  variable=False: the
+    SAME read set through the fixed-chunk path (SimplexBasecaller::basecall).  Returns
     dict(samples_per_s = read samples per second, seconds, batches, bases, samples_incl_padding_per_s, devices)."""
     L = lib()
     d = cfg.to_desc()
@@ -206,10 +207,10 @@ def bench_through_host_variable(cfg: ModelConfig, weights, signals_f16, read_len
     sig = np.ascontiguousarray(signals_f16, np.float16)
     lens = np.ascontiguousarray(np.minimum(np.asarray(read_lens, np.int64), sig.shape[1]))
     out = (C.c_double * 8)()
-    rc = L.mibch_bench_through_host_variable(C.byref(d), arr, len(ws), device.encode(), num_runners, cfg.chunk_size, cfg.overlap,
-                                             batch_size, C.byref(opts), sig.ctypes.data_as(C.c_void_p), int(sig.shape[0]),
-                                             C.c_int64(sig.shape[1]), lens.ctypes.data_as(C.c_void_p), C.c_int64(n_warm),
-                                             C.c_int64(len(lens) - n_warm), out)
+    rc = L.mibch_bench_through_host_mixed(C.byref(d), arr, len(ws), device.encode(), num_runners, cfg.chunk_size, cfg.overlap,
+                                          batch_size, C.byref(opts), sig.ctypes.data_as(C.c_void_p), int(sig.shape[0]),
+                                          C.c_int64(sig.shape[1]), lens.ctypes.data_as(C.c_void_p), C.c_int64(n_warm),
+                                          C.c_int64(len(lens) - n_warm), C.c_int(int(bool(variable))), out)
     if rc != 0:
         raise capi.MibcError(L.mibch_last_error().decode())
     return {"samples_per_s": out[0], "seconds": out[1], "batches": out[2], "bases": out[3],

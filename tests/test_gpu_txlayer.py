@@ -58,3 +58,59 @@ def test_more_rows_than_one_launch_addresses():
     nd, md, rms, amax = _compare(1024 * 1024 + 128 * 5 + 7, 2048, 3)
     assert amax > 0.5
     assert md <= 0.0079 and rms <= 1e-4, (nd, md, rms)
+
+
+def _lcg_stream(seed, n):
+    """The hook's generator (s = s * 1664525 + 1013904223 mod 2^32; value = ((s >> 9) & 0x7fff) / 16384 - 1), vectorised:
+    s_k = a^k s_0 + c (1 + a + ... + a^(k-1)) in wrapping uint32 arithmetic."""
+    import numpy as np
+    a = np.full(n, 1664525, np.uint32)
+    with np.errstate(over="ignore"):
+        ak = np.cumprod(a, dtype=np.uint32)                         # a^1 .. a^n
+        geo = np.cumsum(np.concatenate([[1], ak[:-1]]).astype(np.uint32), dtype=np.uint32)   # 1 + a + ... + a^(k-1)
+        s = ak * np.uint32(seed) + np.uint32(1013904223) * geo
+    return ((s >> np.uint32(9)) & np.uint32(0x7fff)).astype(np.float32) / np.float32(16384.0) - np.float32(1.0), int(s[-1])
+
+
+def test_whole_tail_vs_f64_host_product():
+    """Round 5: the fused layer tail against an INDEPENDENT f64 host evaluation of the reference's
+    arithmetic instead of against its sibling kernels — out = Wo attn + bo; x1 = RMSNorm(out + alpha x) n1 (nn/RMSNorm.cpp:14-18,
+    eps 1e-5; TxModules.cpp:885); t = W1 x1, y | gate = halves (TxModules.cpp:172-175); ff = W2 (silu(gate) y);
+    x2 = RMSNorm(ff + alpha x1) n2 — on the hook's own operands (regenerated here from its LCG; weights and inputs are the f16
+    values the kernel sees, no other rounding in the f64 path).  The kernel stores x1 and the SwiGLU output as f16 and
+    accumulates in f32, so it sits a few f16 ulps from the ideal: max-abs <= 0.03 on |x2| < 16, rms <= 0.003."""
+    import numpy as np
+    R, FF, Cm, mode = 4096, 2048, 512, 3
+    L = capi.dbg_lib()
+    L.mibc_debug_txlayer_compare.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)] + \
+        [C.POINTER(C.c_float)] * 5 + [C.c_void_p, C.c_void_p]
+    nd = C.c_longlong()
+    f = [C.c_float() for _ in range(5)]
+    fused = np.zeros((R, Cm), np.uint16)
+    rc = L.mibc_debug_txlayer_compare(R, FF, mode, 1, C.byref(nd), *[C.byref(v) for v in f], fused.ctypes.data_as(C.c_void_p), None)
+    assert rc == 0
+    got = fused.view(np.float16).astype(np.float64)
+    seed = (4242 + R + 3 * FF + mode) & 0xffffffff
+    sizes = [Cm * Cm, 2 * FF * Cm, Cm * FF, Cm, Cm, Cm, R * Cm, R * Cm]
+    vals, _ = _lcg_stream(seed, sum(sizes))
+    parts = np.split(vals, np.cumsum(sizes)[:-1])
+    h = lambda v: v.astype(np.float16).astype(np.float64)            # what the kernel is handed
+    wo = h(parts[0] * np.float32(0.06)).reshape(Cm, Cm)
+    w1 = h(parts[1] * np.float32(0.06)).reshape(2 * FF, Cm)
+    w2 = h(parts[2] * np.float32(0.03)).reshape(Cm, FF)
+    bo = (parts[3] * np.float32(0.1)).astype(np.float64)
+    n1 = (np.float32(1.0) + np.float32(0.1) * parts[4]).astype(np.float64)
+    n2 = (np.float32(1.0) + np.float32(0.1) * parts[5]).astype(np.float64)
+    attn = h(parts[6]).reshape(R, Cm)
+    x = h(parts[7] * np.float32(0.7)).reshape(R, Cm)
+    alpha = float(np.float32(2.4494897))
+    rms = lambda v, w: v / np.sqrt((v * v).mean(-1, keepdims=True) + 1e-5) * w
+    x1 = rms(attn @ wo.T + bo + alpha * x, n1)
+    t = x1 @ w1.T
+    y, gate = t[:, :FF], t[:, FF:]
+    ffo = (gate / (1.0 + np.exp(-gate)) * y) @ w2.T
+    want = rms(ffo + alpha * x1, n2)
+    d = np.abs(got - want)
+    print(f"fused layer tail vs f64 host product: max {d.max():.5f} rms {np.sqrt((d * d).mean()):.6f} |want| max {np.abs(want).max():.2f}")
+    assert np.abs(want).max() > 0.5
+    assert d.max() <= 0.03 and np.sqrt((d * d).mean()) <= 0.003
