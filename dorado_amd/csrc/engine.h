@@ -46,7 +46,6 @@ struct WsArgs {
     int N, Ns, n0, T;    // head: full batch, sub-batch, first chunk of the sub-batch, steps
     int Tpitch, stride;  // conv3: a2p rows per chunk, conv stride
     int dbg;             // timing ablations (MIBC_WS_DBG); 0 in production
-    int stagger;         // waves NW/2 .. NW-1 start every tile `stagger` x 1024 clocks late (phase offset of the SIMD partners)
 };
 extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mode);
 extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w1, const float *b1,

@@ -510,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_x8dbg_kernel(
         half_t *__restrict__ Xout,        // [T][N][C]
         const half_t *__restrict__ Wf16,  // [C/16][2C/32][4][64][8]
         const float *__restrict__ biasn,  // [4C]: [(hidden/32)][4][32]  (b_ih + b_hh)
-        int T, int N, int reverse, int stagger) {
+        int T, int N, int reverse) {
     constexpr int NB = 64;
     constexpr int NT = 512;
     constexpr int HT = C / 16 / 8;   // 16-unit hidden tiles per wave
@@ -574,10 +574,6 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_x8dbg_kernel(
 #pragma unroll
             for (int p = 0; p < XPF; ++p) xpf[p] = *(const half8_t *)(xg + (size_t)(tid + NT * p) * 8);
         }
-        // round 5 experiment (MIBC_X8_STAGGER): waves 4-7 (the SIMD partners of waves 0-3) start the step late, so that their
-        // gate phases fall into the partners' k-loops instead of coinciding with the partners' gate phases
-        if (wave >= 4)
-            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(8);
 
 #pragma unroll
         for (int jj = 0; jj < HT; ++jj) {
@@ -707,8 +703,7 @@ extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, h
 #ifdef MIBC_DEBUG_KERNELS
     static const int dbg8 = MIBC_ENV_INT("MIBC_LSTM_DBG", 0);
     if (dbg8 && C == 384 && Wf16 != nullptr) {
-        static const int x8stg = MIBC_ENV_INT("MIBC_X8_STAGGER", 0);
-#define X8D(D) case D: hipLaunchKernelGGL((lstm_layer_x8dbg_kernel<384, 4, D>), grid, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse, x8stg); return 0;
+#define X8D(D) case D: hipLaunchKernelGGL((lstm_layer_x8dbg_kernel<384, 4, D>), grid, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse); return 0;
         switch (dbg8) { X8D(1) X8D(2) X8D(4) X8D(7) X8D(8) default: break; }
 #undef X8D
     }

@@ -149,11 +149,6 @@ __global__ __launch_bounds__(NW * 64, 2) void wsgemm_kernel(WsArgs p) {
         const int rows_valid = min(WS_ROWS, ((MODE == 0) ? p.Ns : p.T) - out_base);
         const int tnext = tile + gridDim.x;
         if (tnext < ntiles) tile_fetch(tnext);
-        // Waves w and w + NW/2 share a SIMD.  Started together they run k-loop beside k-loop (matrix pipe shared) and then
-        // epilogue beside epilogue (matrix pipe idle): the phases ADD (head: skeleton 4.8 + k-loop 12.6 + stores 7.6 = 25.0 ms).
-        // Starting the second half of the workgroup late puts one wave's transposition / stores under its partner's MFMAs.
-        if (wave >= NW / 2)
-            for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
 
         const int dbg = p.dbg;
         for (int pass = 0; pass < passes; ++pass) {
@@ -260,11 +255,6 @@ extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mod
     WsArgs adbg = *a;
     if (ws_dbg) {
         adbg.dbg = ws_dbg;
-        a = &adbg;
-    }
-    static const int stg_env = MIBC_ENV_INT("MIBC_WS_STAGGER", -1);
-    if (stg_env >= 0) {
-        adbg.stagger = stg_env;
         a = &adbg;
     }
     static const int nw_env = MIBC_ENV_INT("MIBC_WS_NW", 8);

@@ -246,7 +246,11 @@ def test_packed_chunks_quantised_lstm(C, tanh_conv):
     # a full-length chunk in every row == the fixed-size quantised path (separately compiled unmasked instances)
     Xf = synth.make_signal(N, t_in, seed=19)
     dv = np.abs(eng.forward_var(Xf, [(r, 0, t_in) for r in range(N)]).astype(np.float32) - eng.forward(Xf).astype(np.float32))
-    assert dv.max() <= 0.02, dv.max()
+    # all layers int8 (tanh conv): integer accumulation is exact, the separately compiled masked instances agree to an f16 ulp of
+    # the head; first layer f16 (swish conv): the masked / unmasked f16 instances differ by f16 rounding of single activations,
+    # and one such ulp in front of the int8 conversion flips a round(127 v) step (0.0079) here and there [measured max 0.038]
+    rms_v = float(np.sqrt((dv.astype(np.float64) ** 2).mean()))
+    assert dv.max() <= (0.02 if tanh_conv else 0.12) and rms_v <= 0.01, (dv.max(), rms_v)
     eng.close()
 
 
