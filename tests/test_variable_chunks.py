@@ -255,26 +255,32 @@ def test_packed_chunks_quantised_lstm(C, tanh_conv):
 
 
 @pytest.mark.gpu
-def test_host_layer_variable_chunks_vs_reference_order_of_operations():
+@pytest.mark.parametrize("C,quant", [(128, False), (384, True), (512, True)])
+def test_host_layer_variable_chunks_vs_reference_order_of_operations(C, quant):
     """C++ host layer with variable chunk sizes (SimplexBasecaller::basecall_variable -> mibc_call_var): chunk
     intervals bit-exact vs the oracle, stitched reads == oracle stitch of the per-chunk calls the engine gives
-    for the same chunks packed differently (one chunk per row), and fewer padded samples than fixed chunks."""
-    cfg = config.tiny(128, 4)
-    cfg.lstm_layers = 5
+    for the same chunks packed differently (one chunk per row), and fewer padded samples than fixed chunks.
+    Round 5: also with the quantised LSTM (the reference's default GPU mode is variable chunks over the int8 path): the narrow
+    int8 kernel (C = 384, 64-row granularity) and the int8 cluster kernel (C = 512: the engine reports a 256-row granularity,
+    which the host layer's batch size and row packer follow)."""
+    cfg = config.tiny(C, 4 if C <= 384 else 3)
+    cfg.lstm_layers = 5 if C <= 384 else 3
+    cfg.lstm_quant = quant
     cfg.chunk_size, cfg.overlap = 1200, 120
     cfg.normalise_basecaller_params()
     ws = synth.make_weights(cfg, seed=71)
     lens = [300, 1200, 1201, 2500, 3333, 5000, 799, 4096, 61, 1800]
     reads = [synth.make_signal(1, L, seed=500 + i)[0] for i, L in enumerate(lens)]
-    got, stats = hostapi.basecall_reads(cfg, ws, reads, num_runners=2, batch_size=64, variable_chunks=True)
-    _, stats_fixed = hostapi.basecall_reads(cfg, ws, reads, num_runners=2, batch_size=64)
-    assert stats["samples_processed"] == sum(lens)
     eng = capi.Engine(cfg, ws)
+    N = max(64, eng.batch_granularity())
+    got, stats = hostapi.basecall_reads(cfg, ws, reads, num_runners=2, batch_size=N, variable_chunks=True)
+    _, stats_fixed = hostapi.basecall_reads(cfg, ws, reads, num_runners=2, batch_size=N)
+    assert stats["samples_processed"] == sum(lens)
     st = cfg.stride
     for r, sig in enumerate(reads):
         iv = O.generate_variable_chunks(len(sig), cfg.chunk_size, st, cfg.overlap)
         assert got[r][3] == [b for b, _ in iv]
-        rows, table = np.zeros((64, cfg.chunk_size), np.float16), []
+        rows, table = np.zeros((N, cfg.chunk_size), np.float16), []
         for k, (b, e) in enumerate(iv):
             L = e - b
             P = (L + st - 1) // st * st                                 # BasecallerNode.cpp:408-416 top-up
