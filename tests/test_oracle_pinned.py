@@ -327,3 +327,45 @@ def test_lstm_weight_quantisation_live_against_compiled_reference():
         qr, scr = mod.ref_quantize(w_ih, w_hh)
         assert (sc == scr).all()
         assert (q == qr).all(), int((q != qr).sum())
+
+
+def test_whole_read_composition_vs_reference_pipeline_fixture(golden_dir):
+    """Round 5: tests/golden/pipeline_hac.npz = whole raw reads through the reference's ScalerNode -> BasecallerNode -> CPU
+    ModelRunner compiled in place (oracle/ref_pipeline.cpp).  The oracle's composition of the same path — scaler restatement,
+    generate_chunks, repeat-padding of a short chunk (BasecallerNode.cpp:430-438), f32 network, decoder, stitch — must reproduce
+    its STRUCTURE exactly on the three shortest reads (a sub-chunk read, exactly one chunk, one chunk + 7 samples = two chunks):
+    trim, scale / shift (pA), scaled length, chunk offsets, move-table length, number of bases == number of moves.  The bases
+    themselves are only held to identity >= 0.93: on these random weights f32-vs-f32 noise of 5e-6 rms in the scores (oracle.c
+    vs libtorch summation order; measured at hac size) already flips 1.5 % of the bases — the discriminating base-level checks
+    are the device tests on the reference's confidently called bases (tests/test_gpu_baseline_parity.py)."""
+    import importlib.util
+    from parity_utils import identity
+    spec = importlib.util.spec_from_file_location("make_golden_pipeline", os.path.join(golden_dir, "make_golden_pipeline.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    g = np.load(os.path.join(golden_dir, "pipeline_hac.npz"))
+    cfg = config.hac_v43()
+    ws = synth.make_weights(cfg, seed=mk.WEIGHT_SEED)
+    raws, cal = mk.pipeline_reads()
+    assert np.uint32(zlib.crc32(np.concatenate(raws).tobytes())) == g["raw_crc"]
+    so = np.concatenate([[0], np.cumsum(g["seq_len"])])
+    co = np.concatenate([[0], np.cumsum(g["chunk_counts"])])
+    for i in (26, 27, 28):
+        c = cal[i]
+        sn = O.scaler_node(raws[i], "pa", standardisation=mk.STANDARDISATION, scaling=float(c[0]), offset=float(c[1]),
+                           open_pore_level=float(c[2]), flow_cell_product_code=mk.FLOW_CELL)
+        assert sn["num_trimmed_samples"] == int(g["num_trimmed"][i]) and len(sn["signal"]) == int(g["scaled_len"][i])
+        assert np.float32(sn["scale_pa"]) == g["scale_shift_pa"][i, 0] and np.float32(sn["shift_pa"]) == g["scale_shift_pa"][i, 1]
+        sig = sn["signal"]
+        offs = O.generate_chunks(len(sig), cfg.chunk_size, cfg.stride, cfg.overlap)
+        assert offs == g["chunk_offsets"][co[i]:co[i + 1]].tolist()
+        chunks, sizes = np.zeros((len(offs), cfg.chunk_size), np.float16), []
+        for k, o in enumerate(offs):
+            seg = sig[o:o + cfg.chunk_size]
+            sizes.append(len(seg))
+            chunks[k] = np.resize(seg, cfg.chunk_size) if len(seg) < cfg.chunk_size else seg
+        dec = O.decode(O.forward(cfg, ws, chunks.astype(np.float32)[:, None, :]), q_shift=cfg.qbias, q_scale=cfg.qscale)
+        seq, qs, mv = O.stitch_chunks(offs, sizes, [d[2] for d in dec], [d[0] for d in dec], [d[1] for d in dec], len(sig), cfg.stride)
+        assert len(mv) == int(g["moves_len"][i]) and int(mv.sum()) == len(seq) == len(qs)
+        ref_seq = g["seq"][so[i]:so[i + 1]].tobytes().decode()
+        assert identity(seq, ref_seq) >= 0.93
