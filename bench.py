@@ -280,7 +280,10 @@ def auto_batch(eng, cfg, t_in, device):
     g = eng.batch_granularity()
     if cfg.tx is not None:
         return max(1, min(1024, cap))
-    return max(g, min(256 * g, (cap // g) * g))
+    # the knee (HipCaller::choose_batch_size): one g-row LSTM workgroup per CU; cluster kernels: one 256-row cluster per
+    # lstm_size / 128 CUs (the quantised wide layers report g = 256 = one cluster: 256 g would be 8 x too many rows)
+    knee = (256 // (cfg.lstm_size // 128)) * 256 if (g >= 256 and cfg.lstm_size >= 512) else 256 * g
+    return max(g, min(knee, (cap // g) * g))
 
 
 def run_config(capi, synth, cfg, model_key, device, steps, warmup, batch=0, seed=0xD0AD0, timed_barrier=None,
