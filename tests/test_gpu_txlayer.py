@@ -78,7 +78,8 @@ def test_whole_tail_vs_f64_host_product():
     eps 1e-5; TxModules.cpp:885); t = W1 x1, y | gate = halves (TxModules.cpp:172-175); ff = W2 (silu(gate) y);
     x2 = RMSNorm(ff + alpha x1) n2 — on the hook's own operands (regenerated here from its LCG; weights and inputs are the f16
     values the kernel sees, no other rounding in the f64 path).  The kernel stores x1 and the SwiGLU output as f16 and
-    accumulates in f32, so it sits a few f16 ulps from the ideal: max-abs <= 0.03 on |x2| < 16, rms <= 0.003."""
+    accumulates in f32, so it sits a few f16 ulps from the ideal: max-abs <= 0.008, rms <= 0.001 on |x2| <= 3.6 [measured 0.00243 /
+    0.00031, profiles/r05_c_txlayer_f64.log]."""
     import numpy as np
     R, FF, Cm, mode = 4096, 2048, 512, 3
     L = capi.dbg_lib()
@@ -113,4 +114,4 @@ def test_whole_tail_vs_f64_host_product():
     d = np.abs(got - want)
     print(f"fused layer tail vs f64 host product: max {d.max():.5f} rms {np.sqrt((d * d).mean()):.6f} |want| max {np.abs(want).max():.2f}")
     assert np.abs(want).max() > 0.5
-    assert d.max() <= 0.03 and np.sqrt((d * d).mean()) <= 0.003
+    assert d.max() <= 0.008 and np.sqrt((d * d).mean()) <= 0.001
