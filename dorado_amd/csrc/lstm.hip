@@ -572,7 +572,9 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_x8dbg_kernel(
         {
             const half_t *xg = Xin + ((size_t)tn * N + n0) * C;
 #pragma unroll
-            for (int p = 0; p < XPF; ++p) xpf[p] = *(const half8_t *)(xg + (size_t)(tid + NT * p) * 8);
+            for (int p = 0; p < XPF; ++p)
+                xpf[p] = (DBG & 16) ? __builtin_nontemporal_load((const half8_t *)(xg + (size_t)(tid + NT * p) * 8))   // round 5 A/B: x_t is read once
+                                    : *(const half8_t *)(xg + (size_t)(tid + NT * p) * 8);
         }
 
 #pragma unroll
@@ -645,7 +647,8 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_x8dbg_kernel(
         for (int p = 0; p < XPF; ++p) {
             const int c = tid + NT * p;
             const int row = c / (C / 8), col8 = c % (C / 8);
-            *(half8_t *)(orow + (size_t)c * 8) = *(const half8_t *)(hnext + row * LD + col8 * 8);
+            if (DBG & 32) __builtin_nontemporal_store(*(const half8_t *)(hnext + row * LD + col8 * 8), (half8_t *)(orow + (size_t)c * 8));   // round 5 A/B
+            else *(half8_t *)(orow + (size_t)c * 8) = *(const half8_t *)(hnext + row * LD + col8 * 8);
         }
         __syncthreads();
     }
@@ -704,7 +707,7 @@ extern "C" int mibc_launch_lstm_layer(hipStream_t s, int C, const half_t *Xin, h
     static const int dbg8 = MIBC_ENV_INT("MIBC_LSTM_DBG", 0);
     if (dbg8 && C == 384 && Wf16 != nullptr) {
 #define X8D(D) case D: hipLaunchKernelGGL((lstm_layer_x8dbg_kernel<384, 4, D>), grid, dim3(512), 0, s, Xin, Xout, Wf16, biasn, T, N, reverse); return 0;
-        switch (dbg8) { X8D(1) X8D(2) X8D(4) X8D(7) X8D(8) default: break; }
+        switch (dbg8) { X8D(1) X8D(2) X8D(4) X8D(7) X8D(8) X8D(24) X8D(40) X8D(56) default: break; }
 #undef X8D
     }
     static const int use_x8 = MIBC_ENV_INT("MIBC_LSTM_X8", 1);
