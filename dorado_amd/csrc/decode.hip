@@ -41,19 +41,6 @@ __device__ __forceinline__ float clampf(float v, float c) {
     return (c > 0.0f) ? fminf(fmaxf(v, -c), c) : v;
 }
 
-// NTL (debug build, MIBC_DEC_NT; round 5 A/B): non-temporal loads of the score / guide rows (every row is read once per kernel by
-// one CU) and non-temporal stores of the guides.  Cache policy only: results are unchanged.
-template <bool NTL, typename T>
-__device__ __forceinline__ T dec_ld(const T *p) {
-    if constexpr (NTL) return __builtin_nontemporal_load(p);
-    else return *p;
-}
-template <bool NTL, typename T>
-__device__ __forceinline__ void dec_st(T *p, T v) {
-    if constexpr (NTL) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
-
 // ---------------------------------------------------------------------------------------------
 // k1: backward scan (decode/CPUDecoder.cpp:66-92 + scan :17-38)
 // ---------------------------------------------------------------------------------------------
@@ -107,7 +94,6 @@ __global__ void bwd_scan_kernel(const half_t *__restrict__ scores,  // [N][T][4S
 // (their successor index (s << 2) mod S coincides) and differ only in the score row (fell-off base hi and hi + 2),
 // so the log-sum-exp runs on the packed-f32 pipe for two states at once and the LDS guide reads are halved.
 // Element-wise the arithmetic is the scalar kernel's: bit-identical output.
-template <bool NTL = false>
 __global__ void bwd_scan2_kernel(const half_t *__restrict__ scores,  // [N][T][4S]
                                  float *__restrict__ bwd,            // [N][T+1][S]
                                  int T, int S, float stay, float clampv, VarIdx vi) {
@@ -128,7 +114,7 @@ __global__ void bwd_scan2_kernel(const half_t *__restrict__ scores,  // [N][T][4
     bn[(size_t)T * S + j] = 0.0f;
     bn[(size_t)T * S + j + H] = 0.0f;
     dm_f2 mine = (dm_f2)(0.0f);
-    half8_t row = dec_ld<NTL>((const half8_t *)(sn + (size_t)(T - 1) * K + 8 * j));   // scores of dest states 2j, 2j+1
+    half8_t row = *(const half8_t *)(sn + (size_t)(T - 1) * K + 8 * j);   // scores of dest states 2j, 2j+1
     const int hi = j / Q;                            // fell-off base of state j; state j + S/2 has hi + 2
     const int n0 = (j << 2) & (S - 1);
     const half_t ch = (half_t)((clampv > 0.0f) ? fminf(clampv, 65504.0f) : 65504.0f);
@@ -140,7 +126,7 @@ __global__ void bwd_scan2_kernel(const half_t *__restrict__ scores,  // [N][T][4
         for (int b = 0; b < 4; ++b) *(half2_l *)(scw + b * S + 2 * j) = half2_l{row[b], row[4 + b]};
         __syncthreads();
         if (t > 0) {
-            row = dec_ld<NTL>((const half8_t *)(sn + (size_t)(t - 1) * K + 8 * j));
+            row = *(const half8_t *)(sn + (size_t)(t - 1) * K + 8 * j);
         }
         const float4_t b4 = *(const float4_t *)(beta + p * S + n0);
         const half4_t ma = __builtin_elementwise_min(
@@ -154,8 +140,8 @@ __global__ void bwd_scan2_kernel(const half_t *__restrict__ scores,  // [N][T][4
         mine = v;
         beta[(p ^ 1) * S + j] = v[0];
         beta[(p ^ 1) * S + j + H] = v[1];
-        dec_st<NTL>(bn + (size_t)t * S + j, (float)v[0]);
-        dec_st<NTL>(bn + (size_t)t * S + j + H, (float)v[1]);
+        bn[(size_t)t * S + j] = v[0];
+        bn[(size_t)t * S + j + H] = v[1];
         p ^= 1;
     }
 }
@@ -211,7 +197,7 @@ __device__ __forceinline__ int lanes_below(unsigned long long m, int lane) {
 #define BS_MAXW 32
 #define BS_CAND (5 * BS_MAXW)
 
-template <int S, bool NTL = false>
+template <int S>
 // amdgpu_waves_per_eu(8): the kernel is latency-bound (one wave per chunk, a serial chain per step), so resident waves are its
 // throughput; left alone hipcc takes 86 VGPRs for S = 256 (5 waves per SIMD = 20 chunks per CU); asked for 8 it needs 63 without
 // scratch, and the 5.5 KB LDS arena then sets the limit (29 chunks per CU).  (S = 1024 keeps its 138 registers: LDS-bound at 10.)
@@ -312,9 +298,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
     float rg[GPL];
 #pragma unroll
     for (int i = 0; i < RPL; ++i)
-        if ((i * 64 + lane) * 8 < K) rs[i] = dec_ld<NTL>((const half8_t *)(sn + (i * 64 + lane) * 8));
+        if ((i * 64 + lane) * 8 < K) rs[i] = *(const half8_t *)(sn + (i * 64 + lane) * 8);
 #pragma unroll
-    for (int i = 0; i < GPL; ++i) rg[i] = dec_ld<NTL>(bn + (size_t)S + i * 64 + lane);
+    for (int i = 0; i < GPL; ++i) rg[i] = bn[(size_t)S + i * 64 + lane];
 
     for (int blk = 0; blk < T; ++blk) {
         __syncthreads();  // previous block's LDS reads are complete
@@ -328,9 +314,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
 #pragma unroll
             for (int i = 0; i < RPL; ++i)
                 if ((i * 64 + lane) * 8 < K)
-                    rs[i] = dec_ld<NTL>((const half8_t *)(sn + (size_t)(blk + 1) * K + (i * 64 + lane) * 8));
+                    rs[i] = *(const half8_t *)(sn + (size_t)(blk + 1) * K + (i * 64 + lane) * 8);
 #pragma unroll
-            for (int i = 0; i < GPL; ++i) rg[i] = dec_ld<NTL>(bn + (size_t)(blk + 2) * S + i * 64 + lane);
+            for (int i = 0; i < GPL; ++i) rg[i] = bn[(size_t)(blk + 2) * S + i * 64 + lane];
         }
         const bool active = lane < width;
         const int w4 = width << 2;
@@ -558,7 +544,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
 // ---------------------------------------------------------------------------------------------
 // PAIR: S/2 threads, thread j owns states j and j + S/2 (half the waves per chunk, half the wave reductions,
 // plain arithmetic on the packed-f32 pipe); !PAIR: one state per thread (S = 64).
-template <bool PAIR, bool NTL = false>
+template <bool PAIR>
 __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N][T][4S]
                                   const float *__restrict__ bwd,          // [N][T+1][S]
                                   const uint16_t *__restrict__ path_state,  // [N][T]
@@ -629,8 +615,8 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
         alpha[sid[k]] = 0.0f;
         mine[k] = 0.0f;
         pred[k] = sid[k] >> 2;
-        row[k] = dec_ld<NTL>((const half4_t *)(sn + 4 * sid[k]));
-        bnext[k] = dec_ld<NTL>(bn + (size_t)S + sid[k]);
+        row[k] = *(const half4_t *)(sn + 4 * sid[k]);
+        bnext[k] = bn[(size_t)S + sid[k]];
     }
     int p = 0;
     __syncthreads();
@@ -646,8 +632,8 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
         if (t + 1 < T) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                row[k] = dec_ld<NTL>((const half4_t *)(sn + (size_t)(t + 1) * K + 4 * sid[k]));
-                bnext[k] = dec_ld<NTL>(bn + (size_t)(t + 2) * S + sid[k]);
+                row[k] = *(const half4_t *)(sn + (size_t)(t + 1) * K + 4 * sid[k]);
+                bnext[k] = bn[(size_t)(t + 2) * S + sid[k]];
             }
         }
         const float *a = alpha + p * S;
@@ -796,23 +782,10 @@ extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int 
     const float log_cut = (beam_cut > 0.0f) ? logf(beam_cut) : 3.402823466e+38f;
     const size_t smem1 = (size_t)2 * S * 4 + (size_t)2 * 4 * S * 2;
     static const int k1_pair = MIBC_ENV_INT("MIBC_K1_PAIR", 1);
-#ifdef MIBC_DEBUG_KERNELS
-    static const int dec_nt = MIBC_ENV_INT("MIBC_DEC_NT", 0);   // bit 0: k1, bit 1: k2, bit 2: k3 (S = 256 / 1024 instances)
-    if ((dec_nt & 1) && k1_pair && S >= 128)
-        hipLaunchKernelGGL(bwd_scan2_kernel<true>, dim3(N), dim3(S / 2), smem1, st, scores, bwd, T, S, stay, clampv, vi);
-    else
-#endif
     if (k1_pair && S >= 128)
-        hipLaunchKernelGGL(bwd_scan2_kernel<false>, dim3(N), dim3(S / 2), smem1, st, scores, bwd, T, S, stay, clampv, vi);
+        hipLaunchKernelGGL(bwd_scan2_kernel, dim3(N), dim3(S / 2), smem1, st, scores, bwd, T, S, stay, clampv, vi);
     else
         hipLaunchKernelGGL(bwd_scan_kernel, dim3(N), dim3(S), smem1, st, scores, bwd, T, S, stay, clampv, vi);
-#ifdef MIBC_DEBUG_KERNELS
-    if ((dec_nt & 2) && S == 256) {
-        hipLaunchKernelGGL((beam_search_kernel<256, true>), dim3(N), dim3(64), 0, st, scores, bwd, trace, path_state, moves, T, W, log_cut, stay, clampv, vi);
-    } else if ((dec_nt & 2) && S == 1024) {
-        hipLaunchKernelGGL((beam_search_kernel<1024, true>), dim3(N), dim3(64), 0, st, scores, bwd, trace, path_state, moves, T, W, log_cut, stay, clampv, vi);
-    } else
-#endif
     switch (S) {
         case 64:
             hipLaunchKernelGGL((beam_search_kernel<64>), dim3(N), dim3(64), 0, st, scores, bwd, trace,
@@ -829,12 +802,6 @@ extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int 
     }
     const size_t smem3 = (size_t)(2 * S + 64) * 4 + (size_t)T * 4 + (size_t)T * 2 + (size_t)T + 16;
     static const int k3_pair = MIBC_ENV_INT("MIBC_K3_PAIR", 1);
-#ifdef MIBC_DEBUG_KERNELS
-    if ((dec_nt & 4) && k3_pair && S >= 128)
-        hipLaunchKernelGGL((posts_qual_kernel<true, true>), dim3(N), dim3(S / 2), smem3, st, scores, bwd, path_state, moves,
-                           seq, qstr, prob_tap, T, S, stay, clampv, q_shift, q_scale, vi);
-    else
-#endif
     if (k3_pair && S >= 128)
         hipLaunchKernelGGL(posts_qual_kernel<true>, dim3(N), dim3(S / 2), smem3, st, scores, bwd, path_state, moves,
                            seq, qstr, prob_tap, T, S, stay, clampv, q_shift, q_scale, vi);

@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 model = sys.argv[1] if len(sys.argv) > 1 else "hac"
 batch = {"hac": "16384", "sup": "8192", "sup5": "1024"}[model]
-runs = [("0", "8"), ("1", "24"), ("2", "40"), ("4", "56"), ("7", "8"), ("0", "8")] if model == "hac" else [("0", "0"), ("7", "0"), ("0", "0"), ("7", "0")]
+runs = [("0", "8"), ("0", "56")] * 5 if model == "hac" else [("0", "0")]
 for nt, x8 in runs:
     env = dict(os.environ, MIBC_DEC_NT=nt)
     if x8 != "0":
