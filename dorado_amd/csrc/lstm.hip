@@ -420,9 +420,12 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_x8_kernel(
         if (MASKED) vm = tmask[(size_t)t * gridDim.x + blockIdx.x];
         half8_t xpf[XPF];
         {
+            // non-temporal: x_t is read once and h_t (below) is read by the NEXT launch — kept out of the way, the layer's 21 GB
+            // activation streams no longer push the 2.36 MB weight set out of the XCD's L2 (round 5, same-box A/B over five
+            // alternations: LSTM stack 297.0 -> 293.3 ms, profiles/r05_h_x8_nt_ab.log); cache policy only, results unchanged
             const half_t *xg = Xin + ((size_t)tn * N + n0) * C;
 #pragma unroll
-            for (int p = 0; p < XPF; ++p) xpf[p] = *(const half8_t *)(xg + (size_t)(tid + NT * p) * 8);
+            for (int p = 0; p < XPF; ++p) xpf[p] = __builtin_nontemporal_load((const half8_t *)(xg + (size_t)(tid + NT * p) * 8));
         }
 
 #pragma unroll
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_x8_kernel(
         for (int p = 0; p < XPF; ++p) {
             const int c = tid + NT * p;
             const int row = c / (C / 8), col8 = c % (C / 8);
-            *(half8_t *)(orow + (size_t)c * 8) = *(const half8_t *)(hnext + row * LD + col8 * 8);
+            __builtin_nontemporal_store(*(const half8_t *)(hnext + row * LD + col8 * 8), (half8_t *)(orow + (size_t)c * 8));
         }
         __syncthreads();
     }

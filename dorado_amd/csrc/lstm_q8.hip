@@ -16,6 +16,9 @@
 #include "common.h"
 #include "engine.h"
 
+#ifndef Q8_NT_DEFAULT
+#define Q8_NT_DEFAULT 0
+#endif
 typedef int int4v __attribute__((ext_vector_type(4)));
 typedef float float4q __attribute__((ext_vector_type(4)));
 
@@ -30,7 +33,8 @@ __device__ __forceinline__ int q8_quant(float v) {   // round(127 v), |v| <= 1
 // MASKED (variable chunk sizes, round 5 — the reference's default GPU mode is the quantised LSTM WITH variable chunks,
 // basecall/CudaModelRunner.cpp:21-49 over nn/LSTMStack.cpp:127-211): bit r of tmask[t * gridDim.x + blockIdx.x] = "row r of this
 // workgroup is inside a chunk at step t"; outside, h and c are forced to 0 exactly as in lstm_layer_x8_kernel<.., MASKED>.
-template <int C, int PF, bool OUT_F16, bool MASKED = false>
+// NTX: non-temporal x_t loads and h_t stores (as lstm_layer_x8_kernel, round 5); cache policy only.
+template <int C, int PF, bool OUT_F16, bool MASKED = false, bool NTX = false>
 __global__ __launch_bounds__(512, 2) void lstm_layer_q8_kernel(
         const int8_t *__restrict__ Xin,   // [T][N][C] int8 = round(127 x)
         void *__restrict__ Xout_,
@@ -108,7 +112,8 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_q8_kernel(
         {
             const int8_t *xg = Xin + ((size_t)tn * N + n0) * C;
 #pragma unroll
-            for (int p = 0; p < XPF; ++p) xpf[p] = *(const int4v *)(xg + (size_t)(tid + NT * p) * 16);
+            for (int p = 0; p < XPF; ++p)
+                xpf[p] = NTX ? __builtin_nontemporal_load((const int4v *)(xg + (size_t)(tid + NT * p) * 16)) : *(const int4v *)(xg + (size_t)(tid + NT * p) * 16);
         }
 
 #pragma unroll
@@ -187,7 +192,8 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_q8_kernel(
             for (int p = 0; p < 2 * XPF; ++p) {
                 const int c = tid + NT * p;
                 const int row = c / (C / 8), col8 = c % (C / 8);
-                *(half8_t *)(orow + (size_t)c * 8) = *(const half8_t *)(hout + row * LDH + col8 * 8);
+                if (NTX) __builtin_nontemporal_store(*(const half8_t *)(hout + row * LDH + col8 * 8), (half8_t *)(orow + (size_t)c * 8));
+                else *(half8_t *)(orow + (size_t)c * 8) = *(const half8_t *)(hout + row * LDH + col8 * 8);
             }
         } else {
             int8_t *orow = (int8_t *)Xout_ + ((size_t)t * N + n0) * C;
@@ -195,7 +201,8 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_q8_kernel(
             for (int p = 0; p < XPF; ++p) {
                 const int c = tid + NT * p;
                 const int row = c / (C / 16), col = c % (C / 16);
-                *(int4v *)(orow + (size_t)c * 16) = *(const int4v *)(hnext + row * LDB + col * 16);
+                if (NTX) __builtin_nontemporal_store(*(const int4v *)(hnext + row * LDB + col * 16), (int4v *)(orow + (size_t)c * 16));
+                else *(int4v *)(orow + (size_t)c * 16) = *(const int4v *)(hnext + row * LDB + col * 16);
             }
         }
         __syncthreads();
@@ -238,12 +245,18 @@ extern "C" int mibc_launch_lstm_layer_q8(hipStream_t s, int C, const int8_t *Xin
                                          const unsigned long long *tmask) {
     if (N % 64 != 0 || Wq == nullptr) return 1;
     dim3 grid(N / 64);
-#define Q8(CC, PF_, O_, M_)                                                                                              \
+    static const int q8_nt = MIBC_ENV_INT("MIBC_Q8_NT", Q8_NT_DEFAULT);   // (debug build: A/B switch)
+#define Q8N(CC, PF_, O_, M_, X_)                                                                                         \
     do {                                                                                                                 \
-        MIBC_LDS_ATTR_ONCE((lstm_layer_q8_kernel<CC, PF_, O_, M_>), (q8_lds_bytes<CC, O_>()));                           \
-        hipLaunchKernelGGL((lstm_layer_q8_kernel<CC, PF_, O_, M_>), grid, dim3(512), (q8_lds_bytes<CC, O_>()), s, Xin, Xout, Wq, \
+        MIBC_LDS_ATTR_ONCE((lstm_layer_q8_kernel<CC, PF_, O_, M_, X_>), (q8_lds_bytes<CC, O_>()));                       \
+        hipLaunchKernelGGL((lstm_layer_q8_kernel<CC, PF_, O_, M_, X_>), grid, dim3(512), (q8_lds_bytes<CC, O_>()), s, Xin, Xout, Wq, \
                            biasn, deqn, T, N, reverse, tmask);                                                           \
         return 0;                                                                                                        \
+    } while (0)
+#define Q8(CC, PF_, O_, M_)                                                                                              \
+    do {                                                                                                                 \
+        if (q8_nt) Q8N(CC, PF_, O_, M_, true);                                                                           \
+        else Q8N(CC, PF_, O_, M_, false);                                                                                \
     } while (0)
 #define Q8M(CC)                                                  \
     do {                                                         \
@@ -262,4 +275,5 @@ extern "C" int mibc_launch_lstm_layer_q8(hipStream_t s, int C, const int8_t *Xin
     }
 #undef Q8M
 #undef Q8
+#undef Q8N
 }

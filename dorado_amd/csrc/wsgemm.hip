@@ -98,7 +98,8 @@ __global__ __launch_bounds__(NW * 64, 2) void wsgemm_kernel(WsArgs p) {
             for (int it = 0; it < CH; ++it) {
                 const int c = tid + NT * it;
                 pre[it] = (half8_t)(0);
-                if (c < WS_ROWS * (K / 8) && c / (K / 8) < rows_valid) pre[it] = *(const half8_t *)(src + (size_t)c * 8);
+                if (c < WS_ROWS * (K / 8) && c / (K / 8) < rows_valid)
+                    pre[it] = (p.dbg & 8) ? __builtin_nontemporal_load((const half8_t *)(src + (size_t)c * 8)) : *(const half8_t *)(src + (size_t)c * 8);
             }
         } else {
             const half_t *src = p.A + ((size_t)grp * p.Tpitch + (size_t)p.stride * r0) * 16;
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(NW * 64, 2) void wsgemm_kernel(WsArgs p) {
             for (int it = 0; it < CH; ++it) {
                 const int c = tid + NT * it;
                 pre[it] = (half8_t)(0);
-                if (c < nch && (long)c * 8 + 8 <= avail) pre[it] = *(const half8_t *)(src + (size_t)c * 8);
+                if (c < nch && (long)c * 8 + 8 <= avail)
+                    pre[it] = (p.dbg & 8) ? __builtin_nontemporal_load((const half8_t *)(src + (size_t)c * 8)) : *(const half8_t *)(src + (size_t)c * 8);
             }
         }
     };

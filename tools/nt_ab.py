@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
 """Round 5 experiment (debug library switches; cache policy only, results unchanged): non-temporal loads / stores for data that
-is touched once.  MIBC_DEC_NT bits: 1 = k1 bwd_scan2 (score loads, guide stores), 2 = k2 beam search (score + guide loads),
-4 = k3 posts_qual (score + guide loads).  MIBC_LSTM_DBG: 8 = plain copy of the hac LSTM kernel, 24 = nt x_t loads,
-40 = nt h_t stores, 56 = both.  One child per setting; stage times in ms (HIP events)."""
+is touched once.  MIBC_WS_DBG=8: wsgemm (conv3 / head) activation tile loads non-temporal; MIBC_Q8_NT=1: int8 LSTM kernel, x_t loads
+and h_t stores non-temporal (as adopted for lstm_layer_x8_kernel, profiles/r05_h_x8_nt_ab.log).  One child per setting, alternating;
+stage times in ms (HIP events)."""
 import json
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-model = sys.argv[1] if len(sys.argv) > 1 else "hac"
-batch = {"hac": "16384", "sup": "8192", "sup5": "1024"}[model]
-runs = [("0", "8"), ("0", "56")] * 5 if model == "hac" else [("0", "0")]
-for nt, x8 in runs:
-    env = dict(os.environ, MIBC_DEC_NT=nt)
-    if x8 != "0":
-        env["MIBC_LSTM_DBG"] = x8
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stage_times.py"), "--lib", "dbg", "--model", model, "--batch", batch, "--steps", "3"],
-                       env=env, capture_output=True, text=True, timeout=400)
+
+
+def run(model, batch, quant, env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stage_times.py"), "--lib", "dbg", "--model", model, "--batch", str(batch),
+                        "--steps", "3", "--quant", str(quant)], env=env, capture_output=True, text=True, timeout=400)
     try:
         d = json.loads(r.stdout.strip().splitlines()[-1])
-        print(f"{model} dec_nt {nt} lstm_dbg {x8}: conv {d['conv']} lstm {d['lstm']} {d['lstm_layer']} head {d['head']} decode {d['decode']} total {d['total']}", flush=True)
+        print(f"{model} quant {quant} {env_extra}: conv {d['conv']} lstm {d['lstm']} {d['lstm_layer']} head {d['head']} decode {d['decode']} total {d['total']}", flush=True)
     except Exception:
-        print(f"{model} dec_nt {nt} lstm_dbg {x8}: FAILED {r.stderr[-300:]}", flush=True)
+        print(f"{model} quant {quant} {env_extra}: FAILED {r.stderr[-300:]}", flush=True)
+
+
+for _ in range(4):
+    run("hac", 16384, 0, {"MIBC_WS_DBG": "0"})
+    run("hac", 16384, 0, {"MIBC_WS_DBG": "8"})
+for _ in range(4):
+    run("hac", 16384, 1, {"MIBC_Q8_NT": "0"})
+    run("hac", 16384, 1, {"MIBC_Q8_NT": "1"})
+for _ in range(2):
+    run("sup", 8192, 0, {"MIBC_WS_DBG": "0"})
+    run("sup", 8192, 0, {"MIBC_WS_DBG": "8"})
