@@ -110,10 +110,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LDSP(unsigned char) smem3 = (LDSP(unsigned char))smem;
     const unsigned lds0 = (unsigned)(size_t)smem3;
-    // round 5 A/B (DBG & 8): the token rows (attn, x in; x out) with the non-temporal cache policy (aux = 2), as adopted for the
-    // LSTM kernels' activation streams: 3.2 GB per layer that nobody re-reads in this launch, beside a 6.5 MB weight image that
-    // every CU re-reads from L2 / the Infinity Cache
-    constexpr int TL_AUX_ROWS = (DBG & 8) ? 2 : 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -266,7 +262,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             int vf = voff_frag;
             asm volatile("" : "+v"(vf));
 #pragma unroll
-            for (int ks = 0; ks < 32; ++ks) rf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vf + 32 * ks, soff0, TL_AUX_ROWS);
+            for (int ks = 0; ks < 32; ++ks) rf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vf + 32 * ks, soff0, 0);
         }
         float ss = 0.0f;
         if (!RAW) {
@@ -340,13 +336,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     unsigned f0 = s0[0], f1 = s1[0], f2 = s0[1], f3 = s1[1];
                     tl_u4 f;
                     f[0] = f0; f[1] = f1; f[2] = f2; f[3] = f3;
-                    __builtin_amdgcn_raw_buffer_store_b128(f, rs_x, voff_frag_o + 32 * (2 * c + m), soff0, TL_AUX_ROWS);
+                    __builtin_amdgcn_raw_buffer_store_b128(f, rs_x, voff_frag_o + 32 * (2 * c + m), soff0, 0);
                     if (decltype(to_xf)::value) xf[2 * c + m] = __builtin_bit_cast(half8_t, f);
                     hold[2 * c + m] = f;     // see below: nothing may overwrite a store's data registers before the store is done
                 }
 #else
-                __builtin_amdgcn_raw_buffer_store_b64(ua, rs_x, vq + 64 * c + 32 * m, soff0, TL_AUX_ROWS);
-                __builtin_amdgcn_raw_buffer_store_b64(ub, rs_x, vq + 64 * c + 32 * m + 16, soff0, TL_AUX_ROWS);
+                __builtin_amdgcn_raw_buffer_store_b64(ua, rs_x, vq + 64 * c + 32 * m, soff0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(ub, rs_x, vq + 64 * c + 32 * m + 16, soff0, 0);
                 if (decltype(to_xf)::value) {
                     const auto s0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
@@ -374,7 +370,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("" : "+v"(vf));   // opaque per call: the 32 offsets below stay immediates instead of 32 hoisted registers
 #pragma unroll
         for (int ks = 0; ks < 32; ++ks)
-            xf[ks] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, vf + 32 * ks, soff0, decltype(fresh)::value ? 16 : TL_AUX_ROWS));
+            xf[ks] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, vf + 32 * ks, soff0, decltype(fresh)::value ? 16 : 0));
     };
 
     // After every load_frags: the fragment ring must be back in VGPRs many instructions ahead of the asm MFMAs that read it.
@@ -652,7 +648,6 @@ extern "C" int mibc_launch_tx_layer(hipStream_t s, const half_t *attn, half_t *x
     if (mode == 2 && dbg == 68) TL_LAUNCH_DBG(2, 68);
     if (mode == 3 && dbg == 4) TL_LAUNCH_DBG(3, 4);
     if (mode == 3 && dbg == 64) TL_LAUNCH_DBG(3, 64);
-    if (mode == 3 && dbg == 8) TL_LAUNCH_DBG(3, 8);
     if (dbg != 0) return 1;
     if (mode == 1) { TL_LAUNCH(1); return 0; }
     if (mode == 2) { TL_LAUNCH(2); return 0; }
