@@ -535,6 +535,19 @@ def main():
                                                      "samples_incl_padding_per_s": tf["samples_incl_padding_per_s"],
                                                      "useful_fill": tf["samples_per_s"] / tf["samples_incl_padding_per_s"]}
                     tv["variable_over_fixed_useful_rate"] = tv["samples_per_s"] / tf["samples_per_s"]
+                    # ... and with the opt-in int8 LSTM: variable chunk sizes OVER the quantised LSTM is the reference's default
+                    # GPU mode (basecall/CudaModelRunner.cpp:21-49 + nn/LSTMStack.cpp:127-211); its own tolerance, never `value`
+                    try:
+                        import copy
+                        qcfg = copy.deepcopy(cfg)
+                        qcfg.lstm_quant = True
+                        tq = hostapi.bench_through_host_variable(qcfg, ws, sigs, lens, nwarm, device=args.host_device or f"hip:{local_rank}",
+                                                                 num_runners=2, batch_size=n)
+                        tv["int8_lstm_variable_chunks"] = {"samples_per_s": tq["samples_per_s"], "seconds": tq["seconds"],
+                                                           "batches": tq["batches"],
+                                                           "samples_incl_padding_per_s": tq["samples_incl_padding_per_s"]}
+                    except Exception as ex:
+                        tv["int8_lstm_variable_chunks"] = {"error": repr(ex)}
                     tv["what"] = (f"{len(lens) - nwarm} reads, lengths log-normal(median 6000, sigma 0.9) + uniform 300..3000, "
                                   f"{float(lens[nwarm:].mean()):.0f} samples on average, cut by generate_variable_chunks, first-fit "
                                   f"row packing, mibc_call_var_async with two batches in flight; samples_per_s = read samples "
