@@ -258,7 +258,7 @@ def dominant_kernel(cfg, n):
     if cfg.tx is not None:
         return "transformer encoder stack (per layer: qkv gemm256 + window_attention_v3 + fused out-proj/MLP kernels)", None
     if cfg.lstm_size <= 384 and getattr(cfg, "lstm_quant", False):
-        return "lstm_layer_q8_kernel<%d>" % cfg.lstm_size, "lstm_layer_q8_kernel<%d, 4, false>" % cfg.lstm_size   # the int8 -> int8 instance
+        return "lstm_layer_q8_kernel<%d>" % cfg.lstm_size, "lstm_layer_q8_kernel<%d, 4, false" % cfg.lstm_size   # the int8 -> int8 instance (OUT_F16 = false)
     if getattr(cfg, "lstm_quant", False):
         # (the mangled name of the int8 -> int8 instance: template arguments <C, MASKED = false, DBG = 0, Q8 = 1>)
         return "lstm_layer_cl_kernel<%d, int8>" % cfg.lstm_size, "lstm_layer_cl_kernelILi%dELb0ELi0ELi1E" % cfg.lstm_size
