@@ -45,7 +45,7 @@ struct WsArgs {
     int act;
     int N, Ns, n0, T;    // head: full batch, sub-batch, first chunk of the sub-batch, steps
     int Tpitch, stride;  // conv3: a2p rows per chunk, conv stride
-    int dbg;             // timing ablations (MIBC_WS_DBG); 0 in production
+    int dbg;             // timing ablations (MIBC_WS_DBG: 1 no activation, 2 no stores, 4 no k-loop, 8 non-temporal tile loads); 0 in production
 };
 extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mode);
 extern "C" int mibc_launch_conv12(hipStream_t s, const half_t *x, const float *w1, const float *b1,

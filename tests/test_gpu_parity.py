@@ -281,6 +281,30 @@ def test_transformer_model_vs_oracle(name):
     eng.close()
 
 
+def test_gemm_kernel_choice_depends_on_the_batch_within_an_f16_ulp():
+    """mibc_launch_gemm_tn takes gemm256x (16x16x32 MFMAs) for K = 512 / 1024, Ncols % 256 == 0 and M >= 2048 rows and
+    the 32x32x16 kernels below that — a different f32 summation tree.  With the sup@v5 width a call with ONE 12288-sample chunk
+    (M = 1024 tokens) and a call with TWO (M = 2048) therefore run different GEMM kernels: the same chunk's scores agree to f16
+    rounding of single values [stated: max-abs <= 16 f16 ulps at the largest score magnitude, rms <= 2 ulps], not bit for bit — the
+    recorded batch-size dependence.  Inside one kernel choice rows are independent: chunk 0 of N = 2 and
+    of N = 3 is bit-identical."""
+    cfg = config.sup_v50()
+    cfg.tx.depth = 2
+    ws = synth.make_weights(cfg, seed=61)
+    x16 = synth.make_signal(3, cfg.chunk_size, seed=63)
+    eng = capi.Engine(cfg, ws)
+    s1 = eng.forward(x16[:1])[0].astype(np.float32)
+    s2 = eng.forward(x16[:2])[0].astype(np.float32)
+    s3 = eng.forward(x16[:3])[0].astype(np.float32)
+    eng.close()
+    assert np.array_equal(s2, s3), "same kernel choice (M >= 2048): rows must not depend on the batch"
+    d = np.abs(s1 - s2)
+    ulp = float(np.spacing(np.float16(np.abs(s2).max())))
+    rms = float(np.sqrt((d.astype(np.float64) ** 2).mean()))
+    print(f"N = 1 vs N = 2: max {d.max():.4f} rms {rms:.5f}, f16 ulp at the largest score {ulp:.4f}")
+    assert d.max() <= 16 * ulp and rms <= 2 * ulp, (float(d.max()), rms, ulp)
+
+
 def test_two_phase_calls_equal_synchronous_calls():
     """mibc_call_async / mibc_call_wait with two batches in flight (copies on their own streams beside the other
     batch's kernels) == mibc_call, batch by batch, byte for byte."""
