@@ -197,7 +197,11 @@ __device__ __forceinline__ int lanes_below(unsigned long long m, int lane) {
 #define BS_MAXW 32
 #define BS_CAND (5 * BS_MAXW)
 
-template <int S>
+// HT (round 5): the candidates' sequence hashes are kept BASE-major ([newest base b][beam element e], stays behind them), so that
+// the stay / step merge test — "is there a step with my newest base and my hash" — reads its 32 candidates as eight
+// ds_read_b128 of one row instead of 32 dependent ds_read_b32 in a loop of run-time length (the largest part of the ~450
+// instruction step).  Same matches, same order, same outputs; HT = false is the round 1-4 loop (debug build, MIBC_K2_HT=0).
+template <int S, bool HT = true>
 // amdgpu_waves_per_eu(8): the kernel is latency-bound (one wave per chunk, a serial chain per step), so resident waves are its
 // throughput; left alone hipcc takes 86 VGPRs for S = 256 (5 waves per SIMD = 20 chunks per CU); asked for 8 it needs 63 without
 // scratch, and the 5.5 KB LDS arena then sets the limit (29 chunks per CU).  (S = 1024 keeps its 138 registers: LDS-bound at 10.)
@@ -331,13 +335,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
                 const uint32_t mi = (ns << 2) + (p_state >> (BITS - 2));
                 const float sc = (p_score + clampf((float)sc_row[mi], clampv)) + bg_row[ns];
                 c_score[4 * lane + b] = sc;
-                c_hash[4 * lane + b] = crc32c_bits(p_hash, (uint32_t)b, 2);
+                c_hash[HT ? (b * BS_MAXW + lane) : (4 * lane + b)] = crc32c_bits(p_hash, (uint32_t)b, 2);
                 c_state[4 * lane + b] = (uint16_t)ns;
                 my_max = fmaxf(my_max, sc);
             }
             stay_sc = (p_score + stay) + bg_row[p_state];
             c_score[w4 + lane] = stay_sc;
-            c_hash[w4 + lane] = p_hash;
+            c_hash[HT ? (4 * BS_MAXW + lane) : (w4 + lane)] = p_hash;
             c_state[w4 + lane] = (uint16_t)p_state;
             my_max = fmaxf(my_max, stay_sc);
             tag[4 * lane + 0] = -1;
@@ -352,8 +356,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
         uint32_t mm = 0;
         const int lb = p_state & 3;
         if (active) {
-            for (int e2 = 0; e2 < width; ++e2) {
-                if (c_hash[(e2 << 2) | lb] == p_hash) mm |= (1u << e2);
+            if constexpr (HT) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 *hrow = (const u32x4 *)(c_hash + lb * BS_MAXW);
+#pragma unroll
+                for (int i = 0; i < BS_MAXW / 4; ++i) {
+                    const u32x4 h = hrow[i];
+                    mm |= (h[0] == p_hash ? 1u : 0u) << (4 * i) | (h[1] == p_hash ? 2u : 0u) << (4 * i) |
+                          (h[2] == p_hash ? 4u : 0u) << (4 * i) | (h[3] == p_hash ? 8u : 0u) << (4 * i);
+                }
+                mm &= (width >= 32) ? 0xffffffffu : ((1u << width) - 1u);   // slots >= width hold an earlier block's hashes
+            } else {
+                for (int e2 = 0; e2 < width; ++e2) {
+                    if (c_hash[(e2 << 2) | lb] == p_hash) mm |= (1u << e2);
+                }
             }
         }
         if (__ballot(mm != 0) != 0ull) {
@@ -456,7 +472,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
                     const bool is_stay = slot >= w4;
                     const uint32_t prev = is_stay ? (uint32_t)(slot - w4) : (uint32_t)(slot >> 2);
                     n_score[idx] = cs[g];
-                    n_hash[idx] = c_hash[slot];
+                    n_hash[idx] = c_hash[HT ? (is_stay ? (4 * BS_MAXW + (slot - w4)) : ((slot & 3) * BS_MAXW + (slot >> 2))) : slot];
                     n_meta[idx] = (uint32_t)c_state[slot] | (prev << 16) | ((is_stay ? 1u : 0u) << 24);
                 }
                 base_cnt += __popcll(bal);
@@ -786,6 +802,14 @@ extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int 
         hipLaunchKernelGGL(bwd_scan2_kernel, dim3(N), dim3(S / 2), smem1, st, scores, bwd, T, S, stay, clampv, vi);
     else
         hipLaunchKernelGGL(bwd_scan_kernel, dim3(N), dim3(S), smem1, st, scores, bwd, T, S, stay, clampv, vi);
+#ifdef MIBC_DEBUG_KERNELS
+    static const int k2_ht = MIBC_ENV_INT("MIBC_K2_HT", 1);   // 0: the round 1-4 merge scan (A/B)
+    if (!k2_ht && S == 256) {
+        hipLaunchKernelGGL((beam_search_kernel<256, false>), dim3(N), dim3(64), 0, st, scores, bwd, trace, path_state, moves, T, W, log_cut, stay, clampv, vi);
+    } else if (!k2_ht && S == 1024) {
+        hipLaunchKernelGGL((beam_search_kernel<1024, false>), dim3(N), dim3(64), 0, st, scores, bwd, trace, path_state, moves, T, W, log_cut, stay, clampv, vi);
+    } else
+#endif
     switch (S) {
         case 64:
             hipLaunchKernelGGL((beam_search_kernel<64>), dim3(N), dim3(64), 0, st, scores, bwd, trace,
