@@ -122,7 +122,6 @@ DM_FN dm_f2 dm2_logf(dm_f2 x) {
     return dm2_fma(__builtin_convertvector(e, dm_f2), (dm_f2)(0.693147182464599609375f), r);
 }
 
-#ifdef DM2_LSE5_DEPTH_FIRST   // the round 1-4 form (debug library only: A/B of the schedule; same results)
 DM_FN dm_f2 dm2_lse5(dm_f2 v0, dm_f2 v1, dm_f2 v2, dm_f2 v3, dm_f2 v4) {
     const dm_f2 m = __builtin_elementwise_max(
             __builtin_elementwise_max(__builtin_elementwise_max(v0, v1), __builtin_elementwise_max(v2, v3)), v4);
@@ -133,43 +132,6 @@ DM_FN dm_f2 dm2_lse5(dm_f2 v0, dm_f2 v1, dm_f2 v2, dm_f2 v3, dm_f2 v4) {
     s += dm2_expf(v4 - m);
     return m + dm2_logf(s);
 }
-#else
-// The five exponentials are independent: evaluated BREADTH-first (all five range reductions, then each Horner step for all five)
-// so that dependent v_pk_fma_f32 never stand back to back — hipcc otherwise emits each polynomial depth-first with an s_nop
-// between every two dependent packed operations (28 of the 234 instructions of bwd_scan2_kernel's step, round 5).  Element-wise
-// the operations and the summation order (((e0 + e1) + e2) + e3) + e4 are those of dm2_expf / dm_lse5: bit-identical results.
-DM_FN dm_f2 dm2_lse5(dm_f2 v0, dm_f2 v1, dm_f2 v2, dm_f2 v3, dm_f2 v4) {
-    const dm_f2 m = __builtin_elementwise_max(
-            __builtin_elementwise_max(__builtin_elementwise_max(v0, v1), __builtin_elementwise_max(v2, v3)), v4);
-    dm_f2 x[5] = {v0 - m, v1 - m, v2 - m, v3 - m, v4 - m};
-    dm_f2 n[5], r[5], p[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) x[i] = __builtin_elementwise_max(x[i], (dm_f2)(-86.0f));
-#pragma unroll
-    for (int i = 0; i < 5; ++i) n[i] = __builtin_elementwise_rint(x[i] * (dm_f2)(1.44269504088896341f));
-#pragma unroll
-    for (int i = 0; i < 5; ++i) r[i] = dm2_fma(n[i], (dm_f2)(-0.693147182464599609375f), x[i]);
-#pragma unroll
-    for (int i = 0; i < 5; ++i) p[i] = dm2_fma((dm_f2)(1.9875691500e-4f), r[i], (dm_f2)(1.3981999507e-3f));
-    const float cs[6] = {8.3334519073e-3f, 4.1665795894e-2f, 1.6666665459e-1f, 5.0000001201e-1f, 1.0f, 1.0f};
-#pragma unroll
-    for (int c = 0; c < 6; ++c)
-#pragma unroll
-        for (int i = 0; i < 5; ++i) p[i] = dm2_fma(p[i], r[i], (dm_f2)(cs[c]));
-    dm_f2 e[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const dm_i2 ni = __builtin_convertvector(n[i], dm_i2);
-        e[i] = __builtin_bit_cast(dm_f2, __builtin_bit_cast(dm_u2, p[i]) + (__builtin_bit_cast(dm_u2, ni) << 23));
-    }
-    dm_f2 s = e[0];
-    s += e[1];
-    s += e[2];
-    s += e[3];
-    s += e[4];
-    return m + dm2_logf(s);
-}
-#endif
 #endif
 
 // decode/beam_search.cpp:42-45
