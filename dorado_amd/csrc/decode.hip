@@ -555,6 +555,398 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
 }
 
 // ---------------------------------------------------------------------------------------------
+// k2, 64-lane form (round 5).  The step of beam_search_kernel is bound by VALU issue, not by latency or HBM: ~410 vector
+// instructions x 4 cycles = the 1600 cycles per step and SIMD that 16384 chunks x 1666 steps in 20.4 ms come to.  Its beam
+// of <= 32 elements leaves half of the wave idle in the two largest parts, so here
+//   * lane (e, h) = (lane & 31, lane >> 5) holds beam element e in BOTH halves; half h expands the steps with newest base
+//     2h and 2h + 1 and tests its stay against 16 of the 32 candidates of the merge row; the halves exchange their 16-bit
+//     masks with one v_permlane32_swap;
+//   * a match bit costs v_cmp + v_addc (carry-in = the compare) instead of v_cmp + v_cndmask + shift / or;
+//   * candidates live in FIXED slots (steps 4e + b, stays 128 + e) with their trace word (state | prev << 16 | stay << 24)
+//     written at expansion, so the compaction is ballot + v_mbcnt + three copies (order of the kept candidates = the
+//     reference's: steps in slot order, then stays);
+//   * the wave maximum is six v_max_f32_dpp.
+// Same candidates, same matches, same order, same arithmetic: outputs are bit-identical to beam_search_kernel.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    // (s_nop 1: a VGPR written by a VALU instruction is read through DPP no sooner than two wait states later)
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// m = 2 m + (h == q) for four candidates, h3 first: the compare's lane mask is the carry-in of the add.  gfx950 wants two wait
+// states between a VALU write of an SGPR pair and a VALU read of it as a mask, so the four compares go first (the trailing
+// s_nop 1: the result may be read by a v_permlane32_swap, which has the same rule for VGPRs).
+#define BS_MATCH4(m, h3, h2, h1, h0, q)                                                                              \
+    {                                                                                                                \
+        unsigned long long c0_, c1_, c2_, c3_;                                                                       \
+        asm("v_cmp_eq_u32_e64 %1, %5, %9\n\t"                                                                        \
+            "v_cmp_eq_u32_e64 %2, %6, %9\n\t"                                                                        \
+            "v_cmp_eq_u32_e64 %3, %7, %9\n\t"                                                                        \
+            "v_cmp_eq_u32_e64 %4, %8, %9\n\t"                                                                        \
+            "v_addc_co_u32_e64 %0, %1, %0, %0, %1\n\t"                                                               \
+            "v_addc_co_u32_e64 %0, %2, %0, %0, %2\n\t"                                                               \
+            "v_addc_co_u32_e64 %0, %3, %0, %0, %3\n\t"                                                               \
+            "v_addc_co_u32_e64 %0, %4, %0, %0, %4\n\t"                                                               \
+            "s_nop 1"                                                                                                \
+            : "+v"(m), "=&s"(c0_), "=&s"(c1_), "=&s"(c2_), "=&s"(c3_)                                                \
+            : "v"(h3), "v"(h2), "v"(h1), "v"(h0), "v"(q));                                                           \
+    }
+
+template <int S>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void beam_search64_kernel(
+        const half_t *__restrict__ scores,   // [N][T][4S]
+        const float *__restrict__ bwd,       // [N][T+1][S]
+        uint32_t *__restrict__ trace,        // [N][T+1][W]  state | prev<<16 | stay<<24
+        uint16_t *__restrict__ path_state,   // [N][T]  full k-mer state per block
+        int8_t *__restrict__ moves,          // [N][T]
+        int T, int W, float log_cut, float stay, float clampv, VarIdx vi) {
+    constexpr int K = 4 * S;
+    constexpr int BITS = (S == 64) ? 6 : (S == 256) ? 8 : (S == 1024) ? 10 : 12;
+    constexpr int RPL = (K / 64 / 8) > 0 ? (K / 64 / 8) : 1;  // half8 loads per lane per score row
+    constexpr int GPL = S / 64;      // floats per lane for one guide row
+    constexpr int STAY0 = 4 * BS_MAXW;                   // first stay slot
+    constexpr int A_SC = 0;                              // half_t sc_row[K]
+    constexpr int A_BG = A_SC + K * 2;                   // float bg_row[S]
+    constexpr int A_CS = A_BG + S * 4;                   // float c_score[BS_CAND]     steps 4e + b, stays STAY0 + e
+    constexpr int A_CH = A_CS + BS_CAND * 4;             // uint32 c_hash[BS_CAND]     steps b * 32 + e (base-major), stays STAY0 + e
+    constexpr int A_CM = A_CH + BS_CAND * 4;             // uint32 c_meta[BS_CAND]     as c_score
+    constexpr int A_TG = A_CM + BS_CAND * 4;             // int tag[4W]
+    constexpr int A_NS = A_TG + 4 * BS_MAXW * 4;         // float n_score[W]
+    constexpr int A_NH = A_NS + BS_MAXW * 4;             // uint32 n_hash[W]
+    constexpr int A_NM = A_NH + BS_MAXW * 4;             // uint32 n_meta[W]
+    constexpr int A_END = A_NM + BS_MAXW * 4;
+    constexpr int TB_ROWS = 32;
+    constexpr int A_TB_END = TB_ROWS * BS_MAXW * 4 + TB_ROWS * 2 + TB_ROWS;
+    constexpr int ARENA = (A_END > A_TB_END ? A_END : A_TB_END);
+    __shared__ __attribute__((aligned(16))) unsigned char arena[(ARENA + 15) / 16 * 16];
+    half_t *sc_row = (half_t *)(arena + A_SC);
+    float *bg_row = (float *)(arena + A_BG);
+    float *c_score = (float *)(arena + A_CS);
+    uint32_t *c_hash = (uint32_t *)(arena + A_CH);
+    uint32_t *c_meta = (uint32_t *)(arena + A_CM);
+    int *tag = (int *)(arena + A_TG);
+    float *n_score = (float *)(arena + A_NS);
+    uint32_t *n_hash = (uint32_t *)(arena + A_NH);
+    uint32_t *n_meta = (uint32_t *)(arena + A_NM);
+    uint32_t *tb_tile = (uint32_t *)arena;                                   // [TB_ROWS][W]
+    uint16_t *tb_state = (uint16_t *)(arena + TB_ROWS * BS_MAXW * 4);        // [TB_ROWS]
+    int8_t *tb_move = (int8_t *)(arena + TB_ROWS * BS_MAXW * 4 + TB_ROWS * 2);  // [TB_ROWS]
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+    const int n = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int e = lane & 31, hf = lane >> 5;
+    VAR_SETUP(T)
+    const half_t *sn = scores + so * K;
+    const float *bn = bwd + bo * S;
+    uint32_t *tr = trace + bo * W;
+    const uint32_t mask = S - 1;
+
+    // ---- seed (beam_search.cpp:165-198): threshold = W-th largest back-guide at t = 0 ----
+    float g0[GPL];
+#pragma unroll
+    for (int i = 0; i < GPL; ++i) g0[i] = bn[i * 64 + lane];
+    uint32_t thr_key = 0;  // lowest
+    if (W < S) {
+        // radix select: largest key with count(key >= thr) >= W
+        uint32_t k = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = k | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < GPL; ++i) cnt += __popcll(__ballot(f2key(g0[i]) >= cand));
+            if (cnt >= W) k = cand;
+        }
+        thr_key = k;
+    }
+    int width = 0;
+    {
+        int base_cnt = 0;
+#pragma unroll
+        for (int i = 0; i < GPL; ++i) {
+            const bool keep = f2key(g0[i]) >= thr_key;
+            const unsigned long long bal = __ballot(keep);
+            const int idx = base_cnt + lanes_below(bal, lane);
+            if (keep && idx < W) {
+                const uint32_t st = i * 64 + lane;
+                n_hash[idx] = crc32c_bits(0x12345678u, st, 32);
+                n_meta[idx] = st;
+                n_score[idx] = 0.0f;
+            }
+            base_cnt += __popcll(bal);
+        }
+        width = base_cnt < W ? base_cnt : W;
+    }
+    __syncthreads();
+    // beam element e in both halves of the wave (slots >= width: stale values, never used unmasked)
+    uint32_t p_hash = n_hash[e], p_state = n_meta[e] & 0xffffu;
+    float p_score = (e < width) ? n_score[e] : 0.0f;
+
+    // prefetch row 0 of scores and row 1 of guides
+    half8_t rs[RPL];
+    float rg[GPL];
+#pragma unroll
+    for (int i = 0; i < RPL; ++i)
+        if ((i * 64 + lane) * 8 < K) rs[i] = *(const half8_t *)(sn + (i * 64 + lane) * 8);
+#pragma unroll
+    for (int i = 0; i < GPL; ++i) rg[i] = bn[(size_t)S + i * 64 + lane];
+
+    // slot -> hash index of this lane's three compaction slots (steps are base-major)
+    const int hidx0 = (lane & 3) * BS_MAXW + (lane >> 2), hidx1 = hidx0 + 16;
+    const uint32_t prev16 = (uint32_t)e << 16;
+
+    for (int blk = 0; blk < T; ++blk) {
+        __syncthreads();  // previous block's LDS reads are complete
+#pragma unroll
+        for (int i = 0; i < RPL; ++i)
+            if ((i * 64 + lane) * 8 < K) *(half8_t *)(sc_row + (i * 64 + lane) * 8) = rs[i];
+#pragma unroll
+        for (int i = 0; i < GPL; ++i) bg_row[i * 64 + lane] = rg[i];
+        __syncthreads();
+        if (blk + 1 < T) {
+#pragma unroll
+            for (int i = 0; i < RPL; ++i)
+                if ((i * 64 + lane) * 8 < K)
+                    rs[i] = *(const half8_t *)(sn + (size_t)(blk + 1) * K + (i * 64 + lane) * 8);
+#pragma unroll
+            for (int i = 0; i < GPL; ++i) rg[i] = bn[(size_t)(blk + 2) * S + i * 64 + lane];
+        }
+        const bool act = e < width;
+        const int w4 = width << 2;
+        float my_max = FLT_LOWEST;
+        float stay_sc = FLT_LOWEST;
+        // ---- expand: steps at slot 4e+b (beam_search.cpp:236-260), stay at STAY0+e (:262-271); half hf takes b = 2hf, 2hf+1 ----
+        if (act) {
+            const uint32_t b0 = 2u * (uint32_t)hf;
+            const uint32_t ns0 = ((p_state << 2) & mask) | b0;
+            const uint32_t mi0 = (ns0 << 2) + (p_state >> (BITS - 2));
+            const f32x2 bg = *(const f32x2 *)(bg_row + ns0);
+            const float sc0 = (p_score + clampf((float)sc_row[mi0], clampv)) + bg[0];
+            const float sc1 = (p_score + clampf((float)sc_row[mi0 + 4], clampv)) + bg[1];
+            *(f32x2 *)(c_score + 4 * e + b0) = f32x2{sc0, sc1};
+            c_hash[b0 * BS_MAXW + e] = crc32c_bits(p_hash, b0, 2);
+            c_hash[(b0 + 1u) * BS_MAXW + e] = crc32c_bits(p_hash, b0 + 1u, 2);
+            *(u32x2 *)(c_meta + 4 * e + b0) = u32x2{ns0 | prev16, ns0 | 1u | prev16};
+            *(u32x2 *)(tag + 4 * e + b0) = u32x2{0xffffffffu, 0xffffffffu};
+            my_max = fmaxf(sc0, sc1);
+            if (hf == 0) {
+                stay_sc = (p_score + stay) + bg_row[p_state];
+                c_score[STAY0 + e] = stay_sc;
+                c_hash[STAY0 + e] = p_hash;
+                c_meta[STAY0 + e] = p_state | prev16 | (1u << 24);
+                my_max = fmaxf(my_max, stay_sc);
+            }
+        }
+        __syncthreads();
+        // ---- merge stays with equal-hash steps (beam_search.cpp:273-305).  The reference's 4096-bit presence filter has
+        //      no false negatives, so "compare against every step with the same newest base" is the same set of matches;
+        //      half hf tests candidates 16 hf .. 16 hf + 15 of that row. ----
+        const int lb = p_state & 3;
+        uint32_t mm;
+        {
+            const u32x4 *hrow = (const u32x4 *)(c_hash + lb * BS_MAXW + 16 * hf);
+            const u32x4 q0 = hrow[0], q1 = hrow[1], q2 = hrow[2], q3 = hrow[3];
+            uint32_t m16 = 0;
+            BS_MATCH4(m16, q3[3], q3[2], q3[1], q3[0], p_hash)
+            BS_MATCH4(m16, q2[3], q2[2], q2[1], q2[0], p_hash)
+            BS_MATCH4(m16, q1[3], q1[2], q1[1], q1[0], p_hash)
+            BS_MATCH4(m16, q0[3], q0[2], q0[1], q0[0], p_hash)
+            // lower half: own 16 bits | upper half's << 16
+            const auto sw = __builtin_amdgcn_permlane32_swap(m16, m16, false, false);
+            mm = sw[0] | (sw[1] << 16);
+            mm &= (width >= 32) ? 0xffffffffu : ((1u << width) - 1u);   // slots >= width hold an earlier block's hashes
+            if (!(lane < width)) mm = 0;                                 // one lane per stay does the folding
+        }
+        if (__ballot(mm != 0) != 0ull) {
+            const int tgt = (mm != 0) ? ((__ffs(mm) - 1) * 4 + lb) : 0;
+            if (mm != 0) tag[tgt] = lane;
+            __syncthreads();
+            const bool clash = (mm != 0) && ((__popc(mm) > 1) || (tag[tgt] != lane));
+            if (__ballot(clash) == 0ull) {
+                // common case: every stay folds with at most one step and no step is shared
+                if (mm != 0) {
+                    const float a = stay_sc, b = c_score[tgt];
+                    const float folded = dm_log_sum_exp2(a, b);
+                    if (a > b) {
+                        c_score[STAY0 + lane] = folded;
+                        c_score[tgt] = FLT_LOWEST;
+                    } else {
+                        c_score[tgt] = folded;
+                        c_score[STAY0 + lane] = FLT_LOWEST;
+                    }
+                    my_max = fmaxf(my_max, folded);
+                }
+            } else {
+                // rare (hash collision): replay the reference's sequential order exactly
+                volatile float *vs = c_score;
+                for (int e1 = 0; e1 < width; ++e1) {
+                    uint32_t m = __shfl(mm, e1, 64);
+                    const int elb = __shfl(lb, e1, 64);
+                    while (m) {
+                        const int e2 = __ffs(m) - 1;
+                        m &= m - 1;
+                        const int si = STAY0 + e1, ti = (e2 << 2) | elb;
+                        const float a = vs[si], b = vs[ti];
+                        const float folded = dm_log_sum_exp2(a, b);
+                        if (lane == 0) {
+                            if (a > b) {
+                                vs[si] = folded;
+                                vs[ti] = FLT_LOWEST;
+                            } else {
+                                vs[ti] = folded;
+                                vs[si] = FLT_LOWEST;
+                            }
+                        }
+                        my_max = fmaxf(my_max, folded);
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const float max_score = wave_max_dpp(my_max);
+
+        // ---- cut-off (beam_search.cpp:310-396): slots lane, 64 + lane (steps) and STAY0 + lane (stays).  Which of a lane's
+        //      three slots hold candidates is a uniform lane mask (vm*), so a count is three v_cmp into SGPR pairs + SALU ----
+        const unsigned long long vm0 = (w4 >= 64) ? ~0ull : ((1ull << w4) - 1ull);
+        const unsigned long long vm1 = (w4 >= 128) ? ~0ull : ((w4 > 64) ? ((1ull << (w4 - 64)) - 1ull) : 0ull);
+        const unsigned long long vm2 = (1ull << width) - 1ull;            // width <= 32
+        const float cs0 = c_score[lane], cs1 = c_score[64 + lane], cs2 = c_score[STAY0 + lane];   // (unmasked slots: stale, in-arena)
+        float cutoff = max_score - log_cut;
+        unsigned long long k0, k1, k2;      // candidates >= cutoff
+        auto count_ge = [&](float c) {
+            k0 = __builtin_amdgcn_ballot_w64(cs0 >= c) & vm0;
+            k1 = __builtin_amdgcn_ballot_w64(cs1 >= c) & vm1;
+            k2 = __builtin_amdgcn_ballot_w64(cs2 >= c) & vm2;
+            return __popcll(k0) + __popcll(k1) + __popcll(k2);
+        };
+        int ec = count_ge(cutoff);
+        if (ec > W) {
+            const int minw = (W * 8) / 10;
+            float lo = cutoff, hi = max_score;
+            int guesses = 1;
+            while ((ec > W || ec < minw) && guesses < 10) {
+                // (the reference halves towards hi or towards lo: the same sum either way round)
+                if (ec > W) lo = cutoff;
+                else hi = cutoff;
+                cutoff = (lo + hi) / 2.0f;
+                ec = count_ge(cutoff);
+                ++guesses;
+            }
+            if (guesses == 10) {
+                cutoff = hi;
+                ec = count_ge(cutoff);
+            }
+            if (ec > W) ec = W;
+        }
+        // ---- compaction in slot order, first W (beam_search.cpp:398-409) ----
+        {
+            const int i0 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(k0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)k0, 0u));
+            if (__builtin_amdgcn_inverse_ballot_w64(k0) && i0 < W) {
+                n_score[i0] = cs0;
+                n_hash[i0] = c_hash[hidx0];
+                n_meta[i0] = c_meta[lane];
+            }
+            const uint32_t b1 = (uint32_t)__popcll(k0);
+            const int i1 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(k1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)k1, b1));
+            if (__builtin_amdgcn_inverse_ballot_w64(k1) && i1 < W) {
+                n_score[i1] = cs1;
+                n_hash[i1] = c_hash[hidx1];
+                n_meta[i1] = c_meta[64 + lane];
+            }
+            const uint32_t b2 = b1 + (uint32_t)__popcll(k1);
+            const int i2 = (int)__builtin_amdgcn_mbcnt_lo((uint32_t)k2, b2);     // k2 has no bit above 31
+            if (__builtin_amdgcn_inverse_ballot_w64(k2) && i2 < W) {
+                n_score[i2] = cs2;
+                n_hash[i2] = c_hash[STAY0 + lane];
+                n_meta[i2] = c_meta[STAY0 + lane];
+            }
+        }
+        __syncthreads();
+        uint32_t meta = n_meta[e];
+        p_hash = n_hash[e];
+        p_state = meta & 0xffffu;
+        p_score = (e < ec) ? n_score[e] : FLT_LOWEST;
+        // ---- last block: best element to slot 0 (beam_search.cpp:413-424; strict >, first) ----
+        if (blk == T - 1) {
+            float best = (lane < ec) ? p_score : FLT_LOWEST;
+            const float bmax = wave_max(best);
+            const unsigned long long who = __ballot((lane < ec) && (p_score == bmax));
+            int bi = (who != 0ull) ? (__ffsll((long long)who) - 1) : 0;
+            if (!(bmax > FLT_LOWEST)) bi = 0;
+            const float s0 = __shfl(p_score, 0, 64), sb = __shfl(p_score, bi, 64);
+            const uint32_t h0 = __shfl(p_hash, 0, 64), hb = __shfl(p_hash, bi, 64);
+            const uint32_t m0 = __shfl(meta, 0, 64), mb = __shfl(meta, bi, 64);
+            if (lane == 0) {
+                p_score = sb; p_hash = hb; meta = mb;
+            } else if (lane == bi) {
+                p_score = s0; p_hash = h0; meta = m0;
+            }
+            p_state = meta & 0xffffu;
+        }
+        // ---- store (beam_search.cpp:426-437) ----
+        if (e < ec) p_score -= bg_row[p_state];
+        if (lane < ec) tr[(size_t)(blk + 1) * W + lane] = meta;
+        width = ec;
+    }
+    __syncthreads();
+    __threadfence_block();
+
+    // ---- trace back (beam_search.cpp:448-455), TB_ROWS blocks at a time through LDS ----
+    uint8_t ei = 0;
+    for (int hi_blk = T; hi_blk >= 1; hi_blk -= TB_ROWS) {
+        const int lo_blk = (hi_blk - (TB_ROWS - 1) > 1) ? (hi_blk - (TB_ROWS - 1)) : 1;  // rows lo..hi
+        const int rows = hi_blk - lo_blk + 1;
+        const int words = rows * W;
+        // bulk copy (all loads issued before the first LDS store)
+        constexpr int PER = TB_ROWS * BS_MAXW / 64;
+        uint32_t tmp[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = lane + 64 * q;
+            tmp[q] = (i < words) ? tr[(size_t)lo_blk * W + i] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = lane + 64 * q;
+            if (i < words) tb_tile[i] = tmp[q];
+        }
+        __syncthreads();
+        if (lane == 0) {
+            for (int r = rows - 1; r >= 0; --r) {
+                const uint32_t m = tb_tile[r * W + ei];
+                tb_state[r] = (uint16_t)(m & 0xffffu);
+                tb_move[r] = ((m >> 24) & 1u) ? 0 : 1;
+                ei = (uint8_t)((m >> 16) & 0xffu);
+            }
+        }
+        __syncthreads();
+        ei = (uint8_t)__shfl((int)ei, 0, 64);
+        if (lane < rows) {
+            const int blk = lo_blk + lane - 1;  // beam row b describes block b-1
+            path_state[so + blk] = tb_state[lane];
+            moves[so + blk] = (blk == 0) ? (int8_t)1 : tb_move[lane];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k3: forward scan + posterior of the called path + sequence/qstring
 //     (CPUDecoder.cpp:43-64,130; beam_search.cpp:459-517; beam_search.cpp:54-102)
 // ---------------------------------------------------------------------------------------------
@@ -803,24 +1195,28 @@ extern "C" int mibc_launch_decode_var(hipStream_t st, const half_t *scores, int 
     else
         hipLaunchKernelGGL(bwd_scan_kernel, dim3(N), dim3(S), smem1, st, scores, bwd, T, S, stay, clampv, vi);
 #ifdef MIBC_DEBUG_KERNELS
-    static const int k2_ht = MIBC_ENV_INT("MIBC_K2_HT", 1);   // 0: the round 1-4 merge scan (A/B)
-    if (!k2_ht && S == 256) {
-        hipLaunchKernelGGL((beam_search_kernel<256, false>), dim3(N), dim3(64), 0, st, scores, bwd, trace, path_state, moves, T, W, log_cut, stay, clampv, vi);
-    } else if (!k2_ht && S == 1024) {
-        hipLaunchKernelGGL((beam_search_kernel<1024, false>), dim3(N), dim3(64), 0, st, scores, bwd, trace, path_state, moves, T, W, log_cut, stay, clampv, vi);
-    } else
+    // A/B: MIBC_K2_V=1 the 32-lane kernel of rounds 1-5 (=0: with its round 1-4 merge scan)
+    static const int k2_v = MIBC_ENV_INT("MIBC_K2_V", 2);
+#define K2_OLD(S_, HT_) hipLaunchKernelGGL((beam_search_kernel<S_, HT_>), dim3(N), dim3(64), 0, st, scores, bwd, trace, path_state, moves, T, W, log_cut, stay, clampv, vi)
+    if (k2_v == 0 && S == 256) K2_OLD(256, false);
+    else if (k2_v == 0 && S == 1024) K2_OLD(1024, false);
+    else if (k2_v != 2 && S == 64) K2_OLD(64, true);
+    else if (k2_v != 2 && S == 256) K2_OLD(256, true);
+    else if (k2_v != 2) K2_OLD(1024, true);
+    else
+#undef K2_OLD
 #endif
     switch (S) {
         case 64:
-            hipLaunchKernelGGL((beam_search_kernel<64>), dim3(N), dim3(64), 0, st, scores, bwd, trace,
+            hipLaunchKernelGGL((beam_search64_kernel<64>), dim3(N), dim3(64), 0, st, scores, bwd, trace,
                                path_state, moves, T, W, log_cut, stay, clampv, vi);
             break;
         case 256:
-            hipLaunchKernelGGL((beam_search_kernel<256>), dim3(N), dim3(64), 0, st, scores, bwd,
+            hipLaunchKernelGGL((beam_search64_kernel<256>), dim3(N), dim3(64), 0, st, scores, bwd,
                                trace, path_state, moves, T, W, log_cut, stay, clampv, vi);
             break;
         default:
-            hipLaunchKernelGGL((beam_search_kernel<1024>), dim3(N), dim3(64), 0, st, scores, bwd,
+            hipLaunchKernelGGL((beam_search64_kernel<1024>), dim3(N), dim3(64), 0, st, scores, bwd,
                                trace, path_state, moves, T, W, log_cut, stay, clampv, vi);
             break;
     }
