@@ -168,22 +168,43 @@ __device__ __forceinline__ float dpp_f(float oldv, float v) {
                                                                  __builtin_bit_cast(int, v), CTRL,
                                                                  ROW_MASK, 0xf, false));
 }
+// (v_max_f32_dpp / v_add_f32_dpp: one instruction per stage instead of v_mov_dpp + canonicalise + op; same operands, max and
+//  add commute, so the results are those of the two-instruction forms bit for bit.  wave_sum: rows outside a stage's row_mask
+//  keep their value, which equals adding the +0 the two-instruction form moved in — its users sum non-negative terms.
+//  s_nop 1: a VGPR written by a VALU instruction is read through DPP no sooner than two wait states later; the last one
+//  covers the v_readlane.)
 __device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, dpp_f<0xB1, 0xf>(v, v));    // quad_perm [1,0,3,2]
-    v = fmaxf(v, dpp_f<0x4E, 0xf>(v, v));    // quad_perm [2,3,0,1]
-    v = fmaxf(v, dpp_f<0x141, 0xf>(v, v));   // row_half_mirror
-    v = fmaxf(v, dpp_f<0x140, 0xf>(v, v));   // row_mirror: every lane holds its row's maximum
-    v = fmaxf(v, dpp_f<0x142, 0xa>(v, v));   // row_bcast:15 into rows 1 and 3
-    v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));   // row_bcast:31 into rows 2 and 3
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"      // every lane holds its row's maximum
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"    // into rows 1 and 3
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"    // into rows 2 and 3
+        "s_nop 1"
+        : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_sum(float v) {  // summation order is fixed but not the butterfly's
-    v += dpp_f<0xB1, 0xf>(0.0f, v);
-    v += dpp_f<0x4E, 0xf>(0.0f, v);
-    v += dpp_f<0x141, 0xf>(0.0f, v);
-    v += dpp_f<0x140, 0xf>(0.0f, v);
-    v += dpp_f<0x142, 0xa>(0.0f, v);
-    v += dpp_f<0x143, 0xc>(0.0f, v);
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ uint32_t f2key(float f) {  // monotone float -> uint
@@ -565,27 +586,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
 //   * candidates live in FIXED slots (steps 4e + b, stays 128 + e) with their trace word (state | prev << 16 | stay << 24)
 //     written at expansion, so the compaction is ballot + v_mbcnt + three copies (order of the kept candidates = the
 //     reference's: steps in slot order, then stays);
-//   * the wave maximum is six v_max_f32_dpp.
+//   * the wave maximum is six v_max_f32_dpp (wave_max above);
+//   * tag[] and the new front n_*[] live inside the score row's LDS (dead between the expansion and the next block), so
+//     the arena is 4992 B and 32 waves fit a CU (5888 B: 27).
 // Same candidates, same matches, same order, same arithmetic: outputs are bit-identical to beam_search_kernel.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_max_dpp(float v) {
-    // (s_nop 1: a VGPR written by a VALU instruction is read through DPP no sooner than two wait states later)
-    asm("s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(v));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
 // m = 2 m + (h == q) for four candidates, h3 first: the compare's lane mask is the carry-in of the add.  gfx950 wants two wait
 // states between a VALU write of an SGPR pair and a VALU read of it as a mask, so the four compares go first (the trailing
 // s_nop 1: the result may be read by a v_permlane32_swap, which has the same rule for VGPRs).
@@ -623,11 +628,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
     constexpr int A_CS = A_BG + S * 4;                   // float c_score[BS_CAND]     steps 4e + b, stays STAY0 + e
     constexpr int A_CH = A_CS + BS_CAND * 4;             // uint32 c_hash[BS_CAND]     steps b * 32 + e (base-major), stays STAY0 + e
     constexpr int A_CM = A_CH + BS_CAND * 4;             // uint32 c_meta[BS_CAND]     as c_score
-    constexpr int A_TG = A_CM + BS_CAND * 4;             // int tag[4W]
+    // tag[] (merge phase) and the new front n_*[] (compaction -> top of the next block) are only alive while the score row is
+    // dead (it is read by the expansion alone and rewritten from registers at the top of a block, after the front has been
+    // loaded), so for K >= 448 they live inside it; the accesses are LDS operations of ONE wave, which execute in order
+    constexpr bool IN_ROW = K * 2 >= (4 * BS_MAXW + 3 * BS_MAXW) * 4;
+    constexpr int A_TG = IN_ROW ? A_SC : A_CM + BS_CAND * 4;   // int tag[4W]
     constexpr int A_NS = A_TG + 4 * BS_MAXW * 4;         // float n_score[W]
     constexpr int A_NH = A_NS + BS_MAXW * 4;             // uint32 n_hash[W]
     constexpr int A_NM = A_NH + BS_MAXW * 4;             // uint32 n_meta[W]
-    constexpr int A_END = A_NM + BS_MAXW * 4;
+    constexpr int A_END = IN_ROW ? A_CM + BS_CAND * 4 : A_NM + BS_MAXW * 4;
     constexpr int TB_ROWS = 32;
     constexpr int A_TB_END = TB_ROWS * BS_MAXW * 4 + TB_ROWS * 2 + TB_ROWS;
     constexpr int ARENA = (A_END > A_TB_END ? A_END : A_TB_END);
@@ -700,9 +709,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
     // prefetch row 0 of scores and row 1 of guides
     half8_t rs[RPL];
     float rg[GPL];
+    constexpr bool FULL = RPL * 64 * 8 <= K;    // every lane holds a piece of every score-row load (S >= 128)
 #pragma unroll
     for (int i = 0; i < RPL; ++i)
-        if ((i * 64 + lane) * 8 < K) rs[i] = *(const half8_t *)(sn + (i * 64 + lane) * 8);
+        if (FULL || (i * 64 + lane) * 8 < K) rs[i] = *(const half8_t *)(sn + (i * 64 + lane) * 8);
 #pragma unroll
     for (int i = 0; i < GPL; ++i) rg[i] = bn[(size_t)S + i * 64 + lane];
 
@@ -714,14 +724,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
         __syncthreads();  // previous block's LDS reads are complete
 #pragma unroll
         for (int i = 0; i < RPL; ++i)
-            if ((i * 64 + lane) * 8 < K) *(half8_t *)(sc_row + (i * 64 + lane) * 8) = rs[i];
+            if (FULL || (i * 64 + lane) * 8 < K) *(half8_t *)(sc_row + (i * 64 + lane) * 8) = rs[i];
 #pragma unroll
         for (int i = 0; i < GPL; ++i) bg_row[i * 64 + lane] = rg[i];
         __syncthreads();
         if (blk + 1 < T) {
 #pragma unroll
             for (int i = 0; i < RPL; ++i)
-                if ((i * 64 + lane) * 8 < K)
+                if (FULL || (i * 64 + lane) * 8 < K)
                     rs[i] = *(const half8_t *)(sn + (size_t)(blk + 1) * K + (i * 64 + lane) * 8);
 #pragma unroll
             for (int i = 0; i < GPL; ++i) rg[i] = bn[(size_t)(blk + 2) * S + i * 64 + lane];
@@ -819,7 +829,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
             }
         }
         __syncthreads();
-        const float max_score = wave_max_dpp(my_max);
+        const float max_score = wave_max(my_max);
 
         // ---- cut-off (beam_search.cpp:310-396): slots lane, 64 + lane (steps) and STAY0 + lane (stays).  Which of a lane's
         //      three slots hold candidates is a uniform lane mask (vm*), so a count is three v_cmp into SGPR pairs + SALU ----
@@ -1086,7 +1096,10 @@ __global__ void posts_qual_kernel(const half_t *__restrict__ scores,      // [N]
             ta += red[(t & 1) * 32 + i];
             ts += red[(t & 1) * 32 + 16 + i];
         }
-        if (tid == (t & (NT - 1))) prob[t] = ts / ta;
+        // (the IEEE division only in the wave whose thread stores it: wave-uniform branch)
+        if (wave == ((t & (NT - 1)) >> 6)) {
+            if (tid == (t & (NT - 1))) prob[t] = ts / ta;
+        }
     }
     __syncthreads();
     for (int i = tid; i < T; i += NT) {  // beam_search.cpp:505-506
