@@ -11,9 +11,11 @@
 //                        state vector in LDS (ping-pong), score row prefetched one step ahead and
 //                        staged transposed in LDS ([base][state]) so every read is conflict-free.
 //                        HBM: reads 2K B/step (scores), writes 4S B/step (back-guides).
-//   k2 beam_search_kernel one WAVE per chunk: beam (width <= 32) in registers, 5W candidates in
+//   k2 beam_search64_kernel one WAVE per chunk: beam (width <= 32) in registers (both wave halves
+//                        hold it and share the expansion and the merge test), 5W candidates in
 //                        LDS, hash-merge / bisection cut-off / in-order compaction with wave
 //                        ballots; trace (4 B x W per step) to HBM, traced back through LDS tiles.
+//                        (beam_search_kernel = the 32-lane form of rounds 1-5: debug library only.)
 //   k3 posts_qual_kernel one workgroup per chunk: forward scan fused with the posterior of the
 //                        called k-mer (+ its shifted neighbours) — posts[T+1][S] never touches
 //                        HBM —, then sequence / qstring emission.
