@@ -12,7 +12,7 @@ import glob
 import os
 import sys
 
-DEC = ("bwd_scan2_kernel", "beam_search_kernel", "posts_qual_kernel")
+DEC = ("bwd_scan2_kernel", "beam_search64_kernel", "beam_search_kernel", "posts_qual_kernel")
 NET = ("lstm_layer", "wsgemm_kernel", "conv12_kernel", "gemm256x_kernel", "tx_layer_kernel", "window_attention", "gemm_dma_kernel")
 
 
