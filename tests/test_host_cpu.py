@@ -269,6 +269,56 @@ def test_asm_hazard_checker_detects_and_clears(tmp_path):
     assert listing("\tv_mov_b32_e32 v21, v40\n\tv_mfma_f32_32x32x16_f16 a[0:15], v[20:23], v[24:27], a[0:15]\n") == []
 
 
+def test_decoder_inline_asm_has_no_unpadded_valu_hazard():
+    """csrc/decode.hip holds inline-asm reductions (v_max_f32_dpp / v_add_f32_dpp chains) and the beam search's match bits
+    (v_cmp into an SGPR pair + v_addc reading it as carry-in), none of which hipcc's hazard recogniser sees.  Scan the gfx950
+    ISA of the whole translation unit for the four VALU -> VALU wait-state rules they are subject to (no GPU needed)."""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "check_asm_hazards.py")
+    out = subprocess.run([sys.executable, tool, "--valu"], capture_output=True, text=True)
+    assert out.returncode == 0 and "0 VALU -> VALU hazards around inline asm" in out.stdout, out.stdout + out.stderr
+
+
+def test_valu_hazard_checker_detects_and_clears(tmp_path):
+    """The gate itself, on hand-written listings: each rule fires at too short a distance and clears with padding."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_asm_hazards", os.path.join(ROOT, "tools", "check_asm_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def listing(body):
+        p = tmp_path / "k.s"
+        p.write_text("_Z1kv:\n" + body)
+        return [b[4] for b in mod.scan_valu(str(p))]
+
+    A, E = "\t;;#ASMSTART\n", "\t;;#ASMEND\n"
+    dpp = "\tv_max_f32_dpp v9, v9, v9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+    # DPP: compiler VALU write, asm DPP read
+    assert listing("\tv_max_f32_e32 v9, v1, v2\n" + A + dpp + E) == ["VALU write -> DPP read"]
+    assert listing("\tv_max_f32_e32 v9, v1, v2\n" + A + "\ts_nop 0\n" + dpp + E) == ["VALU write -> DPP read"]
+    assert listing("\tv_max_f32_e32 v9, v1, v2\n" + A + "\ts_nop 1\n" + dpp + E) == []
+    assert listing(A + dpp + dpp + E) == ["VALU write -> DPP read"]                       # two chained stages, unpadded
+    assert listing(A + dpp + "\ts_nop 1\n" + dpp + E) == []
+    # SGPR mask: v_cmp then v_addc reading it
+    cmp_ = "\tv_cmp_eq_u32_e64 s[12:13], v41, v10\n"
+    addc = "\tv_addc_co_u32_e64 v11, s[12:13], v11, v11, s[12:13]\n"
+    other = "\tv_cmp_eq_u32_e64 s[14:15], v40, v10\n"
+    assert listing(A + cmp_ + addc + E) == ["VALU write of an SGPR mask -> carry-in / select read"]
+    assert listing(A + cmp_ + other + addc + E) == ["VALU write of an SGPR mask -> carry-in / select read"]
+    assert listing(A + cmp_ + other + other + addc + E) == []
+    assert listing(A + "\tv_cmp_eq_u32_e32 vcc, v1, v2\n\tv_addc_co_u32_e32 v3, vcc, v3, v3, vcc\n" + E) != []
+    # asm VALU write, compiler swap / readlane behind it
+    w = A + "\tv_add_f32_dpp v5, v5, v5 row_mirror row_mask:0xf bank_mask:0xf\n" + E
+    assert listing("\ts_nop 1\n" + w + "\tv_permlane32_swap_b32_e32 v5, v6\n") == ["VALU write -> v_permlane swap read"]
+    assert listing("\ts_nop 1\n" + w + "\tv_readlane_b32 s3, v5, 63\n") == ["VALU write -> v_readlane read"]
+    w1 = A + "\tv_add_f32_dpp v5, v5, v5 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n" + E
+    assert listing("\ts_nop 1\n" + w1 + "\tv_permlane32_swap_b32_e32 v5, v6\n") == []
+    assert listing("\ts_nop 1\n" + w1 + "\tv_readlane_b32 s3, v5, 63\n") == []
+    # compiler-to-compiler pairs are not its business
+    assert listing("\tv_max_f32_e32 v9, v1, v2\n\tv_mov_b32_dpp v3, v9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n") == []
+
+
 def test_fused_layer_weight_image_layout():
     """csrc/txlayer.hip streams one weight image per layer in consumption order (host function tx_layer_image, no device):
     (16 + 3 FF/32) stages of 32 KB; 16 x Wo | W1(0) | W1(1) W2(0) | ... | W2(NJ-1); every weight exactly once."""
