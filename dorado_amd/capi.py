@@ -43,7 +43,7 @@ class StageMsC(C.Structure):
 
 
 EXPORTS = [
-    "mibc_device_count", "mibc_device_memory", "mibc_last_error", "mibc_create", "mibc_destroy", "mibc_query_memory",
+    "mibc_device_count", "mibc_device_memory", "mibc_last_error", "mibc_build_id", "mibc_create", "mibc_destroy", "mibc_query_memory",
     "mibc_reserve", "mibc_output_steps", "mibc_batch_granularity", "mibc_host_alloc",
     "mibc_host_free", "mibc_device_alloc", "mibc_device_free", "mibc_memcpy_h2d",
     "mibc_memcpy_d2h", "mibc_forward", "mibc_decode", "mibc_call_device", "mibc_call",
@@ -100,6 +100,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.mibc_last_error.restype = C.c_char_p
         L.mibc_last_error.argtypes = [C.c_void_p]
+        L.mibc_build_id.restype = C.c_char_p
         L.mibc_create.argtypes = [C.c_int, C.POINTER(ModelDescC), C.POINTER(C.POINTER(C.c_float)),
                                   C.c_int, C.POINTER(C.c_void_p)]
         L.mibc_destroy.argtypes = [C.c_void_p]

@@ -109,6 +109,7 @@ struct mibc_engine {
     half_t *w3 = nullptr;  // [C][K3pad]
     half_t *w3f = nullptr, *head_w1f = nullptr;  // 16x32 MFMA-fragment order (wsgemm.hip)
     int use_ws = 1;
+    int fuse_q8 = 1;    // conv3 epilogue writes the int8 rows of the quantised LSTM itself (debug library: MIBC_FUSE_Q8=0 -> separate pass)
     int K3 = 0, K3pad = 0;
     std::vector<half_t *> lstm_w;    // 32-unit tiles, k-steps of 16 (v_mfma 32x32x16)
     std::vector<half_t *> lstm_w16;  // 16-unit tiles, k-steps of 32 (v_mfma 16x16x32); C <= 384 only

@@ -443,6 +443,7 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
         e->head_act1 = 3;
     }
     e->use_ws = MIBC_ENV_INT("MIBC_WSGEMM", 1);
+    e->fuse_q8 = MIBC_ENV_INT("MIBC_FUSE_Q8", 1);
     e->use_cluster = MIBC_ENV_INT("MIBC_LSTM_CLUSTER", 1);
     const char *tp = getenv("MIBC_TAPS");
     e->taps = tp ? atoi(tp) : 0;
@@ -460,6 +461,7 @@ static void free_ws(mibc_engine *e) {
                     e->prob_tap, e->trace, e->path_state, e->out3, e->ss_stage, e->cl_flags, e->cl_cstate};
     e->scores2 = nullptr;
     e->dec_pending[0] = e->dec_pending[1] = false;
+    e->timed[0] = e->timed[1] = false;     // the stage-event sets are recreated below: nothing recorded yet
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     e->cl_flags = nullptr;
@@ -571,7 +573,8 @@ extern "C" int mibc_query_memory(const mibc_engine *e, int T_in, size_t *bytes_p
     if (!e || T_in <= 0) return MIBC_ERR_ARG;
     const size_t T = (size_t)mibc_output_steps(e, T_in);
     if (e->is_tx) {
-        const size_t per_dec = T * e->K * 2 + (T + 1) * e->S * 4 + (T + 1) * 32 * 4 + T * 2 + T * 4;
+        // (decode overlap: a second scores buffer per decode sub-batch, mibc_set_decode_overlap — ADVICE r5)
+        const size_t per_dec = T * e->K * 2 * (e->decode_overlap ? 2 : 1) + (T + 1) * e->S * 4 + (T + 1) * 32 * 4 + T * 2 + T * 4;
         if (bytes_per_chunk) *bytes_per_chunk = tx_bytes_per_chunk(e, T_in);
         if (bytes_fixed) *bytes_fixed = per_dec * (size_t)decode_sub_default(e);
         return MIBC_OK;
@@ -582,7 +585,7 @@ extern "C" int mibc_query_memory(const mibc_engine *e, int T_in, size_t *bytes_p
     per += Tpitch * 16 * 2;                  // conv2 out (padded)
     per += 2 * T * e->C * 2;                 // LSTM ping-pong
     per += 3 * T;                            // out planes
-    const size_t per_dec = T * e->K * 2 + (T + 1) * e->S * 4 + (T + 1) * 32 * 4 + T * 2 + T * 4 +
+    const size_t per_dec = T * e->K * 2 * (e->decode_overlap ? 2 : 1) + (T + 1) * e->S * 4 + (T + 1) * 32 * 4 + T * 2 + T * 4 +
                            (e->d.out_features > 0 ? T * e->d.out_features * 2 : 0);
     if (bytes_per_chunk) *bytes_per_chunk = per;
     if (bytes_fixed) *bytes_fixed = per_dec * (size_t)decode_sub_default(e);  // decode scratch is per sub-batch
@@ -710,8 +713,13 @@ extern "C" int mibc_memcpy_h2d(mibc_engine *e, void *dst, const void *src, size_
     HIP_OK(e, hipStreamSynchronize(e->stream));
     return MIBC_OK;
 }
+static int overlap_join(mibc_engine *e, hipStream_t st);
 extern "C" int mibc_memcpy_d2h(mibc_engine *e, void *dst, const void *src, size_t bytes) {
     HIP_OK(e, hipSetDevice(e->device));
+    // decode overlap: the source may be output planes the decoder stream is still writing: `mibc_call_device;
+    // mibc_memcpy_d2h(out)` stays a valid sequence without a mibc_sync in between
+    const int jrc = overlap_join(e, e->stream);
+    if (jrc != MIBC_OK) return jrc;
     HIP_OK(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
     HIP_OK(e, hipStreamSynchronize(e->stream));
     return check_cluster_error(e);
@@ -772,6 +780,12 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
                            e->Tpitch, e->pad3, d.conv_act[0], d.conv_act[1]) != 0)
         return fail(e, MIBC_NOT_SUPPORTED, "conv activation combination not supported");
     bool conv3_done = false;
+    // lstm_quant: every layer int8 when conv3 hands over tanh outputs (the reference's CUTLASS_TNC_I8 layout, nn/ConvStack.cpp:72),
+    // else the first layer in f16 (LSTMStack.cpp:199-207)
+    // (the reference selects that layout for 128 < lstm_size <= 1024 only, nn/ConvStack.cpp:69-73; at lstm_size <= 128 its
+    // quantised path is the NTC forward_quantized scheme, a different one: first layer f16 here)
+    const bool q_all = d.lstm_quant && d.n_convs >= 3 && d.conv_act[d.n_convs - 1] == MIBC_ACT_TANH && e->C > 128;
+    bool conv3_int8 = false;   // round 6: conv3's epilogue wrote the int8 rows itself (no separate conversion pass)
     if (e->use_ws && e->w3f) {
         WsArgs w{};
         w.A = e->a2p;
@@ -784,7 +798,14 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
         w.T = T;
         w.Tpitch = e->Tpitch;
         w.stride = e->stride;
-        conv3_done = (mibc_launch_wsgemm(e->stream, &w, e->K3pad, 1) == 0);
+        if (q_all && e->fuse_q8) {
+            // the reference converts conv3's f16 output in a separate pass (nn/ConvStack.cpp:243,324-329 host_convert); here the
+            // GEMM epilogue emits round(127 f16(tanh)) rows — bit-identical to that pass, minus its 3 bytes per element of HBM traffic
+            w.act = 4;
+            conv3_int8 = conv3_done = (mibc_launch_wsgemm(e->stream, &w, e->K3pad, 1) == 0);
+            w.act = d.conv_act[2];
+        }
+        if (!conv3_done) conv3_done = (mibc_launch_wsgemm(e->stream, &w, e->K3pad, 1) == 0);
     }
     GemmArgs g{};
     g.A = e->a2p;
@@ -806,17 +827,19 @@ static int run_encoder(mibc_engine *e, const half_t *in_dev, int N, int T_in) {
         return fail(e, MIBC_NOT_SUPPORTED, "conv3 gemm shape");
     if (prof) HIP_OK(e, hipEventRecord(e->ev[e->ps][mibc_engine::EV_CONV], e->stream));
     half_t *cur = e->xa, *nxt = e->xb;
-    // lstm_quant: every layer int8 when conv3 hands over tanh outputs (the reference's CUTLASS_TNC_I8 layout, nn/ConvStack.cpp:72),
-    // else the first layer in f16 (LSTMStack.cpp:199-207); conv3's f16 output is converted once (round(127 v), v in (-1, 1))
-    // (the reference selects that layout for 128 < lstm_size <= 1024 only, nn/ConvStack.cpp:69-73; at lstm_size <= 128 its
-    // quantised path is the NTC forward_quantized scheme, a different one: first layer f16 here)
-    const bool q_all = d.lstm_quant && d.n_convs >= 3 && d.conv_act[d.n_convs - 1] == MIBC_ACT_TANH && e->C > 128;
-    if (q_all) {
+    // conv3's f16 output is converted once (round(127 v), v in (-1, 1)) unless its epilogue already wrote int8
+    if (q_all && !conv3_int8) {
         if (mibc_launch_q8_convert(e->stream, cur, (int8_t *)nxt, (size_t)T * N * e->C) != 0) return fail(e, MIBC_NOT_SUPPORTED, "lstm shape");
         half_t *t = cur;
         cur = nxt;
         nxt = t;
     }
+#ifdef MIBC_DEBUG_KERNELS
+    if (MIBC_ENV_INT("MIBC_STOP_AFTER_CONV3", 0)) {   // debug library only: tap 3 then returns what the LSTM stack would read
+        e->lstm_out = cur;
+        return MIBC_OK;
+    }
+#endif
     for (int l = 0; l < d.lstm_layers; ++l) {
         // LSTMStack(layers, size, reverse_first = true): nn/LSTMStack.cpp:29-41, CRFModel.cpp:41
         const int reverse = (l % 2 == 0) ? 1 : 0;
@@ -1234,6 +1257,8 @@ extern "C" int mibc_call_i16(mibc_engine *e, const int16_t *in_host, const float
     HIP_OK(e, hipMemcpyAsync(e->ss_stage, shift_scale_host, (size_t)N * 2 * sizeof(float),
                              hipMemcpyHostToDevice, e->stream));
     rc = mibc_call_device_i16(e, (const int16_t *)e->in_stage, e->ss_stage, N, T_in, o, e->out3);
+    if (rc != MIBC_OK) return rc;
+    rc = overlap_join(e, e->stream);          // decode overlap: the planes are complete when the decoder stream says so
     if (rc != MIBC_OK) return rc;
     HIP_OK(e, hipMemcpyAsync(out_host, e->out3, (size_t)3 * N * T, hipMemcpyDeviceToHost, e->stream));
     HIP_OK(e, hipStreamSynchronize(e->stream));

@@ -31,8 +31,12 @@ __device__ __forceinline__ half8_t wsload(__amdgpu_buffer_rsrc_t rs, int voff, i
 // v_rcp_f32 per element, the rest on the packed-f32 pipe):
 //   3: 5 tanh x = 5 - 10 / (1 + 2^(2 log2e x))      2: tanh x = 1 - 2 / (1 + 2^(2 log2e x))
 //   0: swish x = x / (1 + 2^(-log2e x))              1: min(swish x, 3.5)
-template <int act>
+//   4: tanh x, stored as int8 round(127 f16(tanh x)) — conv3 in front of the int8 LSTM (nn/ConvStack.cpp:243,324-329: the
+//      reference converts in a separate host_convert pass; here the epilogue emits the int8 row, bit-identical to
+//      q8_convert_kernel applied to the f16 output of act 2)
+template <int act_>
 __device__ __forceinline__ float4w ws_activation(float4w v) {
+    constexpr int act = (act_ == 4) ? 2 : act_;
     if (act < 0) return v;
     const float k = (act >= 2) ? 2.88539008f : -1.44269504f;
     const float4w kv = v * (float4w)(k);
@@ -42,8 +46,11 @@ __device__ __forceinline__ float4w ws_activation(float4w v) {
     d = d + (float4w)(1.0f);
 #pragma unroll
     for (int r = 0; r < 4; ++r) d[r] = __builtin_amdgcn_rcpf(d[r]);
-    if (act == 3) return d * (float4w)(-10.0f) + (float4w)(5.0f);
-    if (act == 2) return d * (float4w)(-2.0f) + (float4w)(1.0f);
+    // explicit fused multiply-adds: with -ffp-contract=fast the compiler is free to contract `d * a + b` in one instantiation and
+    // not in another, and one f32 ulp flips an f16 rounding once per ~10^6 outputs — the int8 epilogue (act 4) must reproduce the
+    // f16 epilogue (act 2) bit for bit (tests/test_gpu_lstm_q8.py)
+    if (act == 3) return __builtin_elementwise_fma(d, (float4w)(-10.0f), (float4w)(5.0f));
+    if (act == 2) return __builtin_elementwise_fma(d, (float4w)(-2.0f), (float4w)(1.0f));
     float4w sw = v * d;
     if (act == 1) {
 #pragma unroll
@@ -201,6 +208,40 @@ __global__ __launch_bounds__(NW * 64, 2) void wsgemm_kernel(WsArgs p) {
             // whole row segments (16 B per lane) instead of 8-byte pieces.  LDS operations of one
             // wave execute in order, so the only wait needed is write -> read.
             half_t *stg = stage + wave * (16 * 72);   // [16 rows][64 + 8 pad]
+            if (ACT == 4) {
+                // int8 rows: the patch holds 16 rows x WCOLS bytes (row pitch 80 B), a row leaves as WCOLS / 16 segments of 16 B
+                unsigned char *stg8 = (unsigned char *)stg;
+                constexpr int SEGS8 = WCOLS / 16;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const float4w h4 = ws_activation<ACT>(acc[ct][rt]);
+                        int pk = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float f = fminf(1.0f, fmaxf(-1.0f, (float)(half_t)h4[r]));
+                            pk |= ((int)__builtin_rintf(f * 127.0f) & 0xff) << (8 * r);
+                        }
+                        *(int *)(stg8 + l15 * 80 + ct * 16 + 4 * lq) = pk;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                    {
+                        const int r16 = lane / SEGS8, seg = lane % SEGS8;
+                        const int row = rt * 16 + r16;
+                        if (lane < 16 * SEGS8) {
+                            const int4 v = *(const int4 *)(stg8 + r16 * 80 + seg * 16);
+                            if (row < rows_valid && !(dbg & 2)) {
+                                signed char *orow = (signed char *)p.out + ((size_t)(out_base + row) * p.N + grp) * p.cols;
+                                *(int4 *)(orow + col0 + seg * 16) = v;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                continue;
+            }
             constexpr int SEGS = WCOLS / 8;            // 16-byte segments per row
             constexpr int RPI = 64 / SEGS;             // rows per store instruction
 #pragma unroll
@@ -290,7 +331,7 @@ extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mod
     const int slots = ncu * (NW == 8 ? 1 : 2);
     const int grid = ntiles < slots ? ntiles : slots;
     // activation is a template parameter (a run-time switch costs ~4 extra VALU per output): the
-    // head uses 5*tanh (3) or none (-1), conv3 swish (0), clamped swish (1) or tanh (2)
+    // head uses 5*tanh (3) or none (-1), conv3 swish (0), clamped swish (1), tanh (2) or tanh with int8 rows (4)
 #define WS_ONE(KT_, M_, CT_, RT_, NW_, ACT_)                                                           \
     if (a->act == ACT_) {                                                                              \
         MIBC_LDS_ATTR_ONCE((wsgemm_kernel<KT_, M_, CT_, RT_, NW_, ACT_>), 160 * 1024);                 \
@@ -304,7 +345,7 @@ extern "C" int mibc_launch_wsgemm(hipStream_t s, const WsArgs *a, int K, int mod
             WS_ONE(KT_, M_, CT_, RT_, NW_, 3) WS_ONE(KT_, M_, CT_, RT_, NW_, -1)                       \
         } else {                                                                                       \
             WS_ONE(KT_, M_, CT_, RT_, NW_, 0) WS_ONE(KT_, M_, CT_, RT_, NW_, 1)                        \
-            WS_ONE(KT_, M_, CT_, RT_, NW_, 2)                                                          \
+            WS_ONE(KT_, M_, CT_, RT_, NW_, 2) WS_ONE(KT_, M_, CT_, RT_, NW_, 4)                        \
         }                                                                                              \
         return 1;                                                                                      \
     }

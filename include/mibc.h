@@ -93,6 +93,10 @@ typedef struct mibc_engine mibc_engine;
 MIBC_API int mibc_device_count(void);
 MIBC_API int mibc_device_memory(int device_id, size_t *free_bytes, size_t *total_bytes); /* cuda_utils.cpp:250-262 */
 MIBC_API const char *mibc_last_error(const mibc_engine *e); /* e may be NULL: last global error */
+/* Identity of the binary: 16 hex digits of a sha256 over every source file the library was compiled from (tools/build_id.py;
+ * "-dbg" appended in libmibc_dbg.so) — what a caller logs next to the model name, the role of the Koi / dorado version strings
+ * (dorado/dorado_version.h DORADO_VERSION); the test suite refuses a library whose id is not the tree's. */
+MIBC_API const char *mibc_build_id(void);
 
 /* ---- lifetime (replaces CudaCaller ctor: basecall/CudaCaller.cpp:149-200) ----
  * weights: host f32 tensors in module.parameters() order (basecall/crf_utils.cpp:34-88):
@@ -141,7 +145,9 @@ MIBC_API int mibc_sync(mibc_engine *e);
  * double-buffered, so that the decoder of one batch (HBM streaming, idle matrix pipes) runs under the network of the next
  * (matrix pipe / L2 bound, 0.7 TB/s of HBM traffic), and — where a batch is decoded in sub-batches — under the head of the next
  * sub-batch.  Results are unchanged.  Costs a second scores buffer; per-stage profiling (mibc_get_stage_ms) is not available
- * while it is on.  Applies to mibc_call_device, mibc_call, mibc_call_async (the variable-chunk calls stay serial). */
+ * while it is on.  Applies to mibc_call_device, mibc_call_device_i16, mibc_call, mibc_call_i16, mibc_call_async (the
+ * variable-chunk calls stay serial).  After the asynchronous device calls the output planes are complete once mibc_sync or
+ * mibc_memcpy_d2h returns (both join the decoder stream); mibc_query_memory counts the second scores buffer while it is on. */
 MIBC_API int mibc_set_decode_overlap(mibc_engine *e, int on);
 /* Two-phase form of mibc_call (the overlap CudaCaller gets from its runners' own streams, CudaCaller.cpp:645-719 +
  * decode/CUDADecoder.h:13-15): mibc_call_async enqueues H2D (copy stream) -> network + decode (engine stream) ->

@@ -114,6 +114,45 @@ static float *rounded_copy(const float *w, size_t n) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * int8-LSTM emulation (checker-side only).  The reference's GPU path runs the LSTM stack of the
+ * tanh-conv models in int8 (nn/ConvStack.cpp:69-73, nn/LSTMStack.cpp:127-211 forward_cutlass with
+ * KOI_I8): [W_ih | W_hh] quantised per output row by utils::quantize_tensor on the f16 weights
+ * (torch_utils/tensor_utils.cpp:293-300 as called by LSTMStack.cpp:160-168), int8 activations,
+ * integer accumulation, floating-point bias / gates / cell state.  Koi is closed, so the
+ * activation scale is the device path's own (round(127 v), v in [-1, 1]).  With
+ * orc_set_q8_emulation(1) (which implies the f16-storage roundings everywhere else) the LSTM
+ * layers below follow that arithmetic: "device int8 path vs this" isolates kernel error from the
+ * quantisation noise, "this vs the f32 reference" is the quantisation noise alone.
+ * ---------------------------------------------------------------------------------------- */
+static int g_q8 = 0;
+ORC_API void orc_set_q8_emulation(int on) { g_q8 = on; }
+ORC_API int orc_get_q8_emulation(void) { return g_q8; }
+static inline int q8q(float v) { /* round(127 clamp(v, -1, 1)), ties to even */
+    v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);
+    return (int)nearbyintf(v * 127.0f);
+}
+/* utils::quantize_tensor(cat(W_ih, W_hh, 1).half(), 1): every elementwise result is an f16 tensor
+ * (tensor_utils.cpp:293-300): scale = f16(128 / max|row|), q = clip(round(f16(w scale)), +-127).
+ * q [4C][2C], scale [4C]. */
+ORC_API void orc_quantize_lstm_weights(const float *wih, const float *whh, int C, int8_t *q, float *scale) {
+    for (int row = 0; row < 4 * C; ++row) {
+        float amax = 0.0f;
+        for (int k = 0; k < C; ++k) {
+            amax = fmaxf(amax, fabsf(rf16(wih[(size_t)row * C + k])));
+            amax = fmaxf(amax, fabsf(rf16(whh[(size_t)row * C + k])));
+        }
+        const float s = amax > 0.0f ? rf16(128.0f / amax) : 1.0f;
+        scale[row] = s;
+        for (int k = 0; k < 2 * C; ++k) {
+            const float w = rf16((k < C) ? wih[(size_t)row * C + k] : whh[(size_t)row * C + (k - C)]);
+            float v = nearbyintf(rf16(w * s));
+            v = fminf(127.0f, fmaxf(-127.0f, v));
+            q[(size_t)row * 2 * C + k] = (int8_t)v;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * a12: chunking and stitching (integer, bit-exact contract)
  * ---------------------------------------------------------------------------------------- */
 
@@ -327,7 +366,7 @@ ORC_API void orc_lstm_layer(const float *in, int N, int T, int C, const float *W
             WiT[(size_t)k * G + j] = Wih[(size_t)j * C + k];
             WhT[(size_t)k * G + j] = Whh[(size_t)j * C + k];
         }
-    const int f16 = g_f16;
+    const int f16 = g_f16 || g_q8;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int n = 0; n < N; ++n) {
         float *h = (float *)calloc((size_t)C, sizeof(float));
@@ -367,6 +406,70 @@ ORC_API void orc_lstm_layer(const float *in, int N, int T, int C, const float *W
     }
     free(WiT);
     free(WhT);
+}
+
+/* The int8 instance of the layer above (nn/LSTMStack.cpp:127-211, KOI_I8): x_t and h_{t-1} enter as
+ * round(127 v) int8, the weights as orc_quantize_lstm_weights, the gate pre-activation is
+ * float(acc_i32) / (127 scale[row]) + (b_ih + b_hh), gates and cell state are f32.  in [N,T,C] holds values
+ * in [-1, 1] (f16 conv / layer outputs or q / 127 of the previous int8 layer); out = q(h) / 127 — or, out_f16
+ * (the last layer hands f16 to the CRF head, LSTMStack.cpp:199-207), f16(h) while the recurrence keeps q(h). */
+ORC_API void orc_lstm_layer_q8(const float *in, int N, int T, int C, const float *Wih, const float *Whh,
+                               const float *bih, const float *bhh, int reverse, int out_f16, float *out) {
+    const int G = 4 * C;
+    int8_t *q = (int8_t *)malloc((size_t)G * 2 * C);
+    float *scale = (float *)malloc((size_t)G * sizeof(float));
+    orc_quantize_lstm_weights(Wih, Whh, C, q, scale);
+    /* transposed int16 copy Wt[k][4C] so the loop over the gate index vectorises (integer sums are exact in any order) */
+    int16_t *Wt = (int16_t *)malloc((size_t)2 * C * G * sizeof(int16_t));
+    for (int j = 0; j < G; ++j)
+        for (int k = 0; k < 2 * C; ++k) Wt[(size_t)k * G + j] = q[(size_t)j * 2 * C + k];
+    float *deq = (float *)malloc((size_t)G * sizeof(float));
+    float *bias = (float *)malloc((size_t)G * sizeof(float));
+    for (int j = 0; j < G; ++j) {
+        deq[j] = 1.0f / (127.0f * scale[j]);
+        bias[j] = bih[j] + bhh[j];
+    }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int n = 0; n < N; ++n) {
+        int16_t *hq = (int16_t *)calloc((size_t)C, sizeof(int16_t));
+        int16_t *xq = (int16_t *)malloc((size_t)C * sizeof(int16_t));
+        float *c = (float *)calloc((size_t)C, sizeof(float));
+        int32_t *acc = (int32_t *)malloc((size_t)G * sizeof(int32_t));
+        for (int step = 0; step < T; ++step) {
+            const int t = reverse ? (T - 1 - step) : step;
+            const float *x = in + ((size_t)n * T + t) * C;
+            for (int k = 0; k < C; ++k) xq[k] = (int16_t)q8q(x[k]);
+            for (int j = 0; j < G; ++j) acc[j] = 0;
+            for (int k = 0; k < 2 * C; ++k) {
+                const int32_t v = k < C ? xq[k] : hq[k - C];
+                if (v == 0) continue;
+                const int16_t *w = Wt + (size_t)k * G;
+#pragma omp simd
+                for (int j = 0; j < G; ++j) acc[j] += v * (int32_t)w[j];
+            }
+            float *y = out + ((size_t)n * T + t) * C;
+            for (int j = 0; j < C; ++j) {
+                const float ig = sigmoidf_(fmaf((float)acc[j], deq[j], bias[j]));
+                const float fg = sigmoidf_(fmaf((float)acc[C + j], deq[C + j], bias[C + j]));
+                const float gg = tanhf(fmaf((float)acc[2 * C + j], deq[2 * C + j], bias[2 * C + j]));
+                const float og = sigmoidf_(fmaf((float)acc[3 * C + j], deq[3 * C + j], bias[3 * C + j]));
+                c[j] = fmaf(fg, c[j], ig * gg);
+                const float h = og * tanhf(c[j]);
+                const int hqv = q8q(h);
+                hq[j] = (int16_t)hqv;
+                y[j] = out_f16 ? rf16(h) : (float)hqv / 127.0f;
+            }
+        }
+        free(hq);
+        free(xq);
+        free(c);
+        free(acc);
+    }
+    free(q);
+    free(scale);
+    free(Wt);
+    free(deq);
+    free(bias);
 }
 
 /* nn/CRFModules.cpp:24-34: y = x W^T (+ b); optional tanh * scale.  W [Cout,Cin]. */
@@ -439,7 +542,8 @@ ORC_API int orc_lstm_crf_forward(const orc_model_desc *d, const float *const *we
                                  float *layer_out) {
     int wi = 0;
     const int F = d->num_features;
-    const int f16 = g_f16;
+    const int q8 = g_q8;
+    const int f16 = g_f16 || q8;
     float *cur = (float *)malloc((size_t)N * T_in * F * sizeof(float));
     for (int n = 0; n < N; ++n)
         for (int f = 0; f < F; ++f)
@@ -466,8 +570,21 @@ ORC_API int orc_lstm_crf_forward(const orc_model_desc *d, const float *const *we
     }
     /* LSTMStack(layers, size, reverse_first = true): layer 0 reversed, then alternating. */
     float *buf = (float *)malloc((size_t)N * T * C * sizeof(float));
+    /* int8 emulation: every layer int8 when the last convolution ends in tanh and 128 < C (nn/ConvStack.cpp:69-73: the
+     * convolution writes the CUTLASS_TNC_I8 layout), otherwise the first layer runs in f16 and its output is converted
+     * (LSTMStack.cpp:199-207); the last layer always hands f16 to the head */
+    const int q_all = q8 && d->n_convs >= 3 && d->conv_act[d->n_convs - 1] == 2 && C > 128;
     for (int l = 0; l < d->lstm_layers; ++l) {
         const int reverse = (l % 2 == 0);
+        if (q8 && (l >= 1 || q_all)) {
+            orc_lstm_layer_q8(cur, N, T, C, weights[wi], weights[wi + 1], weights[wi + 2], weights[wi + 3], reverse,
+                              l == d->lstm_layers - 1, buf);
+            wi += 4;
+            float *tmp = cur;
+            cur = buf;
+            buf = tmp;
+            continue;
+        }
         float *wq0 = f16 ? rounded_copy(weights[wi], (size_t)4 * C * C) : NULL;
         float *wq1 = f16 ? rounded_copy(weights[wi + 1], (size_t)4 * C * C) : NULL;
         orc_lstm_layer(cur, N, T, C, f16 ? wq0 : weights[wi], f16 ? wq1 : weights[wi + 1], weights[wi + 2],

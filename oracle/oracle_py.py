@@ -122,6 +122,24 @@ class f16_emulation:
         return False
 
 
+class q8_emulation:
+    """with q8_emulation(): the LSTM layers of the C restatement follow the int8 arithmetic of the reference's GPU path
+    (nn/LSTMStack.cpp:127-211: per-row quantised weights, round(127 v) activations, integer accumulation); everything else
+    rounds as under f16_emulation()."""
+
+    def __init__(self, on=True):
+        self.on = int(bool(on))
+
+    def __enter__(self):
+        self.prev = lib().orc_get_q8_emulation()
+        lib().orc_set_q8_emulation(self.on)
+        return self
+
+    def __exit__(self, *a):
+        lib().orc_set_q8_emulation(self.prev)
+        return False
+
+
 def _wptrs(weights):
     ws = [np.ascontiguousarray(w, np.float32) for w in weights]
     arr = (_f32p * len(ws))(*[_fp(w) for w in ws])

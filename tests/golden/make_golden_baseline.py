@@ -35,9 +35,21 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 # name -> (config factory, N, weight seed, signal seed, sampled steps per chunk)
 CASES = {
     "hac": (config.hac_v43, 64, 42, 0xBA5E0, 4),
-    "sup43": (config.sup_v43, 32, 42, 0xBA5E1, 4),
+    "sup43": (config.sup_v43, 64, 42, 0xBA5E1, 4),
     "sup5": (config.sup_v50, 8, 42, 0xBA5E2, 16),
 }
+
+
+def model_and_signal(name, n=None):
+    """Round 6: the LSTM models use the synthetic model WITH DECISION MARGINS (synth.make_margin_weights on a base-level signal,
+    criteria in tools/margin_sweep.py); the transformer keeps the random weights with the CRF gain of round 4.  Imported by the
+    tests, which regenerate weights and signals from the seeds."""
+    factory, N, wseed, sseed, _ = CASES[name]
+    cfg = factory()
+    n = N if n is None else n
+    if cfg.tx is None:
+        return cfg, synth.make_margin_weights(cfg, seed=wseed), synth.make_base_signal(N, cfg.chunk_size, seed=sseed)[:n]
+    return cfg, synth.make_weights(cfg, seed=wseed), synth.make_signal(N, cfg.chunk_size, seed=sseed)[:n]
 
 
 def wsum(ws):
@@ -78,17 +90,18 @@ def dense_cols(T, K):
     return (np.arange(DENSE_COLS, dtype=np.int32)[None, :] * g + (np.arange(T, dtype=np.int32) % g)[:, None])
 
 
-def make_dense(name, s_ref=None, s_h=None):
+def make_dense(name, s_ref=None, s_h=None, s_q=None):
     factory, N, wseed, sseed, _ = CASES[name]
-    cfg = factory()
-    t_in = cfg.chunk_size
     if s_ref is None:
-        ws = synth.make_weights(cfg, seed=wseed)
-        x16 = synth.make_signal(N, t_in, seed=sseed)[:DENSE_CHUNKS]   # chunks are independent: same rows as the full batch
+        cfg, ws, x16 = model_and_signal(name, DENSE_CHUNKS)              # chunks are independent: same rows as the full batch
         x = x16.astype(np.float32)[:, None, :]
         s_ref = O.forward(cfg, ws, x, use_ref=True)
         with O.f16_emulation():
             s_h = O.forward(cfg, ws, x)
+        if cfg.tx is None:
+            with O.q8_emulation():
+                s_q = O.forward(cfg, ws, x)
+    cfg = factory()
     s_ref, s_h = s_ref[:DENSE_CHUNKS], s_h[:DENSE_CHUNKS]
     T, K = s_ref.shape[1], s_ref.shape[2]
     cols = dense_cols(T, K)
@@ -97,17 +110,16 @@ def make_dense(name, s_ref=None, s_h=None):
     scale = 32767.0 / rngv
     assert max(np.abs(s_ref).max(), np.abs(s_h).max()) <= rngv or cfg.clamp, "dense fixture range too small for these scores"
     q = lambda s: np.round(np.clip(s[:, tt, cols], -rngv, rngv) * scale).astype(np.int16)
+    extra = {"q8_q": q(s_q[:DENSE_CHUNKS])} if s_q is not None else {}
     np.savez_compressed(os.path.join(OUT, f"base_{name}_dense.npz"), chunks=np.arange(DENSE_CHUNKS, dtype=np.int32),
-                        scale=np.float32(scale), ncols=np.int32(DENSE_COLS), ref_q=q(s_ref), f16_q=q(s_h))
+                        scale=np.float32(scale), ncols=np.int32(DENSE_COLS), ref_q=q(s_ref), f16_q=q(s_h), **extra)
     print(f"{name}: dense fixture {DENSE_CHUNKS} x {T} x {DENSE_COLS}", flush=True)
 
 
 def make(name):
     factory, N, wseed, sseed, per = CASES[name]
-    cfg = factory()
+    cfg, ws, x16 = model_and_signal(name)
     t_in = cfg.chunk_size
-    ws = synth.make_weights(cfg, seed=wseed)
-    x16 = synth.make_signal(N, t_in, seed=sseed)
     x = x16.astype(np.float32)[:, None, :]
     t0 = time.time()
     s_ref = O.forward(cfg, ws, x, use_ref=True)
@@ -117,6 +129,17 @@ def make(name):
         s_h = O.forward(cfg, ws, x)
     d_h = O.decode(s_h, q_shift=cfg.qbias, q_scale=cfg.qscale, det=1)
     t2 = time.time()
+    s_q, q8 = None, {}
+    if cfg.tx is None:
+        # int8-LSTM emulation (oracle.c orc_set_q8_emulation: the arithmetic of the reference's GPU path for these models,
+        # nn/LSTMStack.cpp:127-211): what an ideal int8-LSTM pipeline scores and calls
+        with O.q8_emulation():
+            s_q = O.forward(cfg, ws, x)
+        d_q = O.decode(s_q, q_shift=cfg.qbias, q_scale=cfg.qscale, det=1)
+        seq_q, qs_q, mv_q, ln_q = planes(d_q, s_ref.shape[1])
+        eq = np.abs(s_q - s_ref)
+        q8 = dict(q8_seq=seq_q, q8_qstr=qs_q, q8_moves=mv_q, q8_len=ln_q, q8_vs_ref_max=np.float32(eq.max()),
+                  q8_vs_ref_rms=np.float32(np.sqrt((eq.astype(np.float64) ** 2).mean())))
     T = s_ref.shape[1]
     sel = sample_steps(N, T, per, sseed + 7)
     rows = np.arange(N)[:, None]
@@ -131,11 +154,14 @@ def make(name):
         ref_seq=seq, ref_qstr=qs, ref_moves=mv, ref_len=ln,
         f16_seq=seq_h, f16_qstr=qs_h, f16_moves=mv_h, f16_len=ln_h,
         f16_vs_ref_max=np.float32(e.max()), f16_vs_ref_rms=np.float32(np.sqrt((e.astype(np.float64) ** 2).mean())),
+        **({"q8_scores": s_q[rows, sel].astype(np.float16), **q8} if s_q is not None else {}),
     )
+    qv = np.concatenate([np.frombuffer(a[1].encode(), np.uint8).astype(int) - 33 for a in d_ref])
+    print(f"{name}: reference calls {len(qv)} bases, {(qv >= 20).mean():.3f} of them at q >= 20", flush=True)
     print(f"{name}: scores {s_ref.shape} range {s_ref.min():.2f}..{s_ref.max():.2f}; reference {t1 - t0:.0f}s, "
           f"f16 emulation {t2 - t1:.0f}s; f16-vs-ref max {e.max():.4f} rms {np.sqrt((e ** 2).mean()):.5f}; "
           f"bases/step {ln.mean() / T:.3f}", flush=True)
-    make_dense(name, s_ref, s_h)
+    make_dense(name, s_ref, s_h, s_q)
 
 
 if __name__ == "__main__":

@@ -25,6 +25,11 @@ FLOW_CELL = "FLO-PRO114M"
 WEIGHT_SEED, READ_SEED = 42, 0x91BE
 
 
+def model_weights(cfg):
+    """Round 6: the synthetic model with decision margins (synth.make_margin_weights) on base-level reads."""
+    return synth.make_margin_weights(cfg, seed=WEIGHT_SEED)
+
+
 def pipeline_reads():
     """32 raw int16 reads + (scaling, offset, open_pore_level) each: 26 of about five chunks (38 k - 48 k samples), and six edge
     lengths (shorter than a chunk, exactly a chunk after the 10-sample trim, a chunk + a few samples, two and three chunks)."""
@@ -35,7 +40,7 @@ def pipeline_reads():
         scaling = float(rng.uniform(0.14, 0.2))
         offset = float(rng.integers(-260, -200))
         opl = float(rng.uniform(190.0, 210.0))
-        x = synth.make_signal(1, n, seed=READ_SEED + 1 + i)[0].astype(np.float32)
+        x = synth.make_base_signal(1, n, seed=READ_SEED + 1 + i)[0].astype(np.float32)
         pa = STANDARDISATION[1] + STANDARDISATION[2] * x
         raws.append(np.clip(np.round(pa / scaling - offset), -32768, 32767).astype(np.int16))
         cal.append((scaling, offset, opl))
@@ -52,7 +57,7 @@ def main():
     from oracle import oracle_py as O
     assert O.have_ref_pipeline(), "build oracle/_ref first: make -C oracle -f Makefile.ref"
     cfg = config.hac_v43()
-    ws = synth.make_weights(cfg, seed=WEIGHT_SEED)
+    ws = model_weights(cfg)
     raws, cal = pipeline_reads()
     t0 = time.time()
     ref = O.ref_pipeline(cfg, ws, raws, cal, "pa", standardisation=STANDARDISATION, flow_cell_product_code=FLOW_CELL,

@@ -57,4 +57,23 @@ def test_decode_overlap_changes_nothing(model):
     want = eng.call(batches[0])
     for (s1, q1, m1), (s2, q2, m2) in zip(got, want):
         assert s1 == s2 and q1 == q2 and (m1 == m2).all()
+    # the synchronous int16 host call, and `call_device; d2h(out)` WITHOUT a sync in between, join the decoder stream too
+    raw = np.round(batches[1].astype(np.float32) * 200.0).astype(np.int16)
+    ss = np.tile(np.array([[0.0, 200.0]], np.float32), (n, 1))
+    want16 = eng.call_i16(raw, ss)
+    eng.set_decode_overlap(True)
+    got16 = eng.call_i16(raw, ss)
+    T = eng.output_steps(t_in)
+    d_in, d_out = eng.device_alloc(batches[2].nbytes), eng.device_alloc(3 * n * T)
+    eng.h2d(d_in, batches[2])
+    for _ in range(3):                                      # decoders of earlier calls still in flight on the decoder stream
+        eng.call_device(d_in, n, t_in, d_out)
+    h = np.zeros((3, n, T), np.int8)
+    eng.d2h(h, d_out)                                       # no eng.sync() before the copy
+    eng.set_decode_overlap(False)
+    eng.device_free(d_in)
+    eng.device_free(d_out)
+    for (s1, q1, m1), (s2, q2, m2) in zip(got16, want16):
+        assert s1 == s2 and q1 == q2 and (m1 == m2).all()
+    assert (h == a[2]).all()
     eng.close()

@@ -6,6 +6,8 @@ An 8-bit path has its own, STATED tolerance (the f16 path stays the parity headl
     activations: step 0.0079, rms error 0.0023 per element, amplified by the random-weight layers), deterministic;
   * against the COMPILED REFERENCE at BASELINE size: test_gpu_baseline_parity.py::test_quantised_lstm_vs_reference
     (scores rms / max and identity on the reference's confident bases; measured values in DESIGN.md)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -124,3 +126,40 @@ def test_quantised_path_with_swish_front_end_keeps_first_layer_f16(C, state_len,
     rms = float(np.sqrt((d ** 2).mean()))
     print(f"C={C} swish front end: int8 (layers 2..L) vs f16: scores rms {rms:.4f} max {np.abs(d).max():.3f}")
     assert np.isfinite(s8).all() and rms <= 0.15
+
+
+_FUSE_SCRIPT = r"""
+import hashlib, os, sys
+import os
+
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from dorado_amd import capi, config, synth
+if sys.argv[2] == "dbg":
+    capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), "libmibc_dbg.so")
+C_, sl, N = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+cfg = config.tiny(C_, sl)
+cfg.lstm_quant = True
+eng = capi.Engine(cfg, synth.make_weights(cfg, seed=41))
+s = eng.forward(synth.make_signal(N, 1206, seed=42))
+print(hashlib.sha256(np.ascontiguousarray(s).tobytes()).hexdigest())
+"""
+
+
+@pytest.mark.parametrize("C,state_len,N", [(384, 4, 128), (256, 4, 64), (1024, 5, 256)])
+def test_conv3_int8_epilogue_equals_the_separate_conversion_pass(C, state_len, N):
+    """Round 6: with all LSTM layers int8 (tanh conv3, 128 < lstm_size) conv3's GEMM epilogue writes the
+    round(127 f16(tanh)) rows itself (wsgemm_kernel<.., 4>) instead of an f16 tensor + q8_convert_kernel — what the reference
+    does in two passes (nn/ConvStack.cpp:243,324-329).  Bit-identical by construction; asserted: the debug library with the
+    fusion switched off (MIBC_FUSE_Q8=0), the debug library with it on and the product library give the same scores."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for lib, fuse in (("dbg", "0"), ("dbg", "1"), ("product", "1")):
+        env = dict(os.environ, MIBC_FUSE_Q8=fuse)
+        r = subprocess.run([sys.executable, "-c", _FUSE_SCRIPT, root, lib, str(C), str(state_len), str(N)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append(r.stdout.strip().splitlines()[-1])
+    assert out[0] == out[1] == out[2], out

@@ -317,6 +317,13 @@ def test_valu_hazard_checker_detects_and_clears(tmp_path):
     assert listing("\ts_nop 1\n" + w1 + "\tv_readlane_b32 s3, v5, 63\n") == []
     # compiler-to-compiler pairs are not its business
     assert listing("\tv_max_f32_e32 v9, v1, v2\n\tv_mov_b32_dpp v3, v9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n") == []
+    # a label starts a new basic block: the producer may sit on the taken edge, so the textual predecessors do not
+    # clear an asm consumer in the first wait states of a block — padding inside the block does
+    far = "\ts_add_i32 s1, s1, 1\n" * 3
+    assert listing("\tv_max_f32_e32 v9, v1, v2\n" + far + ".LBB0_7:\n" + A + dpp + E) == ["VALU write -> DPP read"]
+    assert listing("\tv_max_f32_e32 v9, v1, v2\n" + far + ".LBB0_7:\n" + A + "\ts_nop 1\n" + dpp + E) == []
+    assert listing(".LBB0_7:\n\ts_add_i32 s1, s1, 1\n\ts_add_i32 s2, s2, 1\n" + A + dpp + E) == []
+    assert listing(".LBB0_8:\n" + A + addc + E) == ["VALU write of an SGPR mask -> carry-in / select read"]
 
 
 def test_fused_layer_weight_image_layout():

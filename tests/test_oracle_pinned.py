@@ -288,6 +288,66 @@ def test_dense_baseline_fixture_consistent_with_sampled_fixture(golden_dir, name
     assert abs(rms - float(g["f16_vs_ref_rms"])) <= 0.25 * float(g["f16_vs_ref_rms"]), (rms, float(g["f16_vs_ref_rms"]))
 
 
+@pytest.mark.parametrize("name", ["hac", "sup43"])
+def test_margin_model_fixture_meets_its_recipe_criteria(golden_dir, name):
+    """Round 6: the LSTM BASELINE fixtures run the synthetic model WITH DECISION MARGINS.  The criteria were
+    fixed before any device output was looked at: the f32 REFERENCE emits 0.40-0.55 bases per output step, >= 40 % of them at
+    q >= 20, and the f16-storage emulation calls them with median per-chunk identity >= 0.995 — checked here on what the compiled
+    reference wrote into the fixture.  Also recorded: the int8-LSTM emulation (oracle.c orc_set_q8_emulation) against the
+    reference, median identity >= 0.99 — the floor the device's int8 path is held to."""
+    from parity_utils import identity
+    g = np.load(os.path.join(golden_dir, f"base_{name}.npz"))
+    N, T = int(g["N"]), int(g["T"])
+    nb = int(g["ref_len"].sum())
+    assert 0.40 <= nb / (N * T) <= 0.55, nb / (N * T)
+    q20 = sum(int((g["ref_qstr"][i, :int(g["ref_len"][i])].astype(int) - 33 >= 20).sum()) for i in range(N))
+    assert q20 >= 0.40 * nb and q20 >= 20000, (q20, nb)
+
+    def seqs(prefix):
+        return [g[prefix + "_seq"][i, :int(g[prefix + "_len"][i])].tobytes().decode() for i in range(N)]
+    ref, f16, q8 = seqs("ref"), seqs("f16"), seqs("q8")
+    id16 = np.median([identity(a, b) for a, b in zip(f16, ref)])
+    id8 = np.median([identity(a, b) for a, b in zip(q8, ref)])
+    assert id16 >= 0.995, id16
+    assert id8 >= 0.99, id8
+    assert float(g["f16_vs_ref_rms"]) <= 0.012 and float(g["q8_vs_ref_rms"]) <= 0.10
+
+
+def test_oracle_weight_quantisation_equals_reference_fixture(golden_dir):
+    """The int8 emulation's weight quantisation (oracle.c orc_quantize_lstm_weights) against the compiled reference's
+    utils::quantize_tensor (fixture lstm_quant.npz): int8 values and scales bit for bit."""
+    import ctypes as C
+    mod = _quant_case()
+    g = np.load(os.path.join(golden_dir, "lstm_quant.npz"))
+    w_ih, w_hh = mod.weights(int(g["seed"]), int(g["C"]))
+    c = int(g["C"])
+    q = np.zeros((4 * c, 2 * c), np.int8)
+    sc = np.zeros(4 * c, np.float32)
+    O.lib().orc_quantize_lstm_weights(C.c_void_p(w_ih.ctypes.data), C.c_void_p(w_hh.ctypes.data), c, C.c_void_p(q.ctypes.data),
+                                      C.c_void_p(sc.ctypes.data))
+    assert (sc == g["scale"]).all() and (q == g["q"]).all()
+
+
+def test_int8_emulation_tracks_the_f32_network_and_is_deterministic():
+    """orc_set_q8_emulation on a small tanh-conv model: all five LSTM layers int8; scores stay within the quantisation noise of the
+    f32 network, differ from the f16 emulation, and the flag restores."""
+    cfg = config.tiny(256, 4)
+    ws = synth.make_margin_weights(cfg, seed=5)
+    x = synth.make_base_signal(4, 1206, seed=6).astype(np.float32)[:, None, :]
+    s32 = O.forward(cfg, ws, x)
+    with O.f16_emulation():
+        s16 = O.forward(cfg, ws, x)
+    with O.q8_emulation():
+        s8 = O.forward(cfg, ws, x)
+        s8b = O.forward(cfg, ws, x)
+    assert O.lib().orc_get_q8_emulation() == 0
+    assert (s8 == s8b).all()
+    r16 = float(np.sqrt(((s16 - s32) ** 2).mean()))
+    r8 = float(np.sqrt(((s8 - s32) ** 2).mean()))
+    assert r16 < r8 <= 0.12, (r16, r8)
+    assert (O.forward(cfg, ws, x) == s32).all()
+
+
 # ---------------------------------------------------------------- lstm_quant weight quantisation (host only)
 def _quant_case():
     import importlib.util
@@ -334,10 +394,10 @@ def test_whole_read_composition_vs_reference_pipeline_fixture(golden_dir):
     ModelRunner compiled in place (oracle/ref_pipeline.cpp).  The oracle's composition of the same path — scaler restatement,
     generate_chunks, repeat-padding of a short chunk (BasecallerNode.cpp:430-438), f32 network, decoder, stitch — must reproduce
     its STRUCTURE exactly on the three shortest reads (a sub-chunk read, exactly one chunk, one chunk + 7 samples = two chunks):
-    trim, scale / shift (pA), scaled length, chunk offsets, move-table length, number of bases == number of moves.  The bases
-    themselves are only held to identity >= 0.93: on these random weights f32-vs-f32 noise of 5e-6 rms in the scores (oracle.c
-    vs libtorch summation order; measured at hac size) already flips 1.5 % of the bases — the discriminating base-level checks
-    are the device tests on the reference's confidently called bases (tests/test_gpu_baseline_parity.py)."""
+    trim, scale / shift (pA), scaled length, chunk offsets, move-table length, number of bases == number of moves.  Round 6: the
+    fixture runs the synthetic model with decision margins (synth.make_margin_weights), so the f32 restatement must also call
+    the reference's BASES: identity >= 0.995 (on round 5's random weights 5e-6 rms of summation-order noise flipped 1.5 % of
+    them and the bound was 0.93)."""
     import importlib.util
     from parity_utils import identity
     spec = importlib.util.spec_from_file_location("make_golden_pipeline", os.path.join(golden_dir, "make_golden_pipeline.py"))
@@ -345,7 +405,7 @@ def test_whole_read_composition_vs_reference_pipeline_fixture(golden_dir):
     spec.loader.exec_module(mk)
     g = np.load(os.path.join(golden_dir, "pipeline_hac.npz"))
     cfg = config.hac_v43()
-    ws = synth.make_weights(cfg, seed=mk.WEIGHT_SEED)
+    ws = mk.model_weights(cfg)
     raws, cal = mk.pipeline_reads()
     assert np.uint32(zlib.crc32(np.concatenate(raws).tobytes())) == g["raw_crc"]
     so = np.concatenate([[0], np.cumsum(g["seq_len"])])
@@ -368,4 +428,4 @@ def test_whole_read_composition_vs_reference_pipeline_fixture(golden_dir):
         seq, qs, mv = O.stitch_chunks(offs, sizes, [d[2] for d in dec], [d[0] for d in dec], [d[1] for d in dec], len(sig), cfg.stride)
         assert len(mv) == int(g["moves_len"][i]) and int(mv.sum()) == len(seq) == len(qs)
         ref_seq = g["seq"][so[i]:so[i + 1]].tobytes().decode()
-        assert identity(seq, ref_seq) >= 0.93
+        assert identity(seq, ref_seq) >= 0.995

@@ -84,8 +84,18 @@ def sregs(tok):
     return {'s' + m.group(1)} if m else set()
 
 
+class _Any(set):
+    """The unknown write set of a basic-block entry: intersects every register set."""
+
+    def __and__(self, other):
+        return bool(other)
+
+
 def scan_valu(path):
-    """-> [(line, kernel, consumer text, producer text, rule)]"""
+    """-> [(line, kernel, consumer text, producer text, rule)]
+    A label starts a new basic block: the instructions in front of it textually are not the only predecessors, so the
+    wait-state window is replaced by an 'unknown producer' entry that covers every register — an asm consumer within its hazard
+    distance of a block entry is reported as unverifiable unless s_nop / independent instructions pad it."""
     lines = open(path).read().split('\n')
     bad = []
     in_asm = False
@@ -102,6 +112,9 @@ def scan_valu(path):
             continue
         if t.startswith(';;#ASMEND'):
             in_asm = False
+            continue
+        if t.endswith(':') and not t.startswith(';') and not m:
+            recent = [("<basic-block entry " + t + " (producer on another edge unknown)>", _Any(), _Any(), True)]
             continue
         if not t or t.startswith(';') or t.startswith('.') or t.endswith(':'):
             continue

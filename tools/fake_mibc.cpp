@@ -171,6 +171,7 @@ int mibc_device_memory(int, size_t *free_bytes, size_t *total_bytes) {
     return MIBC_OK;
 }
 const char *mibc_last_error(const mibc_engine *e) { return e ? e->err.c_str() : g_err.c_str(); }
+const char *mibc_build_id(void) { return "fake-mibc"; }
 
 int mibc_create(int device_id, const mibc_model_desc *desc, const float *const *, int, mibc_engine **out) {
     if (!desc || !out || device_id < 0 || device_id >= mibc_device_count()) return fail(nullptr, MIBC_ERR_ARG, "mibc_create: bad argument");
