@@ -12,8 +12,10 @@
 // in two passes of 64 hidden units (a 256 x 256 accumulator tile = 128 registers per lane), both
 // operands staged HBM/L2 -> LDS by direct DMA (global_load_lds_dwordx4) through a 4-slot ring of
 // K = 32 slabs (XOR-swizzled 64-byte rows; counted vmcnt, raw s_barrier: three slabs in flight),
-// 8 waves = 4 row groups x 2 hidden groups on v_mfma_f32_32x32x16_f16.  The cell state stays in
-// registers (fp32, 64 per lane); gates are lane-local exactly as in lstm.hip.
+// 8 waves = 4 row groups x 2 hidden groups on v_mfma_f32_16x16x32_f16 (round 6: was 32x32x16 — on random data the 32x32
+// shapes pull the shader clock down to 1.2 GHz = 1.26 PF of bare MFMAs, the 16x16 shapes hold 1.87 GHz = 1.91 PF,
+// tools/mfma_ref.hip; this kernel sat at 0.87 of the 32x32 ceiling).  The cell state lives in a
+// private scratch buffer (fp32); gates are lane-local exactly as in lstm.hip.
 //
 // The exchange of h between the members IS the layer output: member j writes its 128-unit slice of
 // h_t into Xout[t] with write-through (sc1) 16-byte stores, and every member reads the full h_{t-1}
@@ -31,7 +33,7 @@
 // Round 4 — Q8: the reference's quantised path (nn/LSTMStack.cpp:127-211, KOI_I8; per-row weight scales
 // utils::quantize_tensor :165-172) on the same machine mapping.  int8 activations (round(127 h), rows of C BYTES) and
 // int8 weights keep the 64-byte slab rows, so every LDS image, DMA piece and fragment read is byte-identical to the f16
-// kernel's; a slab now covers K = 64 (v_mfma_i32_32x32x32_i8: the lane's 16-byte fragment is 16 k-values), i.e. HALF the
+// kernel's; a slab now covers K = 64 (v_mfma_i32_16x16x64_i8: the lane's 16-byte fragment is 16 k-values), i.e. HALF the
 // slabs per time step at the same MFMA count per slab.  Accumulators are int32 (exact), initialised with
 // round(bias / deq[row]); gate pre-activation = float(acc) * deq[row], deq = 1 / (127 * row scale); gates, cell state and
 // the h quantisation are fp32 as in the f16 kernel.  Layers 1 .. L-2 write int8 h (which is also the exchange); the last
@@ -66,8 +68,13 @@ typedef int int16q_t __attribute__((ext_vector_type(16)));
 // byte distance between consecutive K slabs of a weight slice: 64 B along a row (row-major image) or one 16 KiB slab image
 #define CL_WSLAB (MIBC_CL_WROW ? 64u : (unsigned)(CL_WTILE * 2))
 
-__device__ __forceinline__ int16q_t cl_mfma_i8(half8_t a, half8_t b, int16q_t c) {
-    return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(int4q_t, a), __builtin_bit_cast(int4q_t, b), c, 0, 0, 0);
+// A operand = 16 gate rows x K, B operand = 16 batch rows x K of one slab (K = 32 halfs / 64 int8: the lane's 16 bytes are the
+// k-group lane >> 4 of row lane & 15); D[row = 4 (lane >> 4) + r][col = lane & 15]
+__device__ __forceinline__ int4q_t cl_mfma_i8(half8_t a, half8_t b, int4q_t c) {
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(int4q_t, a), __builtin_bit_cast(int4q_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float4_t cl_mfma_f16(half8_t a, half8_t b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
 // One launch = one layer.  grid = KCL * (clusters resident at once); a workgroup loops over the row
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, lhi = lane >> 5;
+    const int l15 = lane & 15, lq = lane >> 4;
     const int rgw = wave >> 1, hg = wave & 1;
 
     // cluster / member of this workgroup.  Observed placement: block b runs on XCD b % 8 — putting the KCL
@@ -146,10 +153,10 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
     bool dead = false;
 
     const bool grpB = wave >= 4;
-    const int sw = (l31 >> 2) & 3;              // (row >> 2) & 3 for every fragment row of this lane
-    const int c0 = ((0 + lhi) ^ sw) << 3, c1 = ((2 + lhi) ^ sw) << 3;
-    // fragment read bases of this lane inside a stage (halfs)
-    const int woff = (hg * 128 + l31) * CL_BK, xoff = CL_WTILE + (rgw * 64 + l31) * CL_BK;
+    const int sw = (l15 >> 2) & 3;              // (row >> 2) & 3 for every fragment row of this lane
+    const int cq = (lq ^ sw) << 3;              // physical 16-byte column of this lane's k-group (halfs)
+    // fragment read bases of this lane inside a stage (halfs): gate-row block (g, hb) at + (g * 32 + hb * 16) rows, batch block bb at + 16 bb rows
+    const int woff = (hg * 128 + l15) * CL_BK + cq, xoff = CL_WTILE + (rgw * 64 + l15) * CL_BK + cq;
     const unsigned long long wslice = (unsigned long long)(Wt + (size_t)j * 2 * KS * CL_WTILE);   // uniform
     const unsigned wlane = (unsigned)(((wave * 2) * 512 + lane * 8) * 2);                              // bytes
     // MIBC_CL_WROW = 1 (experiment, round 4; measured and NOT adopted: 207 vs 200 ms per f16 layer, 114 vs 112 int8): the
@@ -221,33 +228,27 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
         // its B1(g), B waits vmcnt(4) before its B2(g-1) (younger: one slab).  Extra younger operations (h stores,
         // flag fetch) only make a wait stricter.  The DMAs of slab g + 2 reuse the ring slot of slab g - 2, last
         // read in M(g-2), which both groups have finished before the instance A.B1(g).
-        float16_t acc[4][2];
-        int16q_t acq[4][2];        // Q8 accumulators (the unused set is dead code)
-        half8_t wf[4], xa[2];
-        float4_t cpre[2][4];
-        // ---- gates of one pass (gp, time index gt): D row = hidden (r&3) + 8 (r>>2) + 4 lhi, D col = batch row l31.
-        // Cell state: fp32, in a private scratch buffer instead of registers (64 registers per lane buy the fragment
-        // double-buffering of the anti-phase schedule).  Layout [cluster][member][pass][wave][rt][q][lane][4]: every
+        float4_t acc[4][2][4];     // [gate][hidden block of 16][batch block of 16]
+        int4q_t acq[4][2][4];      // Q8 accumulators (the unused set is dead code)
+        half8_t wf[4], xq[4];
+        float4_t cpre[4][2];       // [batch block][hidden block]
+        // ---- gates of one pass (gp, time index gt): the lane holds, for batch row bb * 16 + l15 and hidden units hb * 16 + 4 lq + e,
+        // all four gate pre-activations.  Cell state: fp32, in a private scratch buffer instead of registers (the registers buy
+        // the fragment double-buffering of the anti-phase schedule).  Layout [cluster][member][pass][wave][bb][hb][lane][4]: every
         // access is one coalesced 1 KiB wave transaction; 32 KiB per workgroup and pass.
         auto gates = [&](int gp, int gt, bool gfirst, unsigned long long gvm) __attribute__((always_inline)) {
             if (gfirst || (DBG & 128)) {   // zero initial state (nn/LSTMStack.cpp:29-41: no h0 / c0 given); DBG 128: ablation, no c loads
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
+                for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) cpre[rt][q] = (float4_t)(0.0f);
+                    for (int hb = 0; hb < 2; ++hb) cpre[bb][hb] = (float4_t)(0.0f);
             } else {
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
+                for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        cpre[rt][q] = *((const float4_t *)(cbuf + ((((((size_t)cl * KCL + j) * 2 + gp) * 8 + wave) * 2 + rt) * 4 + q) * 256) + lane);
+                    for (int hb = 0; hb < 2; ++hb)
+                        cpre[bb][hb] = *((const float4_t *)(cbuf + ((((((size_t)cl * KCL + j) * 2 + gp) * 8 + wave) * 4 + bb) * 2 + hb) * 256) + lane);
             }
-
-// ---- gates of this pass: D row = hidden (r&3) + 8 (r>>2) + 4 lhi, D col = batch row l31.
-            // Cell state: fp32, in a private scratch buffer instead of registers (64 registers per
-            // lane buy the fragment double-buffering of the anti-phase schedule).  Layout
-            // [cluster][member][pass][wave][rt][q][lane][4]: every access is one coalesced 1 KiB wave
-            // transaction; 32 KiB per workgroup and pass.
             const int hcol = j * 128 + gp * 64 + hg * 32;
             const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
                     (void *)(Xout + ((size_t)gt * N + n0 + rgw * 64) * C + hcol), 0, 64 * C * 2, 0x00020000);
@@ -255,49 +256,52 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
             const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
                     (void *)((Q8 == 2 ? Hx : (signed char *)Xout) + ((size_t)gt * N + n0 + rgw * 64) * C + hcol), 0, 64 * C, 0x00020000);
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                int pkq[4] = {0, 0, 0, 0};
-                const bool rowon = !MASKED || ((gvm >> (rt * 32 + l31)) & 1ull);
+            for (int rt = 0; rt < 2; ++rt) {          // 32 batch rows at a time through the wave's patch
+                int pkq[2][2] = {{0, 0}, {0, 0}};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    half4_t hv;
-                    float4_t cn;
-                    float4_t dq[4];      // Q8: dequantisation factors of this lane's 4 hidden units, per gate
-                    int pk = 0;          // Q8: round(127 h) of the 4 units, one byte each (kept in pkq[q] for the int8 round)
-                    if (Q8) {
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    const int bb = rt * 2 + b2;
+                    const bool rowon = !MASKED || ((gvm >> (bb * 16 + l15)) & 1ull);
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) dq[g] = *(LDSP(const float4_t))(deq_s + ((gp * 2 + hg) * 4 + g) * 32 + 4 * lhi + 8 * q);
-                    }
+                    for (int hb = 0; hb < 2; ++hb) {
+                        half4_t hv;
+                        float4_t cn;
+                        float4_t dq[4];      // Q8: dequantisation factors of this lane's 4 hidden units, per gate
+                        int pk = 0;          // Q8: round(127 h) of the 4 units, one byte each
+                        if (Q8) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = q * 4 + e;
-                        float c, hval;
-                        if (DBG & 1) {
-                            c = cpre[rt][q][e];
-                            hval = 1e-3f * (acc[0][rt][r] + acc[1][rt][r] + acc[2][rt][r] + acc[3][rt][r]);
-                        } else {
-                            const float p0 = Q8 ? (float)acq[0][rt][r] * dq[0][e] : acc[0][rt][r];
-                            const float p1 = Q8 ? (float)acq[1][rt][r] * dq[1][e] : acc[1][rt][r];
-                            const float p2 = Q8 ? (float)acq[2][rt][r] * dq[2][e] : acc[2][rt][r];
-                            const float p3 = Q8 ? (float)acq[3][rt][r] * dq[3][e] : acc[3][rt][r];
-                            const float ig = fast_sigmoid(p0);
-                            const float fg = fast_sigmoid(p1);
-                            const float gg = fast_tanh(p2);
-                            const float og = fast_sigmoid(p3);
-                            c = fmaf(fg, cpre[rt][q][e], ig * gg);
-                            hval = og * fast_tanh(c);
+                            for (int g = 0; g < 4; ++g) dq[g] = *(LDSP(const float4_t))(deq_s + ((gp * 2 + hg) * 4 + g) * 32 + hb * 16 + 4 * lq);
                         }
-                        if (MASKED && !rowon) {
-                            c = 0.0f;
-                            hval = 0.0f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float c, hval;
+                            if (DBG & 1) {
+                                c = cpre[bb][hb][e];
+                                hval = 1e-3f * (acc[0][hb][bb][e] + acc[1][hb][bb][e] + acc[2][hb][bb][e] + acc[3][hb][bb][e]);
+                            } else {
+                                const float p0 = Q8 ? (float)acq[0][hb][bb][e] * dq[0][e] : acc[0][hb][bb][e];
+                                const float p1 = Q8 ? (float)acq[1][hb][bb][e] * dq[1][e] : acc[1][hb][bb][e];
+                                const float p2 = Q8 ? (float)acq[2][hb][bb][e] * dq[2][e] : acc[2][hb][bb][e];
+                                const float p3 = Q8 ? (float)acq[3][hb][bb][e] * dq[3][e] : acc[3][hb][bb][e];
+                                const float ig = fast_sigmoid(p0);
+                                const float fg = fast_sigmoid(p1);
+                                const float gg = fast_tanh(p2);
+                                const float og = fast_sigmoid(p3);
+                                c = fmaf(fg, cpre[bb][hb][e], ig * gg);
+                                hval = og * fast_tanh(c);
+                            }
+                            if (MASKED && !rowon) {
+                                c = 0.0f;
+                                hval = 0.0f;
+                            }
+                            cn[e] = c;
+                            hv[e] = (half_t)hval;
+                            if (Q8) pk |= ((int)__builtin_rintf(hval * 127.0f) & 0xff) << (8 * e);
                         }
-                        cn[e] = c;
-                        hv[e] = (half_t)hval;
-                        if (Q8) pk |= ((int)__builtin_rintf(hval * 127.0f) & 0xff) << (8 * e);
+                        *((float4_t *)(cbuf + ((((((size_t)cl * KCL + j) * 2 + gp) * 8 + wave) * 4 + bb) * 2 + hb) * 256) + lane) = cn;
+                        if (Q8 != 1) *(LDSP(half4_t))(patch + (b2 * 16 + l15) * CL_PATCH_LD + hb * 16 + 4 * lq) = hv;
+                        if (Q8) pkq[b2][hb] = pk;
                     }
-                    *((float4_t *)(cbuf + ((((((size_t)cl * KCL + j) * 2 + gp) * 8 + wave) * 2 + rt) * 4 + q) * 256) + lane) = cn;
-                    if (Q8 != 1) *(LDSP(half4_t))(patch + l31 * CL_PATCH_LD + 8 * q + 4 * lhi) = hv;
-                    if (Q8) pkq[q] = pk;
                 }
                 __builtin_amdgcn_wave_barrier();   // same wave: LDS operations execute in order
                 if (Q8 != 1) {
@@ -313,7 +317,9 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
                 if (Q8) {   // int8 rows of 32 bytes: one 16-byte piece per lane (the exchange: write-through)
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) *(LDSP(int))(qpatch + l31 * CL_QPATCH_LD + 8 * q + 4 * lhi) = pkq[q];
+                    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                        for (int hb = 0; hb < 2; ++hb) *(LDSP(int))(qpatch + (b2 * 16 + l15) * CL_QPATCH_LD + hb * 16 + 4 * lq) = pkq[b2][hb];
                     __builtin_amdgcn_wave_barrier();
                     const int prow = lane >> 1, seg = lane & 1;
                     const int4q_t v = *(LDSP(const int4q_t))(qpatch + prow * CL_QPATCH_LD + seg * 16);
@@ -323,7 +329,6 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-        
         };
         // pass whose gates group A still owes (it runs them behind L(0) of the NEXT pass, i.e. beside group B's last
         // M + gates of that pass, which come half a slab later by construction, instead of before them)
@@ -409,14 +414,15 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
                         LDSP(const half_t) sp = stage + slot * CL_STAGE;
                         if (DBG & 16) {
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) wf[g] = (half8_t)((half_t)(0.001f * (g + 1)));
-                            xa[0] = (half8_t)((half_t)0.002f);
-                            xa[1] = (half8_t)((half_t)0.003f);
-                        } else {
+                            for (int a = 0; a < 4; ++a) wf[a] = (half8_t)((half_t)(0.001f * (a + 1)));
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) wf[g] = *(LDSP(const half8_t))(sp + woff + g * 32 * CL_BK + c0);
-                            xa[0] = *(LDSP(const half8_t))(sp + xoff + c0);
-                            xa[1] = *(LDSP(const half8_t))(sp + xoff + 32 * CL_BK + c0);
+                            for (int bb = 0; bb < 4; ++bb) xq[bb] = (half8_t)((half_t)(0.002f + 0.001f * bb));
+                        } else {
+                            // gate-row blocks 0-3 (= gates 0, 1 x hidden blocks 0, 1) and the four batch blocks of the slab
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) wf[a] = *(LDSP(const half8_t))(sp + woff + ((a >> 1) * 32 + (a & 1) * 16) * CL_BK);
+#pragma unroll
+                            for (int bb = 0; bb < 4; ++bb) xq[bb] = *(LDSP(const half8_t))(sp + xoff + bb * 16 * CL_BK);
                         }
                         constexpr int LA = 2;
                         const int kt = ks + LA;
@@ -446,65 +452,45 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
                         if (ks == 0) {   // first slab of a pass: accumulators start from the bias
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
-                                LDSP(const float) bp = bias_s + ((p * 2 + hg) * 4 + g) * 32 + 4 * lhi;
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const float4_t v = *(LDSP(const float4_t))(bp + 8 * q);
+                                for (int hb = 0; hb < 2; ++hb) {
+                                    LDSP(const float) bp = bias_s + ((p * 2 + hg) * 4 + g) * 32 + hb * 16 + 4 * lq;
+                                    const float4_t v = *(LDSP(const float4_t))bp;
                                     // (Q8: read the int32 words AS ints — hipcc folded bit_cast<int>(v[e]) of the float vector to
                                     // element 0 for all four e: every hidden unit of a lane started from its first unit's bias)
-                                    const int4q_t vi = *(LDSP(const int4q_t))((LDSP(const int))bp + 8 * q);
+                                    const int4q_t vi = *(LDSP(const int4q_t))((LDSP(const int))bp);
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        if (Q8) {
-                                            acq[g][0][q * 4 + e] = vi[e];
-                                            acq[g][1][q * 4 + e] = vi[e];
-                                        } else {
-                                            acc[g][0][q * 4 + e] = v[e];
-                                            acc[g][1][q * 4 + e] = v[e];
-                                        }
+                                    for (int bb = 0; bb < 4; ++bb) {
+                                        if (Q8) acq[g][hb][bb] = vi;
+                                        else acc[g][hb][bb] = v;
                                     }
                                 }
                             }
                         }
                         LDSP(const half_t) sp = stage + slot * CL_STAGE;
-                        half8_t xb[2];
-                        if (DBG & 16) {
-                            xb[0] = (half8_t)((half_t)0.004f);
-                            xb[1] = (half8_t)((half_t)0.005f);
-                        }
                         __builtin_amdgcn_s_setprio(1);
                         __builtin_amdgcn_sched_barrier(0);
+                        // 32 MFMAs per slab: gate-row block a = 2 g + hb against the four batch blocks; blocks 4-7 are fetched
+                        // in a rolling fashion behind the MFMAs that free their registers
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            if (Q8) {
-                                acq[g][0] = cl_mfma_i8(wf[g], xa[0], acq[g][0]);
-                                acq[g][1] = cl_mfma_i8(wf[g], xa[1], acq[g][1]);
-                            } else if (!(DBG & 4)) {
-                                acc[g][0] = mfma32x32x16(wf[g], xa[0], acc[g][0]);
-                                acc[g][1] = mfma32x32x16(wf[g], xa[1], acc[g][1]);
-                            } else {
-                                asm volatile("" ::"v"(wf[g]), "v"(xa[0]), "v"(xa[1]));
+                        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                            for (int bb = 0; bb < 4; ++bb) {
+                                if (Q8) acq[a >> 1][a & 1][bb] = cl_mfma_i8(wf[a], xq[bb], acq[a >> 1][a & 1][bb]);
+                                else if (!(DBG & 4)) acc[a >> 1][a & 1][bb] = cl_mfma_f16(wf[a], xq[bb], acc[a >> 1][a & 1][bb]);
+                                else asm volatile("" ::"v"(wf[a]), "v"(xq[bb]));
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                            if (!(DBG & 16)) {
-                                wf[g] = *(LDSP(const half8_t))(sp + woff + g * 32 * CL_BK + c1);
-                                if (g == 0) {
-                                    xb[0] = *(LDSP(const half8_t))(sp + xoff + c1);
-                                    xb[1] = *(LDSP(const half8_t))(sp + xoff + 32 * CL_BK + c1);
-                                }
-                            }
+                            if (!(DBG & 16)) wf[a] = *(LDSP(const half8_t))(sp + woff + ((2 + (a >> 1)) * 32 + (a & 1) * 16) * CL_BK);
                             __builtin_amdgcn_sched_barrier(0);
                         }
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            if (Q8) {
-                                acq[g][0] = cl_mfma_i8(wf[g], xb[0], acq[g][0]);
-                                acq[g][1] = cl_mfma_i8(wf[g], xb[1], acq[g][1]);
-                            } else if (!(DBG & 4)) {
-                                acc[g][0] = mfma32x32x16(wf[g], xb[0], acc[g][0]);
-                                acc[g][1] = mfma32x32x16(wf[g], xb[1], acc[g][1]);
-                            } else {
-                                asm volatile("" ::"v"(wf[g]), "v"(xb[0]), "v"(xb[1]));
+                        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                            for (int bb = 0; bb < 4; ++bb) {
+                                if (Q8) acq[2 + (a >> 1)][a & 1][bb] = cl_mfma_i8(wf[a], xq[bb], acq[2 + (a >> 1)][a & 1][bb]);
+                                else if (!(DBG & 4)) acc[2 + (a >> 1)][a & 1][bb] = cl_mfma_f16(wf[a], xq[bb], acc[2 + (a >> 1)][a & 1][bb]);
+                                else asm volatile("" ::"v"(wf[a]), "v"(xq[bb]));
                             }
                         }
                         __builtin_amdgcn_s_setprio(0);

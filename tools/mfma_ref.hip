@@ -12,8 +12,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i16v __attribute__((ext_vector_type(16)));
 
-// SHAPE 0: v_mfma_f32_16x16x32_f16   1: v_mfma_f32_32x32x16_f16   2: v_mfma_i32_16x16x64_i8
+// SHAPE 0: v_mfma_f32_16x16x32_f16   1: v_mfma_f32_32x32x16_f16   2: v_mfma_i32_16x16x64_i8   3: v_mfma_i32_32x32x32_i8
 template <int SHAPE>
 __global__ __launch_bounds__(512) void mfma_ref_kernel(const half8 *in, float *out, unsigned long long *cyc, int iters) {
     const int tid = threadIdx.x;
@@ -25,6 +26,7 @@ __global__ __launch_bounds__(512) void mfma_ref_kernel(const half8 *in, float *o
     f16v acc32[4] = {};
     f4v acc16[16] = {};
     i4v acci[16] = {};
+    i16v acci32[4] = {};
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -33,13 +35,14 @@ __global__ __launch_bounds__(512) void mfma_ref_kernel(const half8 *in, float *o
             for (int i = 0; i < 4; ++i) {
                 if (SHAPE == 1) acc32[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j], b[i], acc32[i], 0, 0, 0);
                 else if (SHAPE == 0) acc16[j * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[i], acc16[j * 4 + i], 0, 0, 0);
-                else acci[j * 4 + i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i4v, a[j]), __builtin_bit_cast(i4v, b[i]), acci[j * 4 + i], 0, 0, 0);
+                else if (SHAPE == 2) acci[j * 4 + i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i4v, a[j]), __builtin_bit_cast(i4v, b[i]), acci[j * 4 + i], 0, 0, 0);
+                else acci32[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i4v, a[j]), __builtin_bit_cast(i4v, b[i]), acci32[i], 0, 0, 0);
             }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     float s = 0;
     for (int i = 0; i < 4; ++i)
-        for (int r = 0; r < 16; ++r) s += acc32[i][r];
+        for (int r = 0; r < 16; ++r) s += acc32[i][r] + (float)acci32[i][r];
     for (int i = 0; i < 16; ++i)
         for (int r = 0; r < 4; ++r) s += acc16[i][r] + (float)acci[i][r];
     out[blockIdx.x * 512 + tid] = s;
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(512) void mfma_ref_kernel(const half8 *in, float *o
 extern "C" __attribute__((visibility("default"))) int mfma_ref_rate(int shape, double seconds, double *tflops, double *clock_ghz,
                                                                     int *launches) {
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return -(int)e_; } while (0)
-    if (shape < 0 || shape > 2 || !tflops) return -1;
+    if (shape < 0 || shape > 3 || !tflops) return -1;
     int dev = 0;
     CK(hipGetDevice(&dev));
     hipDeviceProp_t p;
@@ -78,11 +81,12 @@ extern "C" __attribute__((visibility("default"))) int mfma_ref_rate(int shape, d
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     const int iters = 100000;
-    const double flop_per_launch = (double)ncu * 8 * iters * 16 * (shape == 1 ? 2.0 * 32 * 32 * 16 : shape == 0 ? 2.0 * 16 * 16 * 32 : 2.0 * 16 * 16 * 64);
+    const double flop_per_launch = (double)ncu * 8 * iters * 16 * (shape == 1 ? 2.0 * 32 * 32 * 16 : shape == 0 ? 2.0 * 16 * 16 * 32 : shape == 2 ? 2.0 * 16 * 16 * 64 : 2.0 * 32 * 32 * 32);
     auto launch = [&](int it) {
         if (shape == 0) hipLaunchKernelGGL(mfma_ref_kernel<0>, dim3(ncu), dim3(512), 0, st, d_in, d_out, d_cyc, it);
         else if (shape == 1) hipLaunchKernelGGL(mfma_ref_kernel<1>, dim3(ncu), dim3(512), 0, st, d_in, d_out, d_cyc, it);
-        else hipLaunchKernelGGL(mfma_ref_kernel<2>, dim3(ncu), dim3(512), 0, st, d_in, d_out, d_cyc, it);
+        else if (shape == 2) hipLaunchKernelGGL(mfma_ref_kernel<2>, dim3(ncu), dim3(512), 0, st, d_in, d_out, d_cyc, it);
+        else hipLaunchKernelGGL(mfma_ref_kernel<3>, dim3(ncu), dim3(512), 0, st, d_in, d_out, d_cyc, it);
     };
     launch(iters / 10);
     CK(hipStreamSynchronize(st));
