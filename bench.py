@@ -18,6 +18,15 @@ configurations — BASELINE configs[4] is sup@v5 on 8 GPUs — timed with the sa
   roofline      dominant kernel: algorithmic MFMA flops per launch / mean launch duration measured with HIP events
                 on the engine's stream inside the timed region, against the 2.5 PFLOP/s dense f16 MFMA peak;
                 `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic_*).
+                `bare_mfma_tf` / `bare_clock_ghz` / `frac_of_bare` (round 6): the box's OWN matrix-pipe rate for the MFMA shape of
+                that kernel, measured in this process right before the timed region (tools/mfma_ref.hip: nothing but MFMAs on
+                random operands for ~1 s) — the boxes of the pool differ by 4-7 % in what their power limit lets the matrix pipe
+                sustain, `frac_of_bare` = achieved / bare_mfma_tf does not.
+  lstm_arith    (round 6) the LSTM stack of the tanh-conv LSTM models runs in int8 — the reference's own GPU arithmetic for
+                them (dorado/nn/ConvStack.cpp:69-73, nn/LSTMStack.cpp:127-211) — now that the path has a STATED identity bound on
+                a model with decision margins (tests/test_gpu_baseline_parity.py: median identity vs the f32 reference >= 0.99
+                [0.9972 hac | 0.9986 sup43], device == int8 emulation of the oracle to one f16 ulp); `dtype` "i8+f16".  The f16
+                LSTM (rounds 1-5's headline) is `extra.hac_f16` / `extra.sup_v43_f16`; --quant 0 makes it the headline again.
   parity        bench-scale output check (outside the timed region): the batch tiles 256 distinct chunks, so every
                 row must equal row i % 256, and the first rows must equal a separate small-batch call.
   cpu_baseline  the REFERENCE's own CPU path (oracle/_ref = reference sources compiled in place, libtorch CPU f32,
@@ -71,6 +80,31 @@ def pmc_traffic(kernel_substr, model, n, t_in, total=False):
             if kernel_substr in k:
                 best = {"hbm_bytes": v["hbm_bytes_corrected"], "source": os.path.relpath(path, ROOT)}
     return best
+
+
+_MFMA_REF = {}
+MFMA_SHAPES = {0: "v_mfma_f32_16x16x32_f16", 1: "v_mfma_f32_32x32x16_f16", 2: "v_mfma_i32_16x16x64_i8", 3: "v_mfma_i32_32x32x32_i8"}
+
+
+def bare_mfma(shape, seconds=1.0):
+    """The box's own matrix-pipe reference (tools/libmfma_ref.so, built by __graft_entry__.build()): TFLOP/s and shader clock of
+    nothing but MFMAs of `shape` on random operands, ~`seconds` of back-to-back launches on the current device, mean over the
+    second half (settled clock).  Cached per shape; None if the library is missing (measurement tooling, not the product)."""
+    import ctypes as C
+    if shape in _MFMA_REF:
+        return _MFMA_REF[shape]
+    res = None
+    path = os.path.join(ROOT, "tools", "libmfma_ref.so")
+    if os.path.exists(path):
+        try:
+            L = C.CDLL(path)
+            tf, ck, nl = C.c_double(), C.c_double(), C.c_int()
+            if L.mfma_ref_rate(C.c_int(shape), C.c_double(seconds), C.byref(tf), C.byref(ck), C.byref(nl)) == 0:
+                res = {"tflops": tf.value, "clock_ghz": ck.value, "launches": nl.value, "mfma": MFMA_SHAPES[shape]}
+        except OSError:
+            res = None
+    _MFMA_REF[shape] = res
+    return res
 
 
 def lstm_flops_per_launch(cfg, n, t):
@@ -287,7 +321,7 @@ def auto_batch(eng, cfg, t_in, device):
 
 
 def run_config(capi, synth, cfg, model_key, device, steps, warmup, batch=0, seed=0xD0AD0, timed_barrier=None,
-               with_cpu=False, cpu_kind="hac", check_parity=True, cpu_full=False, decode_overlap=False):
+               with_cpu=False, cpu_kind="hac", check_parity=True, cpu_full=False, decode_overlap=False, measure_bare=True):
     """Times `steps` steps of one configuration on this rank's GPU.  Returns (result dict, elapsed seconds)."""
     t_in = cfg.chunk_size
     ws = synth.make_weights(cfg, seed=42)
@@ -303,6 +337,10 @@ def run_config(capi, synth, cfg, model_key, device, steps, warmup, batch=0, seed
     eng.set_profile(1)
     if decode_overlap:
         eng.set_decode_overlap(True)
+    # the box's bare matrix-pipe rate for the dominant kernel's MFMA shape, same process, right before the timed region
+    # (LSTM kernels: 16x16x32 f16 / 16x16x64 int8; transformer: tx_layer_kernel's 32x32x16)
+    mshape = 1 if cfg.tx is not None else (2 if getattr(cfg, "lstm_quant", False) else 0)
+    bare = bare_mfma(mshape) if measure_bare else None
     for _ in range(warmup):
         eng.call_device(d_in, n, t_in, d_out)
     eng.sync()
@@ -371,6 +409,8 @@ def run_config(capi, synth, cfg, model_key, device, steps, warmup, batch=0, seed
             "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": (tr or {}).get("hbm_bytes"), "traffic_source": (tr or {}).get("source"),
             "traffic_algorithmic": alg_bytes, "launch_ms": k_ms, "flops_per_launch": fl,
+            **({"bare_mfma_tf": bare["tflops"], "bare_clock_ghz": bare["clock_ghz"], "bare_mfma": bare["mfma"],
+                "frac_of_bare": achieved / 1e12 / bare["tflops"]} if bare else {}),
         },
     }
     if with_cpu:
@@ -391,8 +431,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="chunks per GPU per step (0 = auto)")
     ap.add_argument("--model", default="hac")
-    ap.add_argument("--quant", type=int, default=0,
-                    help="1 = run --model with the opt-in int8 LSTM path (lstm_quant); for rocprofv3 / PMC passes of the int8 kernels")
+    ap.add_argument("--quant", type=int, default=-1,
+                    help="LSTM arithmetic of --model: -1 (default) = the reference's GPU rule (int8 for the tanh-conv LSTM models with "
+                         "128 < lstm_size <= 1024, nn/ConvStack.cpp:69-73), 0 = f16 LSTM, 1 = int8 LSTM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-run", action="store_true",
                     help="for rocprofv3 --stats: no small-batch parity call, so per-kernel averages are full-batch launches")
@@ -431,7 +472,13 @@ def main():
     if args.model not in factories:
         raise SystemExit(f"unknown model {args.model}")
     cfg = factories[args.model]()
-    if args.quant:
+
+    def reference_rule_int8(c):
+        """nn/ConvStack.cpp:69-73: the convolution in front of the LSTM stack writes the int8 layout (-> every LSTM layer int8,
+        nn/LSTMStack.cpp:127-211) when it ends in tanh and 128 < lstm_size <= 1024."""
+        return c.tx is None and len(c.convs) >= 3 and c.convs[-1].activation == config.ACT_TANH and 128 < c.lstm_size <= 1024
+
+    if args.quant == 1 or (args.quant < 0 and reference_rule_int8(cfg)):
         cfg.lstm_quant = True
 
     def barrier():
@@ -446,7 +493,7 @@ def main():
                                          with_cpu=single and not args.no_cpu_baseline,
                                          cpu_kind="sup" if args.model in ("sup", "sup5") else "hac",
                                          check_parity=not args.profile_run, cpu_full=args.cpu_baseline_full,
-                                         decode_overlap=bool(args.decode_overlap))
+                                         decode_overlap=bool(args.decode_overlap), measure_bare=not args.profile_run)
     if world > 1:
         tt = torch.tensor([el], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -465,10 +512,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16",
+            "dtype": "i8+f16" if getattr(cfg, "lstm_quant", False) else "f16",
             "data": "synthetic",
             "config": {
                 "workload": res["workload"],
+                "lstm_arith": ("int8 LSTM stack (weights quantised per row, round(127 v) activations, int32 accumulation; conv3's "
+                               "epilogue emits the int8 rows) = the reference's GPU arithmetic for tanh-conv LSTM models, "
+                               "dorado/nn/ConvStack.cpp:69-73 + nn/LSTMStack.cpp:127-211; everything else f16 storage / f32 accumulation"
+                               if getattr(cfg, "lstm_quant", False) else "f16 storage, f32 accumulation"),
                 "chunks_per_gpu": n, "chunk_size": t_in, "output_steps": T,
                 "parallelism": f"{world} independent per-GPU engines, no collective",
                 "bases_per_step_emitted": res["bases_per_step_emitted"],
@@ -535,19 +586,21 @@ def main():
                                                      "samples_incl_padding_per_s": tf["samples_incl_padding_per_s"],
                                                      "useful_fill": tf["samples_per_s"] / tf["samples_incl_padding_per_s"]}
                     tv["variable_over_fixed_useful_rate"] = tv["samples_per_s"] / tf["samples_per_s"]
-                    # ... and with the opt-in int8 LSTM: variable chunk sizes OVER the quantised LSTM is the reference's default
-                    # GPU mode (basecall/CudaModelRunner.cpp:21-49 + nn/LSTMStack.cpp:127-211); its own tolerance, never `value`
+                    # ... and the OTHER LSTM arithmetic on the same read set (int8 is the headline's since round 6: variable chunk
+                    # sizes over the quantised LSTM is the reference's default GPU mode, basecall/CudaModelRunner.cpp:21-49 +
+                    # nn/LSTMStack.cpp:127-211)
+                    okey = "f16_lstm_variable_chunks" if getattr(cfg, "lstm_quant", False) else "int8_lstm_variable_chunks"
                     try:
                         import copy
                         qcfg = copy.deepcopy(cfg)
-                        qcfg.lstm_quant = True
+                        qcfg.lstm_quant = not getattr(cfg, "lstm_quant", False)
                         tq = hostapi.bench_through_host_variable(qcfg, ws, sigs, lens, nwarm, device=args.host_device or f"hip:{local_rank}",
                                                                  num_runners=2, batch_size=n)
-                        tv["int8_lstm_variable_chunks"] = {"samples_per_s": tq["samples_per_s"], "seconds": tq["seconds"],
-                                                           "batches": tq["batches"],
-                                                           "samples_incl_padding_per_s": tq["samples_incl_padding_per_s"]}
+                        tv[okey] = {"samples_per_s": tq["samples_per_s"], "seconds": tq["seconds"],
+                                    "batches": tq["batches"],
+                                    "samples_incl_padding_per_s": tq["samples_incl_padding_per_s"]}
                     except Exception as ex:
-                        tv["int8_lstm_variable_chunks"] = {"error": repr(ex)}
+                        tv[okey] = {"error": repr(ex)}
                     tv["what"] = (f"{len(lens) - nwarm} reads, lengths log-normal(median 6000, sigma 0.9) + uniform 300..3000, "
                                   f"{float(lens[nwarm:].mean()):.0f} samples on average, cut by generate_variable_chunks, first-fit "
                                   f"row packing, mibc_call_var_async with two batches in flight; samples_per_s = read samples "
@@ -564,10 +617,14 @@ def main():
             # failed or not.  The headline `value` above keeps the contract's barrier rule.
             err, r2, el2, n2, t_in2 = None, None, 0.0, 0, 0
             try:
-                r2, el2, n2, _, t_in2, _ = run_config(capi, synth, fac(), mk, local_rank, st, 1, 0, seed=7 + rank,
+                c2 = fac()
+                if args.quant == 1 or (args.quant < 0 and reference_rule_int8(c2)):
+                    c2.lstm_quant = True           # the same LSTM-arithmetic rule as the headline
+                r2, el2, n2, _, t_in2, _ = run_config(capi, synth, c2, mk, local_rank, st, 1, 0, seed=7 + rank,
                                                       timed_barrier=None,
                                                       with_cpu=single and not args.no_cpu_baseline, cpu_kind="sup",
                                                       check_parity=single, cpu_full=args.cpu_baseline_full)
+                r2["dtype"] = "i8+f16" if getattr(c2, "lstm_quant", False) else "f16"
             except Exception as ex:
                 err = repr(ex)
             if world > 1:
@@ -577,27 +634,24 @@ def main():
                     err = err or "another rank failed"
                 elif r2 is not None:
                     el2 = float(tt[0].item())
-                    r2 = {"workload": r2["workload"], "n_gpus": world, "scaling": "weak", "steps": st,
+                    r2 = {"workload": r2["workload"], "n_gpus": world, "scaling": "weak", "steps": st, "dtype": r2["dtype"],
                           "samples_per_s": float(world) * n2 * t_in2 * st / el2, "ms_per_step": el2 / st * 1e3,
                           "chunks_per_gpu": n2, "rank0_roofline": r2["roofline"]}
             extra[key] = {"error": err} if err else r2
         if single:
-            # the opt-in int8 LSTM path (the reference's quantised path) on the headline workload: reported beside the f16
-            # headline, never as `value` (its tolerance is its own: tests/test_gpu_baseline_parity.py)
-            try:
-                qcfg = config.hac_v43()
-                qcfg.lstm_quant = True
-                r3, _, _, _, _, _ = run_config(capi, synth, qcfg, "hac", local_rank, 3, 1, 0, seed=0xD0AD0, with_cpu=False)
-                extra["hac_int8_lstm"] = r3
-            except Exception as ex:
-                extra["hac_int8_lstm"] = {"error": repr(ex)}
-            try:   # the same for the sup@v4.3 shape: the int8 instance of the cluster LSTM kernel (round 4)
-                qcfg = config.sup_v43()
-                qcfg.lstm_quant = True
-                r4, _, _, _, _, _ = run_config(capi, synth, qcfg, "sup", local_rank, 3, 1, 0, seed=7, with_cpu=False)
-                extra["sup_v43_int8_lstm"] = r4
-            except Exception as ex:
-                extra["sup_v43_int8_lstm"] = {"error": repr(ex)}
+            # the OTHER LSTM arithmetic of the two LSTM configurations, beside the lines above: with the default rule (int8, the
+            # reference's GPU arithmetic) these are the f16-LSTM lines that were the headline / extra.sup_v43 of rounds 1-5
+            for okey, mk, fac, seed in (("hac", "hac", config.hac_v43, 0xD0AD0), ("sup_v43", "sup", config.sup_v43, 7)):
+                qcfg = fac()
+                head_q = args.quant == 1 or (args.quant < 0 and reference_rule_int8(qcfg))
+                qcfg.lstm_quant = not head_q
+                name = okey + ("_f16" if head_q else "_int8_lstm")
+                try:
+                    r3, _, _, _, _, _ = run_config(capi, synth, qcfg, mk, local_rank, 3, 1, 0, seed=seed, with_cpu=False)
+                    r3["dtype"] = "i8+f16" if qcfg.lstm_quant else "f16"
+                    extra[name] = r3
+                except Exception as ex:
+                    extra[name] = {"error": repr(ex)}
         if rank == 0:
             line["extra"] = extra
     # north_star's multi-GPU shape is ONE process driving every device (one HipCaller per device fed from shared chunk
