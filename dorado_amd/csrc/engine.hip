@@ -330,7 +330,9 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
             // cluster kernel (lstm_cluster.hip): member j of a cluster owns hidden units [128 j, 128 j + 128); its
             // weight slab (pass p, k-slab ks) is stored as the exact LDS image it is DMA'd into: 256 gate rows
             // [hidden group hg][gate g][32 units] x 32 k, 64-byte rows with the 16-byte column XOR-swizzled by
-            // (row >> 2) & 3 (the read side applies the same XOR)
+            // (-(row >> 2)) & 3 (the read side applies the same XOR; round 6: the swizzle that is conflict-free for the lane groups
+            // of a ds_read_b128 under the 16x16x32 fragment mapping — (row >> 2) & 3, right for the 32x32x16 mapping, is 2-way
+            // conflicted there: SQ_LDS_BANK_CONFLICT 0.22 of the CU's cycles, profiles/r06_e_pmc_clock_sup_n8192.json)
             const int KCL = C / 128, KSL = 2 * C / 32;
             std::vector<half_t> wcl((size_t)4 * C * 2 * C);
             std::vector<float> bcl((size_t)4 * C);
@@ -349,7 +351,7 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
                                 wcl[((size_t)(jm * 2 + p) * 256 + row) * 2 * C + k] = (half_t)v;
 #else
                                 half_t *dst = wcl.data() + ((((size_t)(jm * 2 + p)) * KSL + ks) * 256 + row) * 32;
-                                dst[(((kk >> 3) ^ ((row >> 2) & 3)) << 3) + (kk & 7)] = (half_t)v;
+                                dst[(((kk >> 3) ^ ((0 - (row >> 2)) & 3)) << 3) + (kk & 7)] = (half_t)v;
 #endif
                             }
                         }
@@ -391,7 +393,7 @@ extern "C" int mibc_create(int device_id, const mibc_model_desc *desc, const flo
 #else
                                 int8_t *dst = wclq.data() + ((((size_t)(jm * 2 + p)) * KSQ + ks) * 256 + row) * 64;
                                 for (int kk = 0; kk < 64; ++kk)
-                                    dst[(((kk >> 4) ^ ((row >> 2) & 3)) << 4) + (kk & 15)] = qrow[G * 2 * C + (size_t)ks * 64 + kk];
+                                    dst[(((kk >> 4) ^ ((0 - (row >> 2)) & 3)) << 4) + (kk & 15)] = qrow[G * 2 * C + (size_t)ks * 64 + kk];
 #endif
                             }
                         }

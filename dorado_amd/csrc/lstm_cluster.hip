@@ -135,12 +135,12 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
     const int nclusters = N / CL_ROWS;
 
     // DMA assignment: instruction q of this wave fills 16-byte slots [(wave*2+q)*64, +64) of a slab:
-    // row = (wave*2+q)*16 + lane/4, physical 16-byte column lane%4 <- logical column (lane%4) ^ ((row>>2)&3)
+    // row = (wave*2+q)*16 + lane/4, physical 16-byte column lane%4 <- logical column (lane%4) ^ ((-(row>>2))&3)
     unsigned aoff[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int row = (wave * 2 + q) * 16 + (lane >> 2);
-        const int col = (lane & 3) ^ ((row >> 2) & 3);
+        const int col = (lane & 3) ^ ((0 - (row >> 2)) & 3);
         aoff[q] = (unsigned)(row * C * EB + col * 16);       // bytes
     }
 
@@ -153,7 +153,10 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
     bool dead = false;
 
     const bool grpB = wave >= 4;
-    const int sw = (l15 >> 2) & 3;              // (row >> 2) & 3 for every fragment row of this lane
+    // XOR swizzle of the 16-byte column: (-(row >> 2)) & 3 — the four 16-lane groups a ds_read_b128 is serviced in
+    // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ... MI355X_MICROARCH.md, LDS) then touch 16 distinct bank quads each under the
+    // 16x16x32 fragment mapping (lane = row & 15 | k-group << 4); every fragment row of this lane has the same (row >> 2) & 3
+    const int sw = (0 - (l15 >> 2)) & 3;
     const int cq = (lq ^ sw) << 3;              // physical 16-byte column of this lane's k-group (halfs)
     // fragment read bases of this lane inside a stage (halfs): gate-row block (g, hb) at + (g * 32 + hb * 16) rows, batch block bb at + 16 bb rows
     const int woff = (hg * 128 + l15) * CL_BK + cq, xoff = CL_WTILE + (rgw * 64 + l15) * CL_BK + cq;

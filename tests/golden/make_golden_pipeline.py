@@ -22,6 +22,7 @@ from dorado_amd import config, synth  # noqa: E402
 
 STANDARDISATION = (True, 91.88, 22.65)     # dna_r10.4.1_e8.2_400bps_hac@v4.3.0/config.toml [standardisation]
 FLOW_CELL = "FLO-PRO114M"
+EXPECTED_OPEN_PORE = 199.21                  # ScalerNode.cpp:112-139 for that flow cell
 WEIGHT_SEED, READ_SEED = 42, 0x91BE
 
 
@@ -41,7 +42,10 @@ def pipeline_reads():
         offset = float(rng.integers(-260, -200))
         opl = float(rng.uniform(190.0, 210.0))
         x = synth.make_base_signal(1, n, seed=READ_SEED + 1 + i)[0].astype(np.float32)
-        pa = STANDARDISATION[1] + STANDARDISATION[2] * x
+        # a pore whose open-pore level sits above / below the flow cell's expected one (FLO-PRO114M: 199.21 pA) shifts every level
+        # by the same amount — the shift ScalerNode's open-pore adjustment takes out again (ScalerNode.cpp:205-213); round 6: the
+        # margin model reads LEVELS, so the synthetic read has to obey that physics (the random model of round 5 did not care)
+        pa = STANDARDISATION[1] + STANDARDISATION[2] * x + (opl - EXPECTED_OPEN_PORE)
         raws.append(np.clip(np.round(pa / scaling - offset), -32768, 32767).astype(np.int16))
         cal.append((scaling, offset, opl))
     return raws, np.array(cal, np.float32)
