@@ -21,6 +21,7 @@
 #endif
 typedef int int4v __attribute__((ext_vector_type(4)));
 typedef float float4q __attribute__((ext_vector_type(4)));
+typedef float float2q __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int4v q8_wload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
     return __builtin_bit_cast(int4v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
@@ -67,9 +68,15 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_q8_kernel(
     const int n0 = blockIdx.x * NB;
 
     for (int i = tid; i < NB * LDB / 16; i += NT) ((int4v *)hbuf0)[i] = (int4v)(0);
+    // gate pre-activations are only ever used as exp2 arguments: sigmoid(p) = 1 / (1 + 2^(-log2e p)), tanh(p) = 2 / (1 + 2^(-2 log2e p)) - 1,
+    // so bias and dequantisation factor are stored pre-multiplied by -log2e (gates i, f, o) / -2 log2e (gate g; order
+    // [(hidden / 32)][gate][32]) and the fma that dequantises an accumulator yields the exp2 argument directly (round 6: the
+    // kernel is bound by the vector-instruction count of this gate math, not by the matrix pipe — 33 + 10 quarter-rate
+    // instructions per element against 12 MFMA cycles; profiles/r06_e_pmc_clock_hac_q8_n16384.json)
     for (int i = tid; i < 4 * C; i += NT) {
-        bias_s[i] = biasn[i];
-        deq_s[i] = deqn[i];
+        const float k = (((i >> 5) & 3) == 2) ? -2.88539008f : -1.44269504f;
+        bias_s[i] = biasn[i] * k;
+        deq_s[i] = deqn[i] * k;
     }
 
     float4q cst[HT][4];
@@ -159,21 +166,39 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_q8_kernel(
             for (int rt = 0; rt < 4; ++rt) {
                 half4_t hv;
                 int pk = 0;
+                // two hidden units at a time on the packed-f32 pipe (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two elements per
+                // issue slot); only the conversions and the ten transcendentals per element stay scalar
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float ig = fast_sigmoid(fmaf((float)acc[0][rt][r], dv[0][r], bv[0][r]));
-                    const float fg = fast_sigmoid(fmaf((float)acc[1][rt][r], dv[1][r], bv[1][r]));
-                    const float gg = fast_tanh(fmaf((float)acc[2][rt][r], dv[2][r], bv[2][r]));
-                    const float og = fast_sigmoid(fmaf((float)acc[3][rt][r], dv[3][r], bv[3][r]));
-                    float c = fmaf(fg, cst[jj][rt][r], ig * gg);
-                    float hval = og * fast_tanh(c);
-                    if (MASKED && !((vm >> (rt * 16 + l15)) & 1ull)) {
-                        c = 0.0f;
-                        hval = 0.0f;
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    float2q e[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float2q a = {(float)acc[g][rt][2 * h2], (float)acc[g][rt][2 * h2 + 1]};
+                        const float2q dq = {dv[g][2 * h2], dv[g][2 * h2 + 1]};
+                        const float2q bb = {bv[g][2 * h2], bv[g][2 * h2 + 1]};
+                        const float2q x = __builtin_elementwise_fma(a, dq, bb);                 // the exp2 argument (pre-scaled)
+                        const float2q ex = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                        const float2q d = ex + (float2q)(1.0f);
+                        e[g] = (float2q){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
                     }
-                    cst[jj][rt][r] = c;
-                    pk |= (q8_quant(hval) & 0xff) << (8 * r);
-                    hv[r] = (half_t)hval;
+                    const float2q gg = __builtin_elementwise_fma(e[2], (float2q)(2.0f), (float2q)(-1.0f));
+                    const float2q cprev = {cst[jj][rt][2 * h2], cst[jj][rt][2 * h2 + 1]};
+                    float2q c = __builtin_elementwise_fma(e[1], cprev, e[0] * gg);
+                    const float2q xc = c * (float2q)(-2.88539008f);
+                    const float2q dc = (float2q){__builtin_amdgcn_exp2f(xc[0]), __builtin_amdgcn_exp2f(xc[1])} + (float2q)(1.0f);
+                    const float2q rc = {__builtin_amdgcn_rcpf(dc[0]), __builtin_amdgcn_rcpf(dc[1])};
+                    float2q hval = e[3] * __builtin_elementwise_fma(rc, (float2q)(2.0f), (float2q)(-1.0f));
+                    if (MASKED && !((vm >> (rt * 16 + l15)) & 1ull)) {
+                        c = (float2q)(0.0f);
+                        hval = (float2q)(0.0f);
+                    }
+                    cst[jj][rt][2 * h2] = c[0];
+                    cst[jj][rt][2 * h2 + 1] = c[1];
+                    const float2q hq = hval * (float2q)(127.0f);
+                    pk |= ((int)__builtin_rintf(hq[0]) & 0xff) << (16 * h2);
+                    pk |= ((int)__builtin_rintf(hq[1]) & 0xff) << (16 * h2 + 8);
+                    hv[2 * h2] = (half_t)hval[0];
+                    hv[2 * h2 + 1] = (half_t)hval[1];
                 }
                 *(int *)(hnext + (rt * 16 + l15) * LDB + j * 16 + 4 * lq) = pk;
                 if (OUT_F16) *(half4_t *)(hout + (rt * 16 + l15) * LDH + j * 16 + 4 * lq) = hv;

@@ -33,6 +33,39 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     assert set(declared) <= set(dbg) and all(n.startswith("mibc_debug_") for n in set(dbg) - set(declared))
 
 
+def test_library_build_id_is_the_hash_of_the_tree():
+    """libmibc.so / libmibc_dbg.so carry a hash of every source they were compiled from (mibc_build_id,
+    tools/build_id.py via the Makefile); tests/conftest.py ends the session when it is not the tree's.  Here: the ids agree, and
+    the hash really covers the sources (a changed byte changes it)."""
+    import ctypes
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("build_id", os.path.join(ROOT, "tools", "build_id.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = mod.build_id()
+    assert re.fullmatch(r"[0-9a-f]{16}", want)
+    assert capi.lib().mibc_build_id().decode() == want
+    dbg = ctypes.CDLL(capi.DBG_LIB_PATH)
+    dbg.mibc_build_id.restype = ctypes.c_char_p
+    assert dbg.mibc_build_id().decode() == want + "-dbg"
+    files = mod.source_files()
+    assert any(f.endswith("engine.hip") for f in files) and any(f.endswith("mibc.h") for f in files) and len(files) >= 20
+    real_open = open
+
+    def patched(path, *a, **k):      # the same tree with one byte appended to one kernel source
+        fh = real_open(path, *a, **k)
+        if str(path).endswith("decode.hip") and "b" in (a[0] if a else k.get("mode", "")):
+            import io
+            return io.BytesIO(fh.read() + b" ")
+        return fh
+    import builtins
+    builtins.open, saved = patched, builtins.open
+    try:
+        assert mod.build_id() != want
+    finally:
+        builtins.open = saved
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     if capi.device_count() > 0:
         pytest.skip("GPU present")
