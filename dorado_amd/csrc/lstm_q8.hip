@@ -16,6 +16,9 @@
 #include "common.h"
 #include "engine.h"
 
+#ifndef Q8_STAGGER_DEFAULT
+#define Q8_STAGGER_DEFAULT 0
+#endif
 #ifndef Q8_NT_DEFAULT
 #define Q8_NT_DEFAULT 1   // measured: LSTM stack 195.1 -> 186.1 ms on the hac batch (profiles/r05_i_nt_ab_wsgemm_q8.log)
 #endif
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_q8_kernel(
         const int8_t *__restrict__ Wq,    // [C/16][2C/64][4][64][16]: lane (l15, lq): row g C + 16 j + l15, k = 64 ks + 16 lq ..
         const float *__restrict__ biasn,  // [4C]: [(hidden/32)][4][32]  (b_ih + b_hh)
         const float *__restrict__ deqn,   // [4C]: same order, 1 / (127 * row scale)
-        int T, int N, int reverse, const unsigned long long *__restrict__ tmask = nullptr) {
+        int T, int N, int reverse, const unsigned long long *__restrict__ tmask = nullptr, int stagger = 0) {
     constexpr int NB = 64;
     constexpr int NT = 512;
     constexpr int HT = C / 16 / 8;    // 16-unit hidden tiles per wave
@@ -115,6 +118,11 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_q8_kernel(
 
         unsigned long long vm = ~0ull;
         if (MASKED) vm = tmask[(size_t)t * gridDim.x + blockIdx.x];
+        // SIMD partners in anti-phase: waves w and w + 4 share a SIMD and, left alone, run their k-loops (matrix pipe) and their
+        // gate math (vector pipe) at the same time, so the two pipes take turns.  Waves 4-7 start the step `stagger` x 64 cycles late
+        // (about one k-loop): from then on one partner's gates run under the other's MFMAs.
+        if (stagger > 0 && wave >= 4)
+            for (int d = 0; d < stagger; ++d) __builtin_amdgcn_s_sleep(1);
         int4v xpf[XPF];
         {
             const int8_t *xg = Xin + ((size_t)tn * N + n0) * C;
@@ -271,11 +279,12 @@ extern "C" int mibc_launch_lstm_layer_q8(hipStream_t s, int C, const int8_t *Xin
     if (N % 64 != 0 || Wq == nullptr) return 1;
     dim3 grid(N / 64);
     static const int q8_nt = MIBC_ENV_INT("MIBC_Q8_NT", Q8_NT_DEFAULT);   // (debug build: A/B switch)
+    static const int q8_stagger = MIBC_ENV_INT("MIBC_Q8_STAGGER", Q8_STAGGER_DEFAULT);
 #define Q8N(CC, PF_, O_, M_, X_)                                                                                         \
     do {                                                                                                                 \
         MIBC_LDS_ATTR_ONCE((lstm_layer_q8_kernel<CC, PF_, O_, M_, X_>), (q8_lds_bytes<CC, O_>()));                       \
         hipLaunchKernelGGL((lstm_layer_q8_kernel<CC, PF_, O_, M_, X_>), grid, dim3(512), (q8_lds_bytes<CC, O_>()), s, Xin, Xout, Wq, \
-                           biasn, deqn, T, N, reverse, tmask);                                                           \
+                           biasn, deqn, T, N, reverse, tmask, q8_stagger);                                               \
         return 0;                                                                                                        \
     } while (0)
 #define Q8(CC, PF_, O_, M_)                                                                                              \
