@@ -479,9 +479,7 @@ def main():
     cfg = factories[args.model]()
 
     def reference_rule_int8(c):
-        """nn/ConvStack.cpp:69-73: the convolution in front of the LSTM stack writes the int8 layout (-> every LSTM layer int8,
-        nn/LSTMStack.cpp:127-211) when it ends in tanh and 128 < lstm_size <= 1024."""
-        return c.tx is None and len(c.convs) >= 3 and c.convs[-1].activation == config.ACT_TANH and 128 < c.lstm_size <= 1024
+        return c.reference_gpu_lstm_int8()       # nn/ConvStack.cpp:60-89, restated in dorado_amd/config.py
 
     if args.quant == 1 or (args.quant < 0 and reference_rule_int8(cfg)):
         cfg.lstm_quant = True

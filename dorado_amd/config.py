@@ -172,6 +172,14 @@ class ModelConfig:
     def num_states(self) -> int:
         return 4 ** self.state_len
 
+    def reference_gpu_lstm_int8(self) -> bool:
+        """The LSTM arithmetic the reference's GPU build picks for this model (nn/ConvStack.cpp:60-89 get_koi_lstm_input_layout):
+        the convolution in front of the LSTM stack writes the int8 layout — every LSTM layer int8, nn/LSTMStack.cpp:127-211 — when
+        it ends in tanh and 128 < lstm_size <= 1024, lstm_size % 128 == 0.  (integration/HipModelRunnerAdapter.h restates it in
+        C++ incl. the DORADO_LSTM_MODE override; bench.py uses it to pick the headline arithmetic.)"""
+        return (self.tx is None and len(self.convs) >= 3 and self.lstm_layers >= 2 and self.convs[-1].activation == ACT_TANH
+                and 128 < self.lstm_size <= 1024 and self.lstm_size % 128 == 0)
+
     def normalise_basecaller_params(self) -> None:
         """BatchParams::normalise (BatchParams.cpp:89-105): overlap -> multiple of stride,
         chunk -> multiple of the granularity (= stride for LSTM models)."""

@@ -67,7 +67,10 @@ typedef struct mibc_model_desc {
      * lstm_size 128 / 256 / 384 (any batch) or 512 / 768 / 1024 (batches that are multiples of 256: mibc_batch_granularity()
      * reports 256 then) and >= 2 layers; combinable with variable chunks (mibc_*_var: masked instances of the same kernels —
      * the reference's default GPU mode is both at once, basecall/CudaModelRunner.cpp:21-49).
-     * 0 (default): f16 throughout — the path the parity contract is stated for. */
+     * 0: f16 throughout.  Which of the two a model gets by default is the CALLER's rule: the reference-side binding
+     * (integration/HipModelRunnerAdapter.h mibc_desc_from_config) and bench.py apply the reference's own
+     * (nn/ConvStack.cpp:60-89: int8 for tanh-conv models with 128 < lstm_size <= 1024), both arithmetics have a stated parity
+     * contract. */
     int lstm_quant;
 } mibc_model_desc;
 

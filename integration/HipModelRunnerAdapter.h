@@ -27,9 +27,29 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 namespace dorado::basecall {
+
+// The LSTM arithmetic the reference's own GPU build runs this model in (round 6: the default here too — the int8 path has a stated
+// identity bound): nn/ConvStack.cpp:60-89 get_koi_lstm_input_layout — the convolution in front of the LSTM stack writes
+// the CUTLASS_TNC_I8 layout (=> every LSTM layer int8, nn/LSTMStack.cpp:127-211) when it ends in tanh and 128 < lstm_size <= 1024,
+// lstm_size % 128 == 0; the reference's override DORADO_LSTM_MODE is honoured the same way (CUTLASS_TNC_F16 / CUBLAS_TN2C: f16;
+// CUTLASS_TNC_I8 on a model the rule would run in f16: int8 from the second layer on).
+inline bool mibc_reference_lstm_int8(const config::BasecallModelConfig &c) {
+    if (c.tx.has_value() || c.convs.size() < 3 || c.lstm_layers < 2) return false;
+    const int C = c.lstm_size;
+    const bool cutlass_shape = C <= 1024 && C > 128 && (C % 128) == 0;
+    bool int8 = cutlass_shape && c.convs.back().activation == config::Activation::TANH;
+    if (const char *env = std::getenv("DORADO_LSTM_MODE")) {
+        const std::string m(env);
+        if (m == "CUBLAS_TN2C" || m == "CUTLASS_TNC_F16") int8 = false;
+        else if (m == "CUTLASS_TNC_I8" && cutlass_shape) int8 = true;
+    }
+    return int8;
+}
 
 // config::BasecallModelConfig -> the plain C descriptor of include/mibc.h
 inline mibc_model_desc mibc_desc_from_config(const config::BasecallModelConfig &c) {
@@ -71,6 +91,7 @@ inline mibc_model_desc mibc_desc_from_config(const config::BasecallModelConfig &
         d.state_len = t.crf.state_len;
         d.outsize = t.crf.outsize();
     }
+    d.lstm_quant = mibc_reference_lstm_int8(c) ? 1 : 0;
     return d;
 }
 

@@ -87,8 +87,12 @@ def test_adapter_through_reference_interface(pipeline, model):
 
 @needs_so
 @pytest.mark.gpu
-def test_adapter_variable_chunks_through_reference_interface():
-    """BasecallerCreationParams::variable_chunk_sizes = true: variable_chunk_sizes() is reported, chunks of any
+@pytest.mark.parametrize("lstm_mode", ["CUTLASS_TNC_F16", None])
+def test_adapter_variable_chunks_through_reference_interface(lstm_mode, monkeypatch):
+    """lstm_mode: the reference's DORADO_LSTM_MODE override (nn/ConvStack.cpp:76-88), which the adapter honours; None = the
+    reference's rule (round 6: this tanh-conv lstm_size-256 model then runs its LSTM stack in int8, nn/ConvStack.cpp:69-73 —
+    variable chunk sizes over the int8 LSTM is the reference's default GPU mode).
+    BasecallerCreationParams::variable_chunk_sizes = true: variable_chunk_sizes() is reported, chunks of any
     stride-multiple length go in through accept_chunk (index ignored, CudaModelRunner.cpp:21-32) and come back from one
     call_chunks in order; every chunk must equal the engine's call of that chunk ALONE (zero state, zero padding)."""
     L = _load()
@@ -97,6 +101,12 @@ def test_adapter_variable_chunks_through_reference_interface():
     cfg.chunk_size, cfg.overlap = 1200, 120
     cfg.normalise_basecaller_params()
     ws = [np.ascontiguousarray(w, np.float32) for w in synth.make_weights(cfg, seed=71)]
+    if lstm_mode is None:
+        monkeypatch.delenv("DORADO_LSTM_MODE", raising=False)
+        assert cfg.reference_gpu_lstm_int8()
+        cfg.lstm_quant = True               # what the adapter's descriptor will say; the stand-alone calls below use the same
+    else:
+        monkeypatch.setenv("DORADO_LSTM_MODE", lstm_mode)
     stride, t_in, batch = cfg.stride, cfg.chunk_size, 64
     rng = np.random.default_rng(5)
     # > batch chunks, many short ones (several per row) and a few just over half a row (one per row: forces the
@@ -175,8 +185,8 @@ def test_adapter_honours_creation_params():
 
 @needs_so
 @pytest.mark.gpu
-@pytest.mark.parametrize("variable", [0, 1])
-def test_reference_basecaller_node_drives_the_engine(variable):
+@pytest.mark.parametrize("variable,lstm_mode", [(0, None), (1, "CUTLASS_TNC_F16"), (1, None)])
+def test_reference_basecaller_node_drives_the_engine(variable, lstm_mode, monkeypatch):
     """The drop-in claim end to end: the reference's OWN BasecallerNode (read_pipeline/nodes/BasecallerNode.cpp compiled in place
     with its MessageSink / chunk / stitch sources — integration/basecaller_node_test.cpp) chunks, batches, times out, stitches;
     its runners are the HipModelRunnerAdapter objects create_hip_basecall_runners returns ([device][runner][chunk size], two
@@ -192,6 +202,14 @@ def test_reference_basecaller_node_drives_the_engine(variable):
     cfg.qscale, cfg.qbias = 1.05, -0.3
     cfg.normalise_basecaller_params()
     ws = [np.ascontiguousarray(w, np.float32) for w in synth.make_weights(cfg, seed=17)]
+    # the adapter picks the LSTM arithmetic by the reference's rule (nn/ConvStack.cpp:60-89; DORADO_LSTM_MODE overrides it):
+    # the lstm_size-256 model runs int8 unless the override says f16; this repo's own node gets the same descriptor
+    if lstm_mode is None:
+        monkeypatch.delenv("DORADO_LSTM_MODE", raising=False)
+        cfg.lstm_quant = cfg.reference_gpu_lstm_int8()
+        assert cfg.lstm_quant == bool(variable)
+    else:
+        monkeypatch.setenv("DORADO_LSTM_MODE", lstm_mode)
     lens = [300, 594, 600, 1200, 1206, 2500, 3343, 5010, 809, 4106, 7777, 12000, 312 if variable else 66]
     reads = [synth.make_signal(1, L_, seed=300 + i)[0] for i, L_ in enumerate(lens)]
     d = cfg.to_desc()

@@ -66,6 +66,23 @@ def test_library_build_id_is_the_hash_of_the_tree():
         builtins.open = saved
 
 
+def test_reference_rule_for_the_lstm_arithmetic():
+    """nn/ConvStack.cpp:60-89 get_koi_lstm_input_layout as config.reference_gpu_lstm_int8 (bench.py's headline arithmetic; the
+    adapter restates it in C++ with the DORADO_LSTM_MODE override): int8 iff the last convolution ends in tanh and
+    128 < lstm_size <= 1024, lstm_size % 128 == 0."""
+    assert config.hac_v43().reference_gpu_lstm_int8() and config.sup_v43().reference_gpu_lstm_int8()
+    assert not config.sup_v50().reference_gpu_lstm_int8()            # transformer
+    assert not config.fast_v40().reference_gpu_lstm_int8()           # lstm_size 96, swish front end
+    assert not config.tiny(128, 4).reference_gpu_lstm_int8()         # 128 is not > 128
+    for c in (256, 384, 512, 768, 1024):
+        assert config.tiny(c, 4).reference_gpu_lstm_int8()
+    sw = config.tiny(384, 4)
+    sw.convs[2].activation = config.ACT_SWISH_CLAMP
+    assert not sw.reference_gpu_lstm_int8()                          # CUTLASS_TNC_F16 for a swish front end
+    hdr = open(os.path.join(ROOT, "integration", "HipModelRunnerAdapter.h")).read()
+    assert "mibc_reference_lstm_int8" in hdr and "DORADO_LSTM_MODE" in hdr and "d.lstm_quant = mibc_reference_lstm_int8(c)" in hdr
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     if capi.device_count() > 0:
         pytest.skip("GPU present")
