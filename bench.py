@@ -27,6 +27,8 @@ configurations — BASELINE configs[4] is sup@v5 on 8 GPUs — timed with the sa
                 a model with decision margins (tests/test_gpu_baseline_parity.py: median identity vs the f32 reference >= 0.99
                 [0.9972 hac | 0.9986 sup43], device == int8 emulation of the oracle to one f16 ulp); `dtype` "i8+f16".  The f16
                 LSTM (rounds 1-5's headline) is `extra.hac_f16` / `extra.sup_v43_f16`; --quant 0 makes it the headline again.
+  identity_vs_reference   (BASELINE's metric: "basecall identity vs ref") the per-chunk identity of this arithmetic against the compiled
+                f32 reference at BASELINE size, quoted from the committed report of the GPU parity tests (profiles/r*_parity_base_*).
   parity        bench-scale output check (outside the timed region): the batch tiles 256 distinct chunks, so every
                 row must equal row i % 256, and the first rows must equal a separate small-batch call.
   cpu_baseline  the REFERENCE's own CPU path (oracle/_ref = reference sources compiled in place, libtorch CPU f32,
@@ -105,6 +107,30 @@ def bare_mfma(shape, seconds=1.0):
             res = None
     _MFMA_REF[shape] = res
     return res
+
+
+def committed_identity(model_key, quant):
+    """BASELINE.json's metric names "basecall identity vs ref": the identity of this arithmetic against the compiled f32 reference at
+    BASELINE size, as the `-m gpu` parity tests measured it on an MI355X (tests/test_gpu_baseline_parity.py writes the reports,
+    profiles/r*_parity_base_*.json are committed copies).  Quoted, not re-measured here (the reference fixtures are a CPU-minutes
+    affair); None when no report for this configuration is committed."""
+    name = {"hac": "hac", "sup": "sup43", "sup5": "sup5"}.get(model_key)
+    if name is None:
+        return None
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_parity_base_{name}{'_q8' if quant else ''}.json"))):
+        try:
+            d = json.load(open(path))
+            ci = d.get("confident_identity", {})
+            best = {"vs": "the reference's CPU path compiled in place (f32), synthetic model with decision margins" if name != "sup5"
+                          else "the reference's CPU path compiled in place (f32), random weights with CRF gain 3",
+                    "per_chunk_identity_median": d["identity_vs_reference"]["median"],
+                    "per_chunk_identity_min": d["identity_vs_reference"].get("min"),
+                    "confident_bases_called": [ci.get("matched"), ci.get("confident_ref_bases")],
+                    "source": os.path.relpath(path, ROOT)}
+        except Exception:
+            continue
+    return best
 
 
 def lstm_flops_per_launch(cfg, n, t):
@@ -418,6 +444,9 @@ def run_config(capi, synth, cfg, model_key, device, steps, warmup, batch=0, seed
                 "frac_of_bare": achieved / 1e12 / bare["tflops"]} if bare else {}),
         },
     }
+    ident = committed_identity(model_key, bool(getattr(cfg, "lstm_quant", False))) if not margin_model else None
+    if ident:
+        res["identity_vs_reference"] = ident
     if with_cpu:
         try:
             res["cpu_baseline"] = cpu_baseline(cfg, ws, t_in, cpu_kind, full=cpu_full, model_key=model_key)
@@ -529,6 +558,7 @@ def main():
             },
             "stage_ms_last_step": res["stage_ms_last_step"],
             "parity": res["parity"],
+            **({"identity_vs_reference": res["identity_vs_reference"]} if "identity_vs_reference" in res else {}),
             "network_tflops": value * network_flops_per_sample(cfg) / 1e12,
             "roofline": res["roofline"],
         }
