@@ -391,7 +391,9 @@ static int gx_col_group(const GemmArgs *a) {
 
 // 0 = launched; 1 = shape / epilogue not covered (caller uses gemm256_kernel or gemm_dma_kernel).
 extern "C" int mibc_launch_gemm256x(hipStream_t s, const GemmArgs *a) {
-    if (a->Ncols % 256 != 0 || a->M < 2048 || a->ncols_valid != 0) return 1;
+    // M >= 256 (round 6; was 2048): every batch size that fills one row tile takes THIS kernel, so a chunk's scores no longer depend on
+    // whether it was called alone (M = 1024 / 1666 rows: 32x32x16 kernels until round 5, a different summation tree) or in a batch
+    if (a->Ncols % 256 != 0 || a->M < 256 || a->ncols_valid != 0) return 1;
     if (a->K != 512 && a->K != 1024) return 1;
     if (a->epi_mode != 0 && a->epi_mode != 1) return 1;
     if (a->epi_mode == 1 && (a->rope_T % 256 != 0 || a->rope_cols % 128 != 0 || a->vT == nullptr)) return 1;
