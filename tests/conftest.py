@@ -29,6 +29,10 @@ def _library_build_ids():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     got = {}
+    try:
+        import torch  # noqa: F401  same load order as dorado_amd.capi.lib(): the library shares torch's libamdhip64 (same SONAME)
+    except Exception:  # pragma: no cover
+        pass
     for name, suffix in (("libmibc.so", ""), ("libmibc_dbg.so", "-dbg")):
         path = os.path.join(ROOT, "dorado_amd", name)
         if not os.path.exists(path):
