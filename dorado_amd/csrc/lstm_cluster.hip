@@ -146,7 +146,9 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
 
     for (int i = tid; i < 2 * 2 * 4 * 32; i += 512) {
         bias_s[i] = biascl[(size_t)j * 2 * 2 * 4 * 32 + i];
-        if (Q8) deq_s[i] = deqcl[(size_t)j * 2 * 2 * 4 * 32 + i];
+        // Q8: the dequantisation factor is stored pre-multiplied by -log2e (gates i, f, o) / -2 log2e (gate g; order [(p, hg)][gate][32]):
+        // float(acc) * deq is then the exp2 argument of the gate's sigmoid / tanh directly (as in lstm_q8.hip, round 6)
+        if (Q8) deq_s[i] = deqcl[(size_t)j * 2 * 2 * 4 * 32 + i] * ((((i >> 5) & 3) == 2) ? -2.88539008f : -1.44269504f);
     }
     LDSP(half_t) patch = patch_all + wave * CL_PATCH;
     LDSP(unsigned char) qpatch = (LDSP(unsigned char))patch;   // same memory: the f16 rows (if any) have left before the int8 rows are written
@@ -258,53 +260,145 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
             // Q8: the int8 rows (the layer output when Q8 == 1, the exchange copy Hx when Q8 == 2)
             const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
                     (void *)((Q8 == 2 ? Hx : (signed char *)Xout) + ((size_t)gt * N + n0 + rgw * 64) * C + hcol), 0, 64 * C, 0x00020000);
+            // (1) the arithmetic of all 32 elements of the lane — 8 independent (batch block, hidden block) groups of 4, so that the
+            //     scheduler has dependent chains to interleave (the matrix pipe idles while a wave is here: the chains' latency, not
+            //     the instruction count, is what this costs) — results kept as f16 quads / int8 quads; (2) the rows leave through the
+            //     wave's patch, 32 batch rows at a time.
+            half4_t hvv[4][2];
+            int pkq[4][2];
+            // f16 instance — staged and software-pipelined by hand: the straight-line form leaves hipcc working on two elements at a time
+            // (exp -> add -> rcp chains back to back).  Per block of 4 hidden units x 4 gates: 16 independent exp2 arguments, then
+            // 16 v_exp_f32, 16 adds, 16 v_rcp_f32 (stage 1); the cell update and its own exp / rcp (stage 2) of block n is issued behind
+            // stage 1 of block n + 1.  Same operations per element, same results; same-box A/B: f16 LSTM stack 947.4 -> 935.3 ms.
+            float r1[2][4][4];                     // [buffer][gate][e]: sigmoid / (tanh + 1) / 2 of the four gates
+            auto stage1 = [&](int blk, float (&r)[4][4]) __attribute__((always_inline)) {
+                const int bb = blk >> 1, hb = blk & 1;
+                float x[4][4];
+                if (Q8) {
+                    float4_t dq[4];
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {          // 32 batch rows at a time through the wave's patch
-                int pkq[2][2] = {{0, 0}, {0, 0}};
+                    for (int g = 0; g < 4; ++g) dq[g] = *(LDSP(const float4_t))(deq_s + ((gp * 2 + hg) * 4 + g) * 32 + hb * 16 + 4 * lq);
 #pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2) {
-                    const int bb = rt * 2 + b2;
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[g][e] = (float)acq[g][hb][bb][e] * dq[g][e];     // pre-scaled: the exp2 argument
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[g][e] = acc[g][hb][bb][e] * (g == 2 ? -2.88539008f : -1.44269504f);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[g][e] = __builtin_amdgcn_exp2f(x[g][e]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[g][e] = 1.0f + x[g][e];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[g][e] = __builtin_amdgcn_rcpf(x[g][e]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto stage2 = [&](int blk, const float (&r)[4][4]) __attribute__((always_inline)) {
+                const int bb = blk >> 1, hb = blk & 1;
+                const bool rowon = !MASKED || ((gvm >> (bb * 16 + l15)) & 1ull);
+                float4_t cn;
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gg = fmaf(2.0f, r[2][e], -1.0f);
+                    cn[e] = fmaf(r[1][e], cpre[bb][hb][e], r[0][e] * gg);
+                    t[e] = __builtin_amdgcn_exp2f(cn[e] * -2.88539008f);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __builtin_amdgcn_rcpf(1.0f + t[e]);
+                half4_t hv;
+                int pk = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float hval = r[3][e] * fmaf(2.0f, t[e], -1.0f);
+                    if (MASKED && !rowon) {
+                        cn[e] = 0.0f;
+                        hval = 0.0f;
+                    }
+                    hv[e] = (half_t)hval;
+                    if (Q8) pk |= ((int)__builtin_rintf(hval * 127.0f) & 0xff) << (8 * e);
+                }
+                *((float4_t *)(cbuf + ((((((size_t)cl * KCL + j) * 2 + gp) * 8 + wave) * 4 + bb) * 2 + hb) * 256) + lane) = cn;
+                hvv[bb][hb] = hv;
+                pkq[bb][hb] = pk;
+            };
+            if (DBG & 1) {
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {
+                        half4_t hv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            hv[e] = (half_t)(1e-3f * (Q8 ? (float)(acq[0][hb][bb][e] + acq[1][hb][bb][e] + acq[2][hb][bb][e] + acq[3][hb][bb][e])
+                                                         : (acc[0][hb][bb][e] + acc[1][hb][bb][e] + acc[2][hb][bb][e] + acc[3][hb][bb][e])));
+                        *((float4_t *)(cbuf + ((((((size_t)cl * KCL + j) * 2 + gp) * 8 + wave) * 4 + bb) * 2 + hb) * 256) + lane) = cpre[bb][hb];
+                        hvv[bb][hb] = hv;
+                        pkq[bb][hb] = 0;
+                    }
+            } else if (Q8) {
+                // int8 instances: the straight-line form (the staged one spills 18 registers here and measured 1 % slower,
+                // profiles/r06_s_cl_gates_staged_ab.log)
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
                     const bool rowon = !MASKED || ((gvm >> (bb * 16 + l15)) & 1ull);
 #pragma unroll
                     for (int hb = 0; hb < 2; ++hb) {
                         half4_t hv;
                         float4_t cn;
-                        float4_t dq[4];      // Q8: dequantisation factors of this lane's 4 hidden units, per gate
-                        int pk = 0;          // Q8: round(127 h) of the 4 units, one byte each
-                        if (Q8) {
+                        float4_t dq[4];      // dequantisation factors of this lane's 4 hidden units, per gate (pre-scaled: exp2 arguments)
+                        int pk = 0;          // round(127 h) of the 4 units, one byte each
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) dq[g] = *(LDSP(const float4_t))(deq_s + ((gp * 2 + hg) * 4 + g) * 32 + hb * 16 + 4 * lq);
-                        }
+                        for (int g = 0; g < 4; ++g) dq[g] = *(LDSP(const float4_t))(deq_s + ((gp * 2 + hg) * 4 + g) * 32 + hb * 16 + 4 * lq);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float c, hval;
-                            if (DBG & 1) {
-                                c = cpre[bb][hb][e];
-                                hval = 1e-3f * (acc[0][hb][bb][e] + acc[1][hb][bb][e] + acc[2][hb][bb][e] + acc[3][hb][bb][e]);
-                            } else {
-                                const float p0 = Q8 ? (float)acq[0][hb][bb][e] * dq[0][e] : acc[0][hb][bb][e];
-                                const float p1 = Q8 ? (float)acq[1][hb][bb][e] * dq[1][e] : acc[1][hb][bb][e];
-                                const float p2 = Q8 ? (float)acq[2][hb][bb][e] * dq[2][e] : acc[2][hb][bb][e];
-                                const float p3 = Q8 ? (float)acq[3][hb][bb][e] * dq[3][e] : acc[3][hb][bb][e];
-                                const float ig = fast_sigmoid(p0);
-                                const float fg = fast_sigmoid(p1);
-                                const float gg = fast_tanh(p2);
-                                const float og = fast_sigmoid(p3);
-                                c = fmaf(fg, cpre[bb][hb][e], ig * gg);
-                                hval = og * fast_tanh(c);
-                            }
+                            const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((float)acq[0][hb][bb][e] * dq[0][e]));
+                            const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((float)acq[1][hb][bb][e] * dq[1][e]));
+                            const float gg = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((float)acq[2][hb][bb][e] * dq[2][e])), -1.0f);
+                            const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((float)acq[3][hb][bb][e] * dq[3][e]));
+                            float c = fmaf(fg, cpre[bb][hb][e], ig * gg);
+                            float hval = og * fast_tanh(c);
                             if (MASKED && !rowon) {
                                 c = 0.0f;
                                 hval = 0.0f;
                             }
                             cn[e] = c;
                             hv[e] = (half_t)hval;
-                            if (Q8) pk |= ((int)__builtin_rintf(hval * 127.0f) & 0xff) << (8 * e);
+                            pk |= ((int)__builtin_rintf(hval * 127.0f) & 0xff) << (8 * e);
                         }
                         *((float4_t *)(cbuf + ((((((size_t)cl * KCL + j) * 2 + gp) * 8 + wave) * 4 + bb) * 2 + hb) * 256) + lane) = cn;
-                        if (Q8 != 1) *(LDSP(half4_t))(patch + (b2 * 16 + l15) * CL_PATCH_LD + hb * 16 + 4 * lq) = hv;
-                        if (Q8) pkq[b2][hb] = pk;
+                        hvv[bb][hb] = hv;
+                        pkq[bb][hb] = pk;
                     }
+                }
+            } else {
+                stage1(0, r1[0]);
+#pragma unroll
+                for (int blk = 0; blk < 8; ++blk) {
+                    if (blk + 1 < 8) stage1(blk + 1, r1[(blk + 1) & 1]);
+                    stage2(blk, r1[blk & 1]);
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {          // 32 batch rows at a time through the wave's patch
+                if (Q8 != 1) {
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                        for (int hb = 0; hb < 2; ++hb)
+                            *(LDSP(half4_t))(patch + (b2 * 16 + l15) * CL_PATCH_LD + hb * 16 + 4 * lq) = hvv[rt * 2 + b2][hb];
                 }
                 __builtin_amdgcn_wave_barrier();   // same wave: LDS operations execute in order
                 if (Q8 != 1) {
@@ -322,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void lstm_layer_cl_kernel(
 #pragma unroll
                     for (int b2 = 0; b2 < 2; ++b2)
 #pragma unroll
-                        for (int hb = 0; hb < 2; ++hb) *(LDSP(int))(qpatch + (b2 * 16 + l15) * CL_QPATCH_LD + hb * 16 + 4 * lq) = pkq[b2][hb];
+                        for (int hb = 0; hb < 2; ++hb) *(LDSP(int))(qpatch + (b2 * 16 + l15) * CL_QPATCH_LD + hb * 16 + 4 * lq) = pkq[rt * 2 + b2][hb];
                     __builtin_amdgcn_wave_barrier();
                     const int prow = lane >> 1, seg = lane & 1;
                     const int4q_t v = *(LDSP(const int4q_t))(qpatch + prow * CL_QPATCH_LD + seg * 16);
@@ -569,6 +663,22 @@ extern "C" int mibc_launch_lstm_layer_cl(hipStream_t s, int C, const half_t *Xin
         if (tmask != nullptr) CL_LAUNCH_Q8M(CC, Q_, true);    \
         else CL_LAUNCH_Q8M(CC, Q_, false);                    \
     } while (0)
+#ifdef MIBC_DEBUG_KERNELS
+    // (debug library: timing ablations of the int8 -> int8 instance, MIBC_CL_DBG as for the f16 one; results are wrong)
+    if (q8 == 1 && C == 1024 && tmask == nullptr) {
+        static const int dbgq = MIBC_ENV_INT("MIBC_CL_DBG", 0);
+#define CL_DBGQ(D_)                                                                                         \
+    case D_: {                                                                                              \
+        (void)hipFuncSetAttribute((const void *)lstm_layer_cl_kernel<1024, false, D_, 1>,                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, CL_LDS_BYTES);                \
+        hipLaunchKernelGGL((lstm_layer_cl_kernel<1024, false, D_, 1>), grid, dim3(512), CL_LDS_BYTES, s, Xin, \
+                           Xout, Wt, biascl, zeros, cbuf, flags, err, T, N, reverse, cpx, resident, tmask, deqcl, hx); \
+        return 0;                                                                                           \
+    }
+        switch (dbgq) { CL_DBGQ(1) CL_DBGQ(8) CL_DBGQ(32) CL_DBGQ(64) CL_DBGQ(96) default: break; }
+#undef CL_DBGQ
+    }
+#endif
     if (q8 == 1) {
         switch (C) {
             case 512: CL_LAUNCH_Q8(512, 1); return 0;
