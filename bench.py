@@ -25,7 +25,7 @@ configurations — BASELINE configs[4] is sup@v5 on 8 GPUs — timed with the sa
   lstm_arith    (round 6) the LSTM stack of the tanh-conv LSTM models runs in int8 — the reference's own GPU arithmetic for
                 them (dorado/nn/ConvStack.cpp:69-73, nn/LSTMStack.cpp:127-211) — now that the path has a STATED identity bound on
                 a model with decision margins (tests/test_gpu_baseline_parity.py: median identity vs the f32 reference >= 0.99
-                [0.9972 hac | 0.9986 sup43], device == int8 emulation of the oracle to one f16 ulp); `dtype` "i8+f16".  The f16
+                [0.9972 hac | 0.9980 sup43], device == int8 emulation of the oracle to one f16 ulp); `dtype` "i8+f16".  The f16
                 LSTM (rounds 1-5's headline) is `extra.hac_f16` / `extra.sup_v43_f16`; --quant 0 makes it the headline again.
   identity_vs_reference   (BASELINE's metric: "basecall identity vs ref") the per-chunk identity of this arithmetic against the compiled
                 f32 reference at BASELINE size, quoted from the committed report of the GPU parity tests (profiles/r*_parity_base_*).
