@@ -141,7 +141,8 @@ class ModelConfig:
     signal_norm: SignalNorm = dataclasses.field(default_factory=SignalNorm)
     sample_type: str = "DNA"            # models::SampleType: "DNA" | "RNA002" | "RNA004" (run_info.sample_type or the model name)
     mean_qscore_start_pos: int = -1     # qscore.mean_qscore_start_pos, else 60 (BasecallModelConfig.cpp:23-39)
-    lstm_quant: bool = False   # opt-in: the reference's int8 LSTM path (nn/LSTMStack.cpp:127-211), csrc/lstm_q8.hip
+    lstm_quant: bool = False   # the reference's int8 LSTM path (nn/LSTMStack.cpp:127-211; csrc/lstm_q8.hip, int8 cluster kernel); bench.py and the
+                               # adapter set it by the reference's own rule (reference_gpu_lstm_int8 below); False = f16 throughout
     # synthetic weights only (dorado_amd/synth.py; no effect on a loaded model): gain on the transformer's CRF projection.
     # With gain 1 the random-init sup@v5 model calls NO base with q >= 10 (nothing discriminating to compare identities
     # on); gain 3 gives decision margins: 48 % of the reference's bases at q >= 10, 18 % at q >= 20 (scores +-27).
