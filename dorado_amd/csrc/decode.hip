@@ -628,8 +628,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
     constexpr int A_SC = 0;                              // half_t sc_row[K]
     constexpr int A_BG = A_SC + K * 2;                   // float bg_row[S]
     constexpr int A_CS = A_BG + S * 4;                   // float c_score[BS_CAND]     steps 4e + b, stays STAY0 + e
-    constexpr int A_CH = A_CS + BS_CAND * 4;             // uint32 c_hash[BS_CAND]     steps b * 32 + e (base-major), stays STAY0 + e
-    constexpr int A_CM = A_CH + BS_CAND * 4;             // uint32 c_meta[BS_CAND]     as c_score
+    // hash rows of the four newest bases lie HROW = 36 words apart (round 6; was 32): the merge test reads the row of the lane's own
+    // base with ds_read_b128, and rows 128 B apart put bases 0 / 2 and 1 / 3 on the same bank quads (SQ_LDS_BANK_CONFLICT 0.12 of this
+    // kernel's cycles, profiles/r06_j_pmc_clock_hac_q8_n16384.json); 144 B apart the four rows touch four different quads
+    constexpr int HROW = BS_MAXW + 4;
+    constexpr int HSTAY = 4 * HROW;                      // first stay hash
+    constexpr int A_CH = A_CS + BS_CAND * 4;             // uint32 c_hash[4 * HROW + W]  steps b * HROW + e (base-major), stays HSTAY + e
+    constexpr int A_CM = A_CH + (4 * HROW + BS_MAXW) * 4;   // uint32 c_meta[BS_CAND]     as c_score
     // tag[] (merge phase) and the new front n_*[] (compaction -> top of the next block) are only alive while the score row is
     // dead (it is read by the expansion alone and rewritten from registers at the top of a block, after the front has been
     // loaded), so for K >= 448 they live inside it; the accesses are LDS operations of ONE wave, which execute in order
@@ -719,7 +724,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
     for (int i = 0; i < GPL; ++i) rg[i] = bn[(size_t)S + i * 64 + lane];
 
     // slot -> hash index of this lane's three compaction slots (steps are base-major)
-    const int hidx0 = (lane & 3) * BS_MAXW + (lane >> 2), hidx1 = hidx0 + 16;
+    const int hidx0 = (lane & 3) * HROW + (lane >> 2), hidx1 = hidx0 + 16;
     const uint32_t prev16 = (uint32_t)e << 16;
 
     for (int blk = 0; blk < T; ++blk) {
@@ -751,15 +756,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
             const float sc0 = (p_score + clampf((float)sc_row[mi0], clampv)) + bg[0];
             const float sc1 = (p_score + clampf((float)sc_row[mi0 + 4], clampv)) + bg[1];
             *(f32x2 *)(c_score + 4 * e + b0) = f32x2{sc0, sc1};
-            c_hash[b0 * BS_MAXW + e] = crc32c_bits(p_hash, b0, 2);
-            c_hash[(b0 + 1u) * BS_MAXW + e] = crc32c_bits(p_hash, b0 + 1u, 2);
+            c_hash[b0 * HROW + e] = crc32c_bits(p_hash, b0, 2);
+            c_hash[(b0 + 1u) * HROW + e] = crc32c_bits(p_hash, b0 + 1u, 2);
             *(u32x2 *)(c_meta + 4 * e + b0) = u32x2{ns0 | prev16, ns0 | 1u | prev16};
             *(u32x2 *)(tag + 4 * e + b0) = u32x2{0xffffffffu, 0xffffffffu};
             my_max = fmaxf(sc0, sc1);
             if (hf == 0) {
                 stay_sc = (p_score + stay) + bg_row[p_state];
                 c_score[STAY0 + e] = stay_sc;
-                c_hash[STAY0 + e] = p_hash;
+                c_hash[HSTAY + e] = p_hash;
                 c_meta[STAY0 + e] = p_state | prev16 | (1u << 24);
                 my_max = fmaxf(my_max, stay_sc);
             }
@@ -771,7 +776,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
         const int lb = p_state & 3;
         uint32_t mm;
         {
-            const u32x4 *hrow = (const u32x4 *)(c_hash + lb * BS_MAXW + 16 * hf);
+            const u32x4 *hrow = (const u32x4 *)(c_hash + lb * HROW + 16 * hf);
             const u32x4 q0 = hrow[0], q1 = hrow[1], q2 = hrow[2], q3 = hrow[3];
             uint32_t m16 = 0;
             BS_MATCH4(m16, q3[3], q3[2], q3[1], q3[0], p_hash)
@@ -885,7 +890,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void be
             const int i2 = (int)__builtin_amdgcn_mbcnt_lo((uint32_t)k2, b2);     // k2 has no bit above 31
             if (__builtin_amdgcn_inverse_ballot_w64(k2) && i2 < W) {
                 n_score[i2] = cs2;
-                n_hash[i2] = c_hash[STAY0 + lane];
+                n_hash[i2] = c_hash[HSTAY + lane];
                 n_meta[i2] = c_meta[STAY0 + lane];
             }
         }
