@@ -1,11 +1,11 @@
 #!/bin/bash
 # One GPU-box call that regenerates what profiles/ holds for the GPU configurations of BASELINE.json (+ the opt-in int8 LSTM runs).
-# usage (on the GPU box): bash tools/refresh_profiles.sh <tag>      e.g. r05_j          (STEPS="bench stats pmc" selects parts)
+# usage (on the GPU box): bash tools/refresh_profiles.sh <tag>      e.g. r06_j          (STEPS="bench stats pmc" selects parts)
 #   <tag>_bench.json                         the default bench.py line (hac headline + extra.*)
 #   <tag>_kernel_stats_<model>_n<N>.csv      rocprofv3 --kernel-trace --stats of bench.py --model <model> [--quant 1] --profile-run
 #   <tag>_pmc_traffic_<model>_n<N>.json      HBM bytes per launch (separate FETCH_SIZE / WRITE_SIZE passes, --kernel-trace only)
 set -u
-TAG=${1:-r05_x}
+TAG=${1:-r06_x}
 STEPS=${STEPS:-"bench stats pmc"}
 SPECS=${SPECS:-"hac:0:16384:9996 sup:0:8192:9996 sup5:0:1024:12288 hac:1:16384:9996 sup:1:8192:9996"}
 R=$GRAFT_REPO_ROOT
